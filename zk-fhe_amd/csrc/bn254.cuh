@@ -1,0 +1,421 @@
+// BN254 field and curve arithmetic for gfx950 (host + device).
+//
+// Replaces, for the GPU hot path, what the reference gets from the un-vendored
+// halo2curves crate (`bn256::{Fr,Fq,G1Affine,G1}`; reference call sites
+// src/poly_chip.rs:5-10,90 and examples/bfv.rs:1-6 -- SURVEY.md section 8a/8b):
+//   * Fr / Fq: 256-bit Montgomery residues, R = 2^256, canonical (< p) at rest.
+//     ABI layout = 4 x uint64 little-endian limbs == 8 x uint32 little-endian limbs.
+//   * G1: y^2 = x^3 + 3 over Fq.  Affine {x,y} (identity = (0,0)), and the XYZZ
+//     extended-Jacobian form used for accumulation (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2).
+//
+// Device arithmetic is on 32-bit limbs: gfx950 has no 64x64 multiplier; the widest
+// integer multiply is v_mad_u64_u32 (32x32+64 -> 64), which the CIOS loops below map to.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#else
+#define ZK_HD inline
+#endif
+
+namespace zk {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct FrP {
+  static constexpr u32 MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr u32 ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod p
+  static constexpr u32 R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+  static constexpr u32 INV = 0xefffffffu;  // -p^-1 mod 2^32
+};
+
+struct FqP {
+  static constexpr u32 MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr u32 ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr u32 R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+  static constexpr u32 INV = 0xe4866389u;
+};
+
+template <class P>
+struct alignas(16) Fp {
+  u32 l[8];
+
+  static ZK_HD Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = 0;
+    return r;
+  }
+  static ZK_HD Fp one() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = P::ONE[i];
+    return r;
+  }
+  static ZK_HD Fp r2() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = P::R2[i];
+    return r;
+  }
+  ZK_HD bool is_zero() const {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= l[i];
+    return o == 0;
+  }
+  ZK_HD bool operator==(const Fp& b) const {
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= l[i] ^ b.l[i];
+    return o == 0;
+  }
+  ZK_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = a - p if a >= p (a < 2p).
+template <class P>
+ZK_HD void fp_reduce_once(u32 (&a)[8]) {
+  u32 t[8];
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 d = (u64)a[i] - P::MOD[i] - br;
+    t[i] = (u32)d;
+    br = (d >> 32) & 1;
+  }
+  if (br == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = t[i];
+  }
+}
+
+template <class P>
+ZK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (u64)a.l[i] + b.l[i];
+    r.l[i] = (u32)c;
+    c >>= 32;
+  }
+  // p < 2^254 so a+b < 2^255: no carry out of limb 7.
+  fp_reduce_once<P>(r.l);
+  return r;
+}
+
+template <class P>
+ZK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 d = (u64)a.l[i] - b.l[i] - br;
+    r.l[i] = (u32)d;
+    br = (d >> 32) & 1;
+  }
+  u32 mask = (u32)0 - (u32)br;  // all ones when a < b: add p back
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (u64)r.l[i] + (P::MOD[i] & mask);
+    r.l[i] = (u32)c;
+    c >>= 32;
+  }
+  return r;
+}
+
+template <class P>
+ZK_HD Fp<P> fp_neg(const Fp<P>& a) {
+  if (a.is_zero()) return a;
+  Fp<P> r;
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 d = (u64)P::MOD[i] - a.l[i] - br;
+    r.l[i] = (u32)d;
+    br = (d >> 32) & 1;
+  }
+  return r;
+}
+
+template <class P>
+ZK_HD Fp<P> fp_dbl(const Fp<P>& a) {
+  return fp_add<P>(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.
+// Every partial product is one 32x32+64 multiply-add (v_mad_u64_u32 on gfx950).
+// Bounds: p < 2^254, so the running value stays < 2p < 2^255 after each outer
+// iteration and the 9-limb window t[0..8] never overflows.
+template <class P>
+ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+  u32 t[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 c = 0;
+    const u32 bi = b.l[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c = (u64)a.l[j] * bi + ((u64)t[j] + c);
+      t[j] = (u32)c;
+      c >>= 32;
+    }
+    t[8] += (u32)c;
+    const u32 m = t[0] * P::INV;
+    c = ((u64)m * P::MOD[0] + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      c = (u64)m * P::MOD[j] + ((u64)t[j] + c);
+      t[j - 1] = (u32)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[7] = (u32)c;
+    t[8] = (u32)(c >> 32);
+  }
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = t[i];
+  fp_reduce_once<P>(r.l);
+  return r;
+}
+
+template <class P>
+ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
+  return fp_mul<P>(a, a);
+}
+
+// Montgomery form <-> canonical integer.
+template <class P>
+ZK_HD Fp<P> fp_to_mont(const Fp<P>& a) {
+  return fp_mul<P>(a, Fp<P>::r2());
+}
+template <class P>
+ZK_HD Fp<P> fp_from_mont(const Fp<P>& a) {
+  Fp<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.l[i] = (i == 0) ? 1u : 0u;
+  return fp_mul<P>(a, o);
+}
+
+// a^e for a 256-bit exponent given as 8 little-endian u32 words (not secret: vartime).
+template <class P>
+ZK_HD Fp<P> fp_pow(const Fp<P>& a, const u32 (&e)[8]) {
+  Fp<P> r = Fp<P>::one();
+  bool started = false;
+  for (int i = 255; i >= 0; --i) {
+    if (started) r = fp_sqr<P>(r);
+    if ((e[i >> 5] >> (i & 31)) & 1) {
+      r = started ? fp_mul<P>(r, a) : a;
+      started = true;
+    }
+  }
+  return r;
+}
+
+// a^-1 = a^(p-2); 0 -> 0 (the halo2 `invert().unwrap_or(0)` convention used by batch_invert).
+template <class P>
+ZK_HD Fp<P> fp_inv(const Fp<P>& a) {
+  u32 e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = P::MOD[i];
+  e[0] -= 2;  // low limb of both moduli is >= 2
+  return fp_pow<P>(a, e);
+}
+
+typedef Fp<FrP> Fr;
+typedef Fp<FqP> Fq;
+
+ZK_HD Fr operator+(const Fr& a, const Fr& b) { return fp_add<FrP>(a, b); }
+ZK_HD Fr operator-(const Fr& a, const Fr& b) { return fp_sub<FrP>(a, b); }
+ZK_HD Fr operator*(const Fr& a, const Fr& b) { return fp_mul<FrP>(a, b); }
+ZK_HD Fq operator+(const Fq& a, const Fq& b) { return fp_add<FqP>(a, b); }
+ZK_HD Fq operator-(const Fq& a, const Fq& b) { return fp_sub<FqP>(a, b); }
+ZK_HD Fq operator*(const Fq& a, const Fq& b) { return fp_mul<FqP>(a, b); }
+
+// ---------------------------------------------------------------------------
+// G1
+// ---------------------------------------------------------------------------
+struct G1Affine {  // 64 B; identity encoded as (0,0) (halo2curves convention)
+  Fq x, y;
+  ZK_HD bool is_identity() const { return x.is_zero() && y.is_zero(); }
+};
+
+struct G1Jac {  // 96 B, ABI output form {X,Y,Z}: x = X/Z^2, y = Y/Z^3, identity Z = 0
+  Fq x, y, z;
+};
+
+struct G1X {  // XYZZ accumulator, 128 B; identity zz = zzz = 0
+  Fq x, y, zz, zzz;
+  static ZK_HD G1X identity() {
+    G1X r;
+    r.x = Fq::zero();
+    r.y = Fq::zero();
+    r.zz = Fq::zero();
+    r.zzz = Fq::zero();
+    return r;
+  }
+  ZK_HD bool is_identity() const { return zz.is_zero(); }
+};
+
+// 2*P for affine P (not identity) -> XYZZ   (EFD "mdbl-2008-s-1")
+ZK_HD G1X g1x_from_affine_dbl(const G1Affine& p) {
+  G1X r;
+  Fq u = fp_dbl<FqP>(p.y);
+  Fq v = fp_sqr<FqP>(u);
+  Fq w = u * v;
+  Fq s = p.x * v;
+  Fq xx = fp_sqr<FqP>(p.x);
+  Fq m = fp_add<FqP>(fp_dbl<FqP>(xx), xx);  // a = 0
+  r.x = fp_sqr<FqP>(m) - fp_dbl<FqP>(s);
+  r.y = m * (s - r.x) - w * p.y;
+  r.zz = v;
+  r.zzz = w;
+  return r;
+}
+
+ZK_HD G1X g1x_from_affine(const G1Affine& p) {
+  G1X r;
+  if (p.is_identity()) return G1X::identity();
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = Fq::one();
+  r.zzz = Fq::one();
+  return r;
+}
+
+// 2*P in XYZZ  (EFD "dbl-2008-s-1")
+ZK_HD G1X g1x_dbl(const G1X& p) {
+  if (p.is_identity()) return p;
+  G1X r;
+  Fq u = fp_dbl<FqP>(p.y);
+  Fq v = fp_sqr<FqP>(u);
+  Fq w = u * v;
+  Fq s = p.x * v;
+  Fq xx = fp_sqr<FqP>(p.x);
+  Fq m = fp_add<FqP>(fp_dbl<FqP>(xx), xx);
+  r.x = fp_sqr<FqP>(m) - fp_dbl<FqP>(s);
+  r.y = m * (s - r.x) - w * p.y;
+  r.zz = v * p.zz;
+  r.zzz = w * p.zzz;
+  return r;
+}
+
+// acc += (neg ? -q : q), q affine  (EFD "madd-2008-s", with the doubling / cancel cases)
+ZK_HD void g1x_add_affine(G1X& acc, const G1Affine& q, bool neg) {
+  if (q.is_identity()) return;
+  Fq qy = neg ? fp_neg<FqP>(q.y) : q.y;
+  if (acc.is_identity()) {
+    acc.x = q.x;
+    acc.y = qy;
+    acc.zz = Fq::one();
+    acc.zzz = Fq::one();
+    return;
+  }
+  Fq u2 = q.x * acc.zz;
+  Fq s2 = qy * acc.zzz;
+  Fq p = u2 - acc.x;
+  Fq r = s2 - acc.y;
+  if (p.is_zero()) {
+    if (r.is_zero()) {
+      G1Affine t;
+      t.x = q.x;
+      t.y = qy;
+      acc = g1x_from_affine_dbl(t);
+    } else {
+      acc = G1X::identity();
+    }
+    return;
+  }
+  Fq pp = fp_sqr<FqP>(p);
+  Fq ppp = p * pp;
+  Fq qq = acc.x * pp;
+  Fq x3 = fp_sqr<FqP>(r) - ppp - fp_dbl<FqP>(qq);
+  acc.y = r * (qq - x3) - acc.y * ppp;
+  acc.x = x3;
+  acc.zz = acc.zz * pp;
+  acc.zzz = acc.zzz * ppp;
+}
+
+// acc += q, both XYZZ  (EFD "add-2008-s")
+ZK_HD void g1x_add(G1X& acc, const G1X& q) {
+  if (q.is_identity()) return;
+  if (acc.is_identity()) {
+    acc = q;
+    return;
+  }
+  Fq u1 = acc.x * q.zz;
+  Fq u2 = q.x * acc.zz;
+  Fq s1 = acc.y * q.zzz;
+  Fq s2 = q.y * acc.zzz;
+  Fq p = u2 - u1;
+  Fq r = s2 - s1;
+  if (p.is_zero()) {
+    if (r.is_zero()) {
+      acc = g1x_dbl(acc);
+    } else {
+      acc = G1X::identity();
+    }
+    return;
+  }
+  Fq pp = fp_sqr<FqP>(p);
+  Fq ppp = p * pp;
+  Fq qq = u1 * pp;
+  Fq x3 = fp_sqr<FqP>(r) - ppp - fp_dbl<FqP>(qq);
+  acc.y = r * (qq - x3) - s1 * ppp;
+  acc.x = x3;
+  acc.zz = acc.zz * q.zz * pp;
+  acc.zzz = acc.zzz * q.zzz * ppp;
+}
+
+ZK_HD G1X g1x_neg(const G1X& p) {
+  G1X r = p;
+  r.y = fp_neg<FqP>(p.y);
+  return r;
+}
+
+// XYZZ -> affine (one field inversion); identity -> (0,0)
+ZK_HD G1Affine g1x_to_affine(const G1X& p) {
+  G1Affine r;
+  if (p.is_identity()) {
+    r.x = Fq::zero();
+    r.y = Fq::zero();
+    return r;
+  }
+  Fq izzz = fp_inv<FqP>(p.zzz);       // 1/ZZZ
+  Fq izz = fp_sqr<FqP>(izzz * p.zz);  // (ZZ/ZZZ)^2 = 1/ZZ  (since ZZ^3 = ZZZ^2)
+  r.x = p.x * izz;
+  r.y = p.y * izzz;
+  return r;
+}
+
+// XYZZ -> Jacobian {X,Y,Z} with Z = ZZZ/ZZ:  X_j = x Z^2 = X*ZZZ^2/ZZ^3 ... use affine-free map:
+// take Z = ZZ (then Z^2 = ZZ^2, Z^3 = ZZ^3 = ZZZ^2):  X_j = X*ZZ, Y_j = Y*ZZZ.
+ZK_HD G1Jac g1x_to_jac(const G1X& p) {
+  G1Jac r;
+  if (p.is_identity()) {
+    r.x = Fq::zero();
+    r.y = Fq::one();
+    r.z = Fq::zero();
+    return r;
+  }
+  r.x = p.x * p.zz;
+  r.y = p.y * p.zzz;
+  r.z = p.zz;
+  return r;
+}
+
+}  // namespace zk
