@@ -1,0 +1,138 @@
+/* zkfhe.h -- C ABI of the MI355X (gfx950) backend for zk-fhe's BFV-proof hot path.
+ *
+ * The reference (enricobottazzi/zk-fhe) is a Rust crate with no FFI of its own; its prover hot loops
+ * live in third-party crates reached through the single call `run_eth(bfv_encryption_circuit, args)`
+ * (reference examples/bfv.rs:311).  Each entry point below names the Rust seam it replaces -- the
+ * function a maintainer would re-route through `extern "C"` (binding stubs: INTEGRATION.md):
+ *
+ *   zkfhe_ntt_batch        <- halo2_proofs::arithmetic::best_fft(&mut [Fr], omega, log_n) and
+ *                             poly::EvaluationDomain::{lagrange_to_coeff, coeff_to_lagrange}
+ *   zkfhe_coset_ntt_batch  <- EvaluationDomain::{coeff_to_extended, extended_to_coeff}
+ *   zkfhe_basis_create     <- poly::kzg::commitment::ParamsKZG {g, g_lagrange} (the SRS halves)
+ *   zkfhe_msm_batch        <- arithmetic::best_multiexp(&[Fr], &[G1Affine]) as used by
+ *                             ParamsKZG::{commit, commit_lagrange}
+ *   zkfhe_fr_*             <- the coefficient-wise Fr mul/add/sub loops of `parallelize(...)` bodies
+ *                             (and src/poly_chip.rs:122-174 add / scalar_mul witness values)
+ *   zkfhe_fr_batch_invert  <- ff::BatchInvert / halo2 `batch_invert_assigned`
+ *   zkfhe_witness_*        <- the per-coefficient witness loops of src/poly_chip.rs:226-252
+ *                             (reduce_by_modulo -> RangeChip::div_mod) and src/poly.rs:75-191
+ *
+ * Data layouts (identical to halo2curves' in-memory representation):
+ *   Fr, Fq      4 x uint64_t little-endian limbs, Montgomery form with R = 2^256, value < p.
+ *   G1 affine   {Fq x, Fq y} = 64 bytes; the identity is (0, 0).
+ * Conventions: every call returns 0 on success or a negative ZKFHE_E* code and never throws or aborts
+ * across the ABI; zkfhe_last_error() gives the message.  `*_dev` pointers are device (HBM) addresses
+ * obtained from zkfhe_dev_alloc (or any hipMalloc'd buffer of the same process); everything else is
+ * host memory.  One context per GPU; calls on one context are ordered on its stream and are
+ * asynchronous with respect to the host unless stated (zkfhe_sync / zkfhe_download wait).
+ * There is no CPU fallback: without the HIP runtime and a gfx950 device zkfhe_ctx_create fails.
+ */
+#ifndef ZKFHE_H
+#define ZKFHE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKFHE_OK 0
+#define ZKFHE_EINVAL (-1)   /* bad argument */
+#define ZKFHE_EHIP (-2)     /* HIP runtime error (message in zkfhe_last_error) */
+#define ZKFHE_ENOMEM (-3)
+#define ZKFHE_ENODEV (-4)   /* no usable gfx950 device */
+
+typedef struct zkfhe_ctx zkfhe_ctx;
+typedef struct zkfhe_basis zkfhe_basis;
+
+typedef struct { uint64_t l[4]; } zkfhe_fr;
+typedef struct { uint64_t l[4]; } zkfhe_fq;
+typedef struct { zkfhe_fq x, y; } zkfhe_g1_affine;
+
+/* ---- context / memory -------------------------------------------------------------------- */
+/* hip_stream: an existing hipStream_t to run on, or NULL to let the context create its own. */
+int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out);
+int zkfhe_ctx_destroy(zkfhe_ctx *ctx);
+const char *zkfhe_last_error(const zkfhe_ctx *ctx);   /* ctx may be NULL: last creation error */
+int zkfhe_sync(zkfhe_ctx *ctx);
+void *zkfhe_stream(zkfhe_ctx *ctx);                   /* the hipStream_t the context launches on */
+int zkfhe_device_info(zkfhe_ctx *ctx, char *arch_name, size_t arch_len, int *num_cu, size_t *hbm_bytes);
+
+int zkfhe_dev_alloc(zkfhe_ctx *ctx, size_t bytes, void **dptr);
+int zkfhe_dev_free(zkfhe_ctx *ctx, void *dptr);
+int zkfhe_upload(zkfhe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);     /* waits */
+int zkfhe_download(zkfhe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* waits */
+int zkfhe_copy_dev(zkfhe_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+int zkfhe_memset_dev(zkfhe_ctx *ctx, void *dst_dev, int byte, size_t bytes);
+
+/* HIP-event timing on the context's stream (what bench.py uses for per-kernel durations). */
+int zkfhe_timer_start(zkfhe_ctx *ctx);
+int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms);   /* waits for the stop event */
+
+/* ---- coefficient-wise Fr arithmetic (device buffers, out may alias a or b) ----------------- */
+int zkfhe_fr_add(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);
+int zkfhe_fr_sub(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);
+int zkfhe_fr_mul(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);
+/* out[i] = a[i] * s   (s: one host-side Fr) */
+int zkfhe_fr_scale(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *s_host, zkfhe_fr *out_dev, size_t n);
+/* canonical integer <-> Montgomery form */
+int zkfhe_fr_to_mont(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, zkfhe_fr *out_dev, size_t n);
+int zkfhe_fr_from_mont(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, zkfhe_fr *out_dev, size_t n);
+/* in place a[i] <- a[i]^-1, zero stays zero (halo2 batch_invert convention) */
+int zkfhe_fr_batch_invert(zkfhe_ctx *ctx, zkfhe_fr *a_dev, size_t n);
+/* modmul micro-benchmark: out[i] = a[i]^(2^iters) by repeated squaring (ALU-roofline probe) */
+int zkfhe_fr_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, zkfhe_fr *out_dev, size_t n, int iters);
+
+/* ---- NTT ---------------------------------------------------------------------------------- */
+/* n_cols independent transforms of length 2^log_n, column c at cols_dev + c * 2^log_n, in place,
+ * natural order in and out.  inverse = 0: out[i] = sum_j a[j] w^(ij) with w = halo2's omega for
+ * this log_n (= ROOT_OF_UNITY^(2^(28-log_n)));  inverse = 1: w^-1 and a final multiplication by
+ * n^-1 (lagrange_to_coeff).  1 <= log_n <= 26. */
+int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse);
+
+/* coeff_to_extended (inverse = 0): column c holds 2^log_n coefficients at in_dev + c*2^log_n; writes
+ * the 2^(log_n+log_ext_factor) evaluations over the coset g*<w_ext> to out_dev + c*2^(log_n+lef) in
+ * COSET-MAJOR order: out[k1*2^log_n + k2] = f(g * w_ext^(k1 + 2^lef * k2)), i.e. row k1 is the
+ * evaluation over (g*w_ext^k1)*<w>; a rotation by w stays inside a row.
+ * extended_to_coeff (inverse = 1): the same layout in -> 2^(log_n+lef) coefficients out (natural order).
+ * g is `zeta`-coset generator of halo2's extended domain, passed by the caller (host Fr). */
+int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols,
+                          int log_n, int log_ext_factor, const zkfhe_fr *g_host, int inverse);
+
+/* ---- MSM (KZG commit) ---------------------------------------------------------------------- */
+/* Uploads n affine bases (host memory) and builds the per-window tables 2^(c*w) * P_i used by the
+ * single-bucket-set Pippenger (DESIGN.md "MSM").  window_bits = 0 picks the default for n. */
+int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t n, int window_bits,
+                       zkfhe_basis **out);
+int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis);
+size_t zkfhe_basis_len(const zkfhe_basis *basis);
+/* out_dev[c] = sum_i scalars_dev[c*n + i] * bases[i], c < n_cols; n = zkfhe_basis_len; result affine */
+int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols,
+                    zkfhe_g1_affine *out_dev);
+
+/* ---- G1 helpers (device, used by tests and by the SRS builder) ------------------------------ */
+/* out[i] = a[i] + b[i] (affine in, affine out; handles doubling / inverse / identity) */
+int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a_dev, const zkfhe_g1_affine *b_dev,
+                 zkfhe_g1_affine *out_dev, size_t n);
+/* out[i] = k[i] * p[i] */
+int zkfhe_g1_mul(zkfhe_ctx *ctx, const zkfhe_g1_affine *p_dev, const zkfhe_fr *k_dev,
+                 zkfhe_g1_affine *out_dev, size_t n);
+
+/* ---- BFV witness kernels -------------------------------- */
+/* Negacyclic product in R_q = Z_q[x]/(x^N+1) is NOT what the reference computes: Poly::mul
+ * (src/poly.rs:75-103) is the plain integer product of two degree-(N-1) polynomials, 2N-1 coefficients.
+ * a, b: N canonical integers < 2^64 each (uint64), big-endian coefficient order as in bfv.in;
+ * out: 2N-1 Montgomery Fr values (exact integers, < 2^132 << r).  N a power of two <= 2^20. */
+int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, size_t n,
+                               zkfhe_fr *out_dev);
+/* RangeChip::div_mod witness (src/poly_chip.rs:236-246): for canonical values a[i] < 2^128 held as
+ * Montgomery Fr, q a u64 modulus: div[i] = floor(a/q), rem[i] = a mod q (both returned as Montgomery Fr). */
+int zkfhe_witness_div_mod(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, uint64_t q, zkfhe_fr *div_dev,
+                          zkfhe_fr *rem_dev, size_t n);
+
+const char *zkfhe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

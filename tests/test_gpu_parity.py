@@ -1,0 +1,213 @@
+"""GPU parity tests: every C-ABI entry point against the CPU oracle (oracle/), bit-exact.
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from oracle import pyref
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch  # noqa: F401  (loads the ROCm runtime the extension links against first)
+    import zk_fhe_amd as zk
+    c = zk.Context(0)
+    assert c.device_info()["arch"].startswith("gfx950")
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def vec():
+    with open(os.path.join(HERE, "golden", "bn254_vectors.json")) as f:
+        return json.load(f)
+
+
+def rand_fr(rng, n):
+    return orc.ints_to_mont([int.from_bytes(rng.bytes(32), "little") % pyref.R for _ in range(n)])
+
+
+def hx(lst):
+    return [int(x, 16) for x in lst]
+
+
+def test_field_golden(ctx, vec):
+    v = vec["fr"]
+    a = orc.ints_to_mont(hx(v["a"]))
+    b = orc.ints_to_mont(hx(v["b"]))
+    for op in ("add", "sub", "mul"):
+        assert orc.mont_to_ints(ctx.fr_binop(op, a, b)) == hx(v[op]), op
+    assert orc.mont_to_ints(ctx.fr_unop("batch_invert", a)) == hx(v["inv"])
+    # to/from Montgomery
+    canon = orc.ints_to_arr(hx(v["a"]))
+    assert np.array_equal(ctx.fr_unop("to_mont", canon), a)
+    assert np.array_equal(ctx.fr_unop("from_mont", a), canon)
+
+
+def test_field_random_vs_oracle(ctx):
+    rng = np.random.default_rng(11)
+    n = 100_003
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    a[5] = 0
+    for op in ("add", "sub", "mul"):
+        assert np.array_equal(ctx.fr_binop(op, a, b), orc.fe_binop(op, a, b)), op
+    assert np.array_equal(ctx.fr_unop("batch_invert", a), orc.fr_batch_inv(a))
+    s = rand_fr(rng, 1)
+    assert np.array_equal(ctx.fr_unop("scale", a, s), orc.fe_binop("mul", a, np.repeat(s, n, axis=0)))
+    x = a[:1000]
+    want = x.copy()
+    for _ in range(5):
+        want = orc.fe_binop("mul", want, want)
+    assert np.array_equal(ctx.fr_unop("sqr_chain", x, 5), want)
+
+
+def test_g1_golden(ctx, vec):
+    g = vec["g1"]
+    G = orc.points_to_arr([pyref.G1_GEN] * len(g["k"]))
+    k = orc.ints_to_mont(hx(g["k"]))
+    want = [None if (int(x, 16) == 0 and int(y, 16) == 0) else (int(x, 16), int(y, 16)) for x, y in g["kG"]]
+    assert orc.arr_to_points(ctx.g1_mul(G, k)) == want
+    pts = orc.points_to_arr(want)
+    A = np.stack([pts[c["i"]] for c in g["add"]])
+    B = np.stack([pts[c["j"]] if c["j"] >= 0 else np.zeros(8, dtype=np.uint64) for c in g["add"]])
+    got = orc.arr_to_points(ctx.g1_add(A, B))
+    for s, c in zip(got, g["add"]):
+        assert (s or (0, 0)) == (int(c["sum"][0], 16), int(c["sum"][1], 16))
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+def test_ntt_vs_oracle(ctx, log_n):
+    rng = np.random.default_rng(100 + log_n)
+    n_cols = 5 if log_n < 13 else 3
+    a = rand_fr(rng, n_cols << log_n).reshape(n_cols, 1 << log_n, 4)
+    fwd = ctx.ntt(a, log_n, False)
+    assert np.array_equal(fwd, orc.ntt(a, log_n, False))
+    assert np.array_equal(ctx.ntt(a, log_n, True), orc.ntt(a, log_n, True))
+    assert np.array_equal(ctx.ntt(fwd, log_n, True), a)
+
+
+def test_ntt_golden(ctx, vec):
+    for t in vec["ntt"]:
+        a = orc.ints_to_mont(hx(t["in"]))
+        assert orc.mont_to_ints(ctx.ntt(a[None], t["log_n"], False)[0]) == hx(t["out"])
+
+
+@pytest.mark.parametrize("log_n", [14, 16])
+def test_ntt_large(ctx, log_n):
+    rng = np.random.default_rng(log_n)
+    a = rand_fr(rng, 2 << log_n).reshape(2, 1 << log_n, 4)
+    assert np.array_equal(ctx.ntt(a, log_n, False), orc.ntt(a, log_n, False))
+    assert np.array_equal(ctx.ntt(a, log_n, True), orc.ntt(a, log_n, True))
+
+
+def test_ntt_k13_batch_properties(ctx):
+    """BASELINE size (k=13, 197 witness columns): round trip + linearity, plus oracle on a column sample."""
+    rng = np.random.default_rng(5)
+    log_n, n_cols = 13, 197
+    a = rand_fr(rng, n_cols << log_n).reshape(n_cols, 1 << log_n, 4)
+    f = ctx.ntt(a, log_n, False)
+    assert np.array_equal(ctx.ntt(f, log_n, True), a)
+    for c in (0, 77, 196):
+        assert np.array_equal(f[c], orc.ntt(a[c:c + 1], log_n, False)[0])
+    s = orc.fe_binop("add", a[0], a[1])
+    assert np.array_equal(ctx.ntt(s[None], log_n, False)[0], orc.fe_binop("add", f[0], f[1]))
+
+
+@pytest.mark.parametrize("log_n,lef", [(4, 2), (7, 1), (10, 3), (13, 2)])
+def test_coset_ntt(ctx, log_n, lef):
+    rng = np.random.default_rng(log_n * 10 + lef)
+    n, E = 1 << log_n, 1 << lef
+    n_cols = 2
+    a = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    g = orc.ints_to_mont([pyref.FR_GEN])[0]
+    got = ctx.coset_ntt(a, log_n, lef, g)
+    for c in range(n_cols):
+        nat = orc.coset_ntt(a[c], log_n + lef, g)  # nat[k] = f(g w_ext^k)
+        want = nat.reshape(n, E, 4).transpose(1, 0, 2).reshape(n * E, 4)  # [k1][k2] <- nat[k1 + E k2]
+        assert np.array_equal(got[c], want)
+    # inverse: random extended-domain values of a degree < n*E polynomial
+    coeffs = rand_fr(rng, n_cols * n * E).reshape(n_cols, n * E, 4)
+    ext = np.stack([orc.coset_ntt(coeffs[c], log_n + lef, g).reshape(n, E, 4).transpose(1, 0, 2).reshape(n * E, 4)
+                    for c in range(n_cols)])
+    back = ctx.coset_ntt(ext, log_n, lef, g, inverse=True)
+    assert np.array_equal(back, coeffs)
+
+
+def _bases(n, seed=1):
+    return orc.g1_powers(orc.ints_to_mont([seed * 7919 + 3])[0], orc.ints_to_mont([0x1234567 + seed])[0], n)
+
+
+def test_msm_golden(ctx, vec):
+    import zk_fhe_amd as zk
+    for m in vec["msm"]:
+        bases = [None if (int(x, 16) == 0 and int(y, 16) == 0) else (int(x, 16), int(y, 16)) for x, y in m["bases"]]
+        B = zk.Basis(ctx, orc.points_to_arr(bases))
+        got = orc.arr_to_points(ctx.msm(B, orc.ints_to_mont(hx(m["scalars"]))[None]))[0]
+        assert (got or (0, 0)) == (int(m["result"][0], 16), int(m["result"][1], 16))
+        B.destroy()
+
+
+@pytest.mark.parametrize("n,c", [(64, 0), (1000, 0), (1000, 4), (4096, 0), (8192, 0), (8192, 10)])
+def test_msm_vs_oracle(ctx, n, c):
+    import zk_fhe_amd as zk
+    rng = np.random.default_rng(n + c)
+    bases = _bases(n, seed=n)
+    bases[n // 3] = 0  # identity base
+    n_cols = 4
+    sc = [[int.from_bytes(rng.bytes(32), "little") % pyref.R for _ in range(n)] for _ in range(n_cols)]
+    # column 1: witness-like small / negative-small values; column 2: heavily skewed (0/1/2^29-ish); column 3: zeros
+    sc[1] = [int(rng.integers(0, 256)) if i % 3 else (pyref.R - int(rng.integers(1, 1000))) for i in range(n)]
+    sc[2] = [[0, 1, 536870908][int(rng.integers(0, 3))] for _ in range(n)]
+    sc[3] = [0] * n
+    sc[0][:6] = [0, 1, pyref.R - 1, (pyref.R - 1) // 2, (pyref.R + 1) // 2, 2]
+    S = np.stack([orc.ints_to_mont(col) for col in sc])
+    B = zk.Basis(ctx, bases, c)
+    got = ctx.msm(B, S)
+    assert np.array_equal(got, orc.msm(S, bases))
+    B.destroy()
+
+
+def test_msm_k13_batch_linearity(ctx):
+    """BASELINE size: 64 columns x 8192 with the witness scalar mix; oracle on a sample + additivity."""
+    import zk_fhe_amd as zk
+    rng = np.random.default_rng(99)
+    n, n_cols = 8192, 64
+    bases = _bases(n, seed=13)
+    S = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    S[2] = orc.fe_binop("add", S[0], S[1])
+    B = zk.Basis(ctx, bases)
+    got = ctx.msm(B, S)
+    assert np.array_equal(ctx.g1_add(got[0:1], got[1:2])[0], got[2])
+    assert np.array_equal(got[5:7], orc.msm(S[5:7], bases))
+    B.destroy()
+
+
+def test_witness_kernels(ctx):
+    rng = np.random.default_rng(21)
+    Q = 536870909
+    n = 1024
+    a = rng.integers(0, Q, size=n, dtype=np.uint64)
+    b = np.array([[0, 1, Q - 1][int(x)] for x in rng.integers(0, 3, size=n)], dtype=np.uint64)
+    prod = ctx.witness_poly_mul_u64(a, b)
+    want = [0] * (2 * n - 1)
+    ai, bi = [int(x) for x in a], [int(x) for x in b]
+    for i in range(n):
+        if bi[i]:
+            for j in range(n):
+                want[i + j] += ai[j] * bi[i]
+    assert orc.mont_to_ints(prod) == want
+    d, r = ctx.witness_div_mod(prod, Q)
+    assert orc.mont_to_ints(d) == [w // Q for w in want]
+    assert orc.mont_to_ints(r) == [w % Q for w in want]
+    big = orc.ints_to_mont([(1 << 128) - 1, 0, Q, Q - 1, (1 << 127) + 12345])
+    d, r = ctx.witness_div_mod(big, (1 << 60) - 93)
+    q60 = (1 << 60) - 93
+    assert orc.mont_to_ints(d) == [v // q60 for v in [(1 << 128) - 1, 0, Q, Q - 1, (1 << 127) + 12345]]
+    assert orc.mont_to_ints(r) == [v % q60 for v in [(1 << 128) - 1, 0, Q, Q - 1, (1 << 127) + 12345]]

@@ -1,0 +1,305 @@
+"""zk-fhe_amd: host-side binding of the MI355X (gfx950) backend for zk-fhe's BFV-proof hot path.
+
+This package is a thin ctypes mirror of include/zkfhe.h -- the C ABI is the product boundary, the
+HIP kernels behind it are the product.  There is NO CPU fallback: if libzkfhe_hip.so is missing or
+no gfx950 device is present, creating a Context raises.
+
+The directory name contains a hyphen (it mirrors the reference's repository name), so import it
+through the root shim:  `import zk_fhe_amd as zk`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkfhe_hip.so")
+_lib = None
+
+EXPORTS = [
+    "zkfhe_ctx_create", "zkfhe_ctx_destroy", "zkfhe_last_error", "zkfhe_sync", "zkfhe_stream", "zkfhe_device_info",
+    "zkfhe_dev_alloc", "zkfhe_dev_free", "zkfhe_upload", "zkfhe_download", "zkfhe_copy_dev", "zkfhe_memset_dev",
+    "zkfhe_timer_start", "zkfhe_timer_stop_ms",
+    "zkfhe_fr_add", "zkfhe_fr_sub", "zkfhe_fr_mul", "zkfhe_fr_scale", "zkfhe_fr_to_mont", "zkfhe_fr_from_mont",
+    "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain",
+    "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
+    "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
+    "zkfhe_g1_add", "zkfhe_g1_mul",
+    "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",
+    "zkfhe_version",
+]
+
+
+class ZkfheError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree HIP extension. Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZkfheError("HIP extension %s is missing: run `python zk-fhe_amd/build.py` (or __graft_entry__.build())" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.zkfhe_last_error.restype = ctypes.c_char_p
+    lib.zkfhe_last_error.argtypes = [vp]
+    lib.zkfhe_version.restype = ctypes.c_char_p
+    lib.zkfhe_stream.restype = vp
+    lib.zkfhe_stream.argtypes = [vp]
+    lib.zkfhe_basis_len.restype = sz
+    lib.zkfhe_basis_len.argtypes = [vp]
+    lib.zkfhe_ctx_create.argtypes = [ci, vp, ctypes.POINTER(vp)]
+    lib.zkfhe_ctx_destroy.argtypes = [vp]
+    lib.zkfhe_sync.argtypes = [vp]
+    lib.zkfhe_device_info.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(ci), ctypes.POINTER(sz)]
+    lib.zkfhe_dev_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    lib.zkfhe_dev_free.argtypes = [vp, vp]
+    lib.zkfhe_upload.argtypes = [vp, vp, vp, sz]
+    lib.zkfhe_download.argtypes = [vp, vp, vp, sz]
+    lib.zkfhe_copy_dev.argtypes = [vp, vp, vp, sz]
+    lib.zkfhe_memset_dev.argtypes = [vp, vp, ci, sz]
+    lib.zkfhe_timer_start.argtypes = [vp]
+    lib.zkfhe_timer_stop_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    for f in ("zkfhe_fr_add", "zkfhe_fr_sub", "zkfhe_fr_mul"):
+        getattr(lib, f).argtypes = [vp, vp, vp, vp, sz]
+    lib.zkfhe_fr_scale.argtypes = [vp, vp, vp, vp, sz]
+    lib.zkfhe_fr_to_mont.argtypes = [vp, vp, vp, sz]
+    lib.zkfhe_fr_from_mont.argtypes = [vp, vp, vp, sz]
+    lib.zkfhe_fr_batch_invert.argtypes = [vp, vp, sz]
+    lib.zkfhe_fr_sqr_chain.argtypes = [vp, vp, vp, sz, ci]
+    lib.zkfhe_ntt_batch.argtypes = [vp, vp, sz, ci, ci]
+    lib.zkfhe_coset_ntt_batch.argtypes = [vp, vp, vp, sz, ci, ci, vp, ci]
+    lib.zkfhe_basis_create.argtypes = [vp, vp, sz, ci, ctypes.POINTER(vp)]
+    lib.zkfhe_basis_destroy.argtypes = [vp, vp]
+    lib.zkfhe_msm_batch.argtypes = [vp, vp, vp, sz, vp]
+    lib.zkfhe_g1_add.argtypes = [vp, vp, vp, vp, sz]
+    lib.zkfhe_g1_mul.argtypes = [vp, vp, vp, vp, sz]
+    lib.zkfhe_witness_poly_mul_u64.argtypes = [vp, vp, vp, sz, vp]
+    lib.zkfhe_witness_div_mod.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, sz]
+    _lib = lib
+    return lib
+
+
+class DeviceBuffer:
+    """A device (HBM) allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        ctx._check(ctx.lib.zkfhe_dev_alloc(ctx.h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.zkfhe_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def at(self, byte_offset):
+        return ctypes.c_void_p(self.ptr + int(byte_offset))
+
+    def upload(self, arr, byte_offset=0):
+        a = np.ascontiguousarray(arr)
+        assert byte_offset + a.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.zkfhe_upload(self.ctx.h, self.at(byte_offset), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+        return self
+
+    def download(self, dtype=np.uint64, shape=None, byte_offset=0, nbytes=None):
+        nbytes = self.nbytes - byte_offset if nbytes is None else nbytes
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self.ctx._check(self.ctx.lib.zkfhe_download(self.ctx.h, out.ctypes.data_as(ctypes.c_void_p), self.at(byte_offset), nbytes))
+        return out.reshape(shape) if shape is not None else out
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Basis:
+    """Device-resident MSM basis (SRS half) with its per-window tables."""
+
+    def __init__(self, ctx, bases, window_bits=0):
+        b = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.zkfhe_basis_create(ctx.h, b.ctypes.data_as(ctypes.c_void_p), b.shape[0], int(window_bits), ctypes.byref(h)))
+        self.h = h
+        self.n = b.shape[0]
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.zkfhe_basis_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """One per GPU. Mirrors zkfhe_ctx; raises ZkfheError on any non-zero status."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.zkfhe_ctx_create(int(device_id), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if rc != 0:
+            raise ZkfheError("zkfhe_ctx_create failed (%d): %s" % (rc, self.lib.zkfhe_last_error(None).decode()))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ZkfheError("zkfhe call failed (%d): %s" % (rc, self.lib.zkfhe_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.zkfhe_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._check(self.lib.zkfhe_sync(self.h))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(64)
+        cu = ctypes.c_int()
+        mem = ctypes.c_size_t()
+        self._check(self.lib.zkfhe_device_info(self.h, name, 64, ctypes.byref(cu), ctypes.byref(mem)))
+        return {"arch": name.value.decode(), "num_cu": cu.value, "hbm_bytes": mem.value}
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        a = np.ascontiguousarray(arr)
+        return self.alloc(a.nbytes).upload(a)
+
+    def timer_start(self):
+        self._check(self.lib.zkfhe_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.zkfhe_timer_stop_ms(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- device-resident calls (pointers are DeviceBuffer or c_void_p) ----
+    @staticmethod
+    def _p(x):
+        return ctypes.c_void_p(x.ptr) if isinstance(x, DeviceBuffer) else x
+
+    def fr_binop_dev(self, op, a, b, out, n):
+        self._check(getattr(self.lib, "zkfhe_fr_" + op)(self.h, self._p(a), self._p(b), self._p(out), n))
+
+    def ntt_dev(self, cols, n_cols, log_n, inverse=False):
+        self._check(self.lib.zkfhe_ntt_batch(self.h, self._p(cols), n_cols, log_n, int(bool(inverse))))
+
+    def coset_ntt_dev(self, src, dst, n_cols, log_n, log_ext_factor, g, inverse=False):
+        g = np.ascontiguousarray(g, dtype=np.uint64)
+        self._check(self.lib.zkfhe_coset_ntt_batch(self.h, self._p(src), self._p(dst), n_cols, log_n, log_ext_factor,
+                                                  g.ctypes.data_as(ctypes.c_void_p), int(bool(inverse))))
+
+    def msm_dev(self, basis, scalars, n_cols, out):
+        self._check(self.lib.zkfhe_msm_batch(self.h, basis.h, self._p(scalars), n_cols, self._p(out)))
+
+    # ---- numpy convenience (host in, host out; used by tests and smoke) ----
+    def _fr(self, a):
+        return np.ascontiguousarray(a, dtype=np.uint64)
+
+    def fr_binop(self, op, a, b):
+        a, b = self._fr(a), self._fr(b)
+        n = a.size // 4
+        da, db = self.to_device(a), self.to_device(b)
+        self.fr_binop_dev(op, da, db, da, n)
+        out = da.download(shape=a.shape)
+        da.free(), db.free()
+        return out
+
+    def fr_unop(self, name, a, *extra):
+        a = self._fr(a)
+        n = a.size // 4
+        da = self.to_device(a)
+        if name == "batch_invert":
+            self._check(self.lib.zkfhe_fr_batch_invert(self.h, self._p(da), n))
+        elif name == "scale":
+            s = self._fr(extra[0])
+            self._check(self.lib.zkfhe_fr_scale(self.h, self._p(da), s.ctypes.data_as(ctypes.c_void_p), self._p(da), n))
+        elif name == "sqr_chain":
+            self._check(self.lib.zkfhe_fr_sqr_chain(self.h, self._p(da), self._p(da), n, int(extra[0])))
+        else:
+            self._check(getattr(self.lib, "zkfhe_fr_" + name)(self.h, self._p(da), self._p(da), n))
+        out = da.download(shape=a.shape)
+        da.free()
+        return out
+
+    def ntt(self, cols, log_n, inverse=False):
+        a = self._fr(cols)
+        n = 1 << log_n
+        n_cols = a.size // 4 // n
+        d = self.to_device(a)
+        self.ntt_dev(d, n_cols, log_n, inverse)
+        out = d.download(shape=a.shape)
+        d.free()
+        return out
+
+    def coset_ntt(self, cols, log_n, log_ext_factor, g, inverse=False):
+        a = self._fr(cols)
+        n, ne = 1 << log_n, 1 << (log_n + log_ext_factor)
+        if not inverse:
+            n_cols = a.size // 4 // n
+            src, dst = self.to_device(a), self.alloc(n_cols * ne * 32)
+        else:
+            n_cols = a.size // 4 // ne
+            src, dst = self.to_device(a), self.alloc(n_cols * ne * 32)
+        self.coset_ntt_dev(src, dst, n_cols, log_n, log_ext_factor, g, inverse)
+        out = dst.download(shape=(n_cols, ne, 4))
+        src.free(), dst.free()
+        return out
+
+    def msm(self, basis, scalars):
+        s = self._fr(scalars)
+        n_cols = s.size // 4 // basis.n
+        ds, do = self.to_device(s), self.alloc(n_cols * 64)
+        self.msm_dev(basis, ds, n_cols, do)
+        out = do.download(shape=(n_cols, 8))
+        ds.free(), do.free()
+        return out
+
+    def g1_add(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 8)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 8)
+        da, db = self.to_device(a), self.to_device(b)
+        self._check(self.lib.zkfhe_g1_add(self.h, self._p(da), self._p(db), self._p(da), a.shape[0]))
+        out = da.download(shape=a.shape)
+        da.free(), db.free()
+        return out
+
+    def g1_mul(self, p, k):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 8)
+        k = np.ascontiguousarray(k, dtype=np.uint64).reshape(-1, 4)
+        dp, dk = self.to_device(p), self.to_device(k)
+        self._check(self.lib.zkfhe_g1_mul(self.h, self._p(dp), self._p(dk), self._p(dp), p.shape[0]))
+        out = dp.download(shape=p.shape)
+        dp.free(), dk.free()
+        return out
+
+    def witness_poly_mul_u64(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        n = a.size
+        da, db, do = self.to_device(a), self.to_device(b), self.alloc((2 * n - 1) * 32)
+        self._check(self.lib.zkfhe_witness_poly_mul_u64(self.h, self._p(da), self._p(db), n, self._p(do)))
+        out = do.download(shape=(2 * n - 1, 4))
+        da.free(), db.free(), do.free()
+        return out
+
+    def witness_div_mod(self, a, q):
+        a = self._fr(a).reshape(-1, 4)
+        n = a.shape[0]
+        da, dd, dr = self.to_device(a), self.alloc(n * 32), self.alloc(n * 32)
+        self._check(self.lib.zkfhe_witness_div_mod(self.h, self._p(da), ctypes.c_uint64(int(q)), self._p(dd), self._p(dr), n))
+        d, r = dd.download(shape=(n, 4)), dr.download(shape=(n, 4))
+        da.free(), dd.free(), dr.free()
+        return d, r
+
+
+def version():
+    return load_library().zkfhe_version().decode()

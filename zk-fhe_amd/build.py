@@ -1,0 +1,94 @@
+"""Builds libzkfhe_hip.so (HIP kernels + C ABI, gfx950 only) in-tree with plain hipcc.
+
+    python zk-fhe_amd/build.py [--force] [--jobs N]
+
+Objects go to zk-fhe_amd/_build/, the library to zk-fhe_amd/libzkfhe_hip.so (git-ignored, but it
+travels to the GPU box with the snapshot).  hipcc cross-compiles without a GPU.
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libzkfhe_hip.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wno-unused-value",
+         "-mllvm", "-pragma-unroll-threshold=1000000", "-I", os.path.join(HERE, "..", "include")]
+TILE_SIZES = list(range(3, 14))
+
+
+def hipcc():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return p
+
+
+def units():
+    u = []
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hip") and f != "ntt_tile_inst.hip":
+            u.append((os.path.join(CSRC, f), os.path.join(OUT, f[:-4] + ".o"), []))
+    for k in TILE_SIZES:
+        u.append((os.path.join(CSRC, "ntt_tile_inst.hip"), os.path.join(OUT, "ntt_tile_%d.o" % k), ["-DZK_TILE_LOGN=%d" % k]))
+    return u
+
+
+def newest_header():
+    t = 0.0
+    for d in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(d):
+            if f.endswith((".cuh", ".hpp", ".h")):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def compile_one(src, obj, extra):
+    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (os.path.basename(obj), r.stdout[-4000:]))
+    return obj
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(OUT, exist_ok=True)
+    hdr_t = newest_header()
+    todo = []
+    objs = []
+    for src, obj, extra in units():
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append((src, obj, extra))
+    if todo:
+        jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 4)))
+        if verbose:
+            print("[zkfhe build] compiling %d unit(s) for %s with %d job(s)" % (len(todo), ARCH, jobs), flush=True)
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for f in [ex.submit(compile_one, *t) for t in todo]:
+                f.result()
+    if todo or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout[-4000:])
+        if verbose:
+            print("[zkfhe build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    try:
+        build(a.force, a.jobs)
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)

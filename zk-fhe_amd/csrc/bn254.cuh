@@ -9,7 +9,7 @@
 //     extended-Jacobian form used for accumulation (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2).
 //
 // Device arithmetic is on 32-bit limbs: gfx950 has no 64x64 multiplier; the widest
-// integer multiply is v_mad_u64_u32 (32x32+64 -> 64), which the CIOS loops below map to.
+// integer multiply is v_mad_u64_u32 (32x32+64 -> 64), which fp_mul below is built from.
 #pragma once
 #include <stdint.h>
 
@@ -82,33 +82,29 @@ struct alignas(16) Fp {
   ZK_HD bool operator!=(const Fp& b) const { return !(*this == b); }
 };
 
+// Carry-chain helpers.  __builtin_addc/__builtin_subc lower to v_add_co_u32 / v_addc_co_u32
+// (v_sub_co / v_subb_co) chains on gfx950 -- one VALU op per limb, carries in VCC -- instead of the
+// 64-bit-per-limb arithmetic a (u64) formulation produces.
+ZK_HD u32 zk_addc(u32 a, u32 b, u32 cin, u32 *cout) { return __builtin_addc(a, b, cin, cout); }
+ZK_HD u32 zk_subc(u32 a, u32 b, u32 bin, u32 *bout) { return __builtin_subc(a, b, bin, bout); }
+
 // r = a - p if a >= p (a < 2p).
 template <class P>
 ZK_HD void fp_reduce_once(u32 (&a)[8]) {
   u32 t[8];
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u64 d = (u64)a[i] - P::MOD[i] - br;
-    t[i] = (u32)d;
-    br = (d >> 32) & 1;
-  }
-  if (br == 0) {
+  for (int i = 0; i < 8; ++i) t[i] = zk_subc(a[i], P::MOD[i], br, &br);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = t[i];
-  }
+  for (int i = 0; i < 8; ++i) a[i] = br ? a[i] : t[i];
 }
 
 template <class P>
 ZK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
   Fp<P> r;
-  u64 c = 0;
+  u32 c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    c += (u64)a.l[i] + b.l[i];
-    r.l[i] = (u32)c;
-    c >>= 32;
-  }
+  for (int i = 0; i < 8; ++i) r.l[i] = zk_addc(a.l[i], b.l[i], c, &c);
   // p < 2^254 so a+b < 2^255: no carry out of limb 7.
   fp_reduce_once<P>(r.l);
   return r;
@@ -117,21 +113,13 @@ ZK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
 template <class P>
 ZK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
   Fp<P> r;
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u64 d = (u64)a.l[i] - b.l[i] - br;
-    r.l[i] = (u32)d;
-    br = (d >> 32) & 1;
-  }
-  u32 mask = (u32)0 - (u32)br;  // all ones when a < b: add p back
-  u64 c = 0;
+  for (int i = 0; i < 8; ++i) r.l[i] = zk_subc(a.l[i], b.l[i], br, &br);
+  const u32 mask = (u32)0 - br;  // all ones when a < b: add p back
+  u32 c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    c += (u64)r.l[i] + (P::MOD[i] & mask);
-    r.l[i] = (u32)c;
-    c >>= 32;
-  }
+  for (int i = 0; i < 8; ++i) r.l[i] = zk_addc(r.l[i], P::MOD[i] & mask, c, &c);
   return r;
 }
 
@@ -139,13 +127,9 @@ template <class P>
 ZK_HD Fp<P> fp_neg(const Fp<P>& a) {
   if (a.is_zero()) return a;
   Fp<P> r;
-  u64 br = 0;
+  u32 br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u64 d = (u64)P::MOD[i] - a.l[i] - br;
-    r.l[i] = (u32)d;
-    br = (d >> 32) & 1;
-  }
+  for (int i = 0; i < 8; ++i) r.l[i] = zk_subc(P::MOD[i], a.l[i], br, &br);
   return r;
 }
 
@@ -154,20 +138,75 @@ ZK_HD Fp<P> fp_dbl(const Fp<P>& a) {
   return fp_add<P>(a, a);
 }
 
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.
-// Every partial product is one 32x32+64 multiply-add (v_mad_u64_u32 on gfx950).
-// Bounds: p < 2^254, so the running value stays < 2p < 2^255 after each outer
-// iteration and the 9-limb window t[0..8] never overflows.
+// Montgomery product a*b*R^-1 mod p.
+//
+// Device: finely-integrated product scanning (FIPS) over 32-bit limbs.  Column k of a*b + m*p is
+// summed into a 96-bit accumulator {acc (64 bit), top (32 bit)}: every partial product is ONE
+// v_mad_u64_u32 (32x32+64 -> 64, carry-out in VCC) followed by ONE v_addc_co_u32 into `top`.
+// 128 multiply-adds + 8 v_mul_lo_u32 per product, ~30 live VGPRs.  The modulus limbs are SGPR
+// operands (VOP3 on gfx9-family cannot encode a 32-bit literal).
+// Host: portable CIOS with the same result (both are exact, result canonical < p).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void zk_mac(u64 &acc, u32 &top, u32 a, u32 b) {
+  // gfx950: a VALU write of VCC needs 2 wait states before a VALU reads it as carry-in; hipcc does
+  // not pad inside an asm string, so the s_nop is ours.
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(top)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+__device__ __forceinline__ void zk_mac_s(u64 &acc, u32 &top, u32 a, u32 b_sgpr) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(top)
+      : "v"(a), "s"(b_sgpr)
+      : "vcc");
+}
+
+template <class P>
+__device__ __forceinline__ Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+  u32 m[8];
+  u32 r[8];
+  u64 acc = 0;
+  u32 top = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      zk_mac(acc, top, a.l[j], b.l[k - j]);
+      zk_mac_s(acc, top, m[j], P::MOD[k - j]);
+    }
+    zk_mac(acc, top, a.l[k], b.l[0]);
+    m[k] = (u32)acc * P::INV;
+    zk_mac_s(acc, top, m[k], P::MOD[0]);  // low word becomes 0
+    acc = (acc >> 32) | ((u64)top << 32);
+    top = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; ++k) {
+#pragma unroll
+    for (int j = k - 7; j < 8; ++j) {
+      zk_mac(acc, top, a.l[j], b.l[k - j]);
+      zk_mac_s(acc, top, m[j], P::MOD[k - j]);
+    }
+    r[k - 8] = (u32)acc;
+    acc = (acc >> 32) | ((u64)top << 32);
+    top = 0;
+  }
+  // a, b < p < 2^254  =>  result < 2p < 2^255: nothing left in acc
+  Fp<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.l[i] = r[i];
+  fp_reduce_once<P>(o.l);
+  return o;
+}
+#else
 template <class P>
 ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
   u32 t[9];
-#pragma unroll
   for (int i = 0; i < 9; ++i) t[i] = 0;
-#pragma unroll
   for (int i = 0; i < 8; ++i) {
     u64 c = 0;
     const u32 bi = b.l[i];
-#pragma unroll
     for (int j = 0; j < 8; ++j) {
       c = (u64)a.l[j] * bi + ((u64)t[j] + c);
       t[j] = (u32)c;
@@ -176,7 +215,6 @@ ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
     t[8] += (u32)c;
     const u32 m = t[0] * P::INV;
     c = ((u64)m * P::MOD[0] + t[0]) >> 32;
-#pragma unroll
     for (int j = 1; j < 8; ++j) {
       c = (u64)m * P::MOD[j] + ((u64)t[j] + c);
       t[j - 1] = (u32)c;
@@ -187,11 +225,11 @@ ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
     t[8] = (u32)(c >> 32);
   }
   Fp<P> r;
-#pragma unroll
   for (int i = 0; i < 8; ++i) r.l[i] = t[i];
   fp_reduce_once<P>(r.l);
   return r;
 }
+#endif
 
 template <class P>
 ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {

@@ -1,0 +1,288 @@
+// Context, device memory, timing and coefficient-wise Fr kernels of the C ABI (include/zkfhe.h).
+#include <cstdio>
+#include <cstring>
+
+#include "ctx.hpp"
+
+using namespace zk;
+
+static thread_local std::string g_create_err;
+
+int zk_fail(zkfhe_ctx *ctx, int code, const char *what, hipError_t e, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  if (ctx) ctx->err = buf; else g_create_err = buf;
+  return code;
+}
+int zk_fail_msg(zkfhe_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg; else g_create_err = msg;
+  return code;
+}
+
+int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out) {
+  if (ctx->scratch_sz[slot] < bytes) {
+    if (ctx->scratch[slot]) {
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ZK_HIP(ctx, hipFree(ctx->scratch[slot]));
+      ctx->scratch[slot] = nullptr;
+      ctx->scratch_sz[slot] = 0;
+    }
+    size_t want = bytes + bytes / 4;
+    ZK_HIP(ctx, hipMalloc(&ctx->scratch[slot], want));
+    ctx->scratch_sz[slot] = want;
+  }
+  *out = ctx->scratch[slot];
+  return ZKFHE_OK;
+}
+
+Fr zk_fr_from_u64(uint64_t v) {
+  Fr t = Fr::zero();
+  t.l[0] = (u32)v;
+  t.l[1] = (u32)(v >> 32);
+  return fp_to_mont<FrP>(t);
+}
+
+Fr zk_fr_root_of_unity(int log_n) {
+  // 7^((r-1)/2^28), canonical (SURVEY.md section 4 KAT 4)
+  Fr c;
+  const u32 w[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du, 0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u};
+  for (int i = 0; i < 8; ++i) c.l[i] = w[i];
+  Fr r = fp_to_mont<FrP>(c);
+  for (int i = 0; i < 28 - log_n; ++i) r = fp_sqr<FrP>(r);
+  return r;
+}
+
+extern "C" {
+
+const char *zkfhe_version(void) { return "zkfhe-mi355x 0.1 (gfx950)"; }
+
+int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
+  if (!out) return zk_fail_msg(nullptr, ZKFHE_EINVAL, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return zk_fail_msg(nullptr, ZKFHE_ENODEV, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device_id < 0 || device_id >= count) return zk_fail_msg(nullptr, ZKFHE_EINVAL, "device_id out of range");
+  hipDeviceProp_t prop;
+  ZK_HIP(nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return zk_fail_msg(nullptr, ZKFHE_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  ZK_HIP(nullptr, hipSetDevice(device_id));
+  zkfhe_ctx *ctx = new zkfhe_ctx();
+  ctx->device = device_id;
+  ctx->num_cu = prop.multiProcessorCount;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return zk_fail(nullptr, ZKFHE_EHIP, "hipStreamCreate", e, __FILE__, __LINE__); }
+    ctx->own_stream = true;
+  }
+  hipEventCreate(&ctx->ev0);
+  hipEventCreate(&ctx->ev1);
+  *out = ctx;
+  return ZKFHE_OK;
+}
+
+int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
+  if (!ctx) return ZKFHE_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->domains) {
+    hipFree(kv.second.fwd);
+    hipFree(kv.second.inv);
+  }
+  for (int i = 0; i < 4; ++i)
+    if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+  hipEventDestroy(ctx->ev0);
+  hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ZKFHE_OK;
+}
+
+const char *zkfhe_last_error(const zkfhe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int zkfhe_sync(zkfhe_ctx *ctx) {
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKFHE_OK;
+}
+
+void *zkfhe_stream(zkfhe_ctx *ctx) { return (void *)ctx->stream; }
+
+int zkfhe_device_info(zkfhe_ctx *ctx, char *arch_name, size_t arch_len, int *num_cu, size_t *hbm_bytes) {
+  hipDeviceProp_t prop;
+  ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (arch_name && arch_len) { strncpy(arch_name, prop.gcnArchName, arch_len - 1); arch_name[arch_len - 1] = 0; }
+  if (num_cu) *num_cu = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return ZKFHE_OK;
+}
+
+int zkfhe_dev_alloc(zkfhe_ctx *ctx, size_t bytes, void **dptr) {
+  ZK_ARG(ctx, dptr != nullptr);
+  ZK_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return zk_fail_msg(ctx, ZKFHE_ENOMEM, "hipMalloc: out of device memory");
+  ZK_HIP(ctx, e);
+  return ZKFHE_OK;
+}
+int zkfhe_dev_free(zkfhe_ctx *ctx, void *dptr) {
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, hipFree(dptr));
+  return ZKFHE_OK;
+}
+int zkfhe_upload(zkfhe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKFHE_OK;
+}
+int zkfhe_download(zkfhe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+  ZK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ZKFHE_OK;
+}
+int zkfhe_copy_dev(zkfhe_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {
+  ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return ZKFHE_OK;
+}
+int zkfhe_memset_dev(zkfhe_ctx *ctx, void *dst_dev, int byte, size_t bytes) {
+  ZK_HIP(ctx, hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
+  return ZKFHE_OK;
+}
+
+int zkfhe_timer_start(zkfhe_ctx *ctx) {
+  ZK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return ZKFHE_OK;
+}
+int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms) {
+  ZK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ZK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return ZKFHE_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// coefficient-wise kernels: one Fr (32 B = 2 x 16 B vector loads) per thread, grid-stride
+// ---------------------------------------------------------------------------------------------
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_fr_binop(const Fr *__restrict__ a, const Fr *__restrict__ b, Fr *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr x = a[i], y = b[i];
+    Fr r = OP == OP_ADD ? x + y : OP == OP_SUB ? x - y : x * y;
+    out[i] = r;
+  }
+}
+
+// MODE 0: * s ; 1: to_mont ; 2: from_mont
+template <int MODE>
+__global__ void __launch_bounds__(256) k_fr_unop(const Fr *__restrict__ a, Fr s, Fr *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr x = a[i];
+    out[i] = MODE == 0 ? x * s : MODE == 1 ? fp_to_mont<FrP>(x) : fp_from_mont<FrP>(x);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fr_sqr_chain(const Fr *__restrict__ a, Fr *__restrict__ out, size_t n, int iters) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr x = a[i];
+  for (int k = 0; k < iters; ++k) x = fp_sqr<FrP>(x);
+  out[i] = x;
+}
+
+// Batch inversion, Montgomery trick per thread over a strided chunk of CHUNK elements:
+// thread t owns elements t, t+T, t+2T, ... (T = total threads) so every load/store is coalesced.
+// prefix products go to `tmp` (n elements).  Zero elements are skipped and stay zero.
+#define BI_CHUNK 32
+__global__ void __launch_bounds__(256) k_fr_batch_invert(Fr *__restrict__ a, Fr *__restrict__ tmp, size_t n, size_t T) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  Fr acc = Fr::one();
+  int cnt = 0;
+  for (size_t i = t; i < n; i += T, ++cnt) {
+    tmp[i] = acc;
+    Fr x = a[i];
+    if (!x.is_zero()) acc = acc * x;
+  }
+  acc = fp_inv<FrP>(acc);
+  for (int k = cnt - 1; k >= 0; --k) {
+    size_t i = t + (size_t)k * T;
+    Fr x = a[i];
+    if (x.is_zero()) continue;
+    Fr inv = acc * tmp[i];
+    acc = acc * x;
+    a[i] = inv;
+  }
+}
+
+static unsigned ew_grid(zkfhe_ctx *ctx, size_t n) {
+  size_t b = (n + 255) / 256;
+  size_t cap = (size_t)ctx->num_cu * 8;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" {
+
+int zkfhe_fr_add(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *b, zkfhe_fr *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_fr_binop<OP_ADD><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, (const Fr *)b, (Fr *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_sub(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *b, zkfhe_fr *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_fr_binop<OP_SUB><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, (const Fr *)b, (Fr *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_mul(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *b, zkfhe_fr *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_fr_binop<OP_MUL><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, (const Fr *)b, (Fr *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_scale(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *s_host, zkfhe_fr *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  ZK_ARG(ctx, s_host != nullptr);
+  Fr s;
+  memcpy(&s, s_host, 32);
+  k_fr_unop<0><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, s, (Fr *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_to_mont(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_fr_unop<1><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, Fr::zero(), (Fr *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_from_mont(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_fr_unop<2><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, Fr::zero(), (Fr *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_batch_invert(zkfhe_ctx *ctx, zkfhe_fr *a, size_t n) {
+  if (!n) return ZKFHE_OK;
+  void *tmp;
+  int rc = zk_scratch(ctx, 0, n * sizeof(Fr), &tmp);
+  if (rc) return rc;
+  size_t T = (n + BI_CHUNK - 1) / BI_CHUNK;
+  k_fr_batch_invert<<<zk_blocks(T, 256), 256, 0, ctx->stream>>>((Fr *)a, (Fr *)tmp, n, T);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+int zkfhe_fr_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t n, int iters) {
+  if (!n) return ZKFHE_OK;
+  k_fr_sqr_chain<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const Fr *)a, (Fr *)out, n, iters);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Internal context shared by the C-ABI translation units (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkfhe.h"
+#include "bn254.cuh"
+
+struct NttDomain {
+  int log_n = 0;
+  zk::Fr *fwd = nullptr;  // omega^j, j < n
+  zk::Fr *inv = nullptr;  // omega^-j, j < n
+  zk::Fr n_inv;           // (2^log_n)^-1
+  zk::Fr omega, omega_inv;
+};
+
+struct zkfhe_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  int num_cu = 0;
+  std::map<int, NttDomain> domains;
+  // grow-only scratch arenas (bytes)
+  void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[4] = {0, 0, 0, 0};
+};
+
+struct zkfhe_basis {
+  size_t n = 0;
+  int c = 0;        // window bits
+  int windows = 0;  // number of signed windows
+  zk::G1Affine *table = nullptr;  // [windows][n] : 2^(c*w) * P_i
+};
+
+int zk_fail(zkfhe_ctx *ctx, int code, const char *what, hipError_t e, const char *file, int line);
+int zk_fail_msg(zkfhe_ctx *ctx, int code, const std::string &msg);
+
+#define ZK_HIP(ctx, expr)                                                             \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) return zk_fail((ctx), ZKFHE_EHIP, #expr, _e, __FILE__, __LINE__); \
+  } while (0)
+
+#define ZK_LAUNCH_CHECK(ctx) ZK_HIP(ctx, hipGetLastError())
+
+#define ZK_ARG(ctx, cond)                                                        \
+  do {                                                                           \
+    if (!(cond)) return zk_fail_msg((ctx), ZKFHE_EINVAL, std::string("bad argument: ") + #cond); \
+  } while (0)
+
+// returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse
+int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
+int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out);
+
+// host-side Fr helpers (same code as the device, compiled for the host)
+zk::Fr zk_fr_from_u64(uint64_t v);
+zk::Fr zk_fr_root_of_unity(int log_n);
+
+static inline unsigned zk_blocks(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }

@@ -1,0 +1,430 @@
+// Batched multi-scalar multiplication over BN254 G1 for gfx950 (the KZG commit of the prover).
+//
+// Replaces halo2_proofs `arithmetic::best_multiexp(&[Fr], &[G1Affine]) -> G1` as called by
+// `ParamsKZG::{commit, commit_lagrange}` (third-party; reached from reference examples/bfv.rs:311).
+// The result is a group element, so any exact algorithm gives identical bytes once normalised to
+// affine; parity is checked against oracle/oracle.c orc_msm.
+//
+// Algorithm: Pippenger with ONE bucket set per MSM and per-window precomputed bases.
+//   * The SRS is fixed, HBM is 288 GB: zkfhe_basis_create stores T[w][i] = 2^(c*w) * P_i for every
+//     signed window w (n*W*64 bytes; 10 MiB at n = 2^13, c = 13).  Digit d of scalar i in window w then
+//     contributes sign(d) * T[w][i] to bucket |d| -- all windows share the same 2^(c-1) buckets, so
+//     there is one bucket reduction per MSM and no window-combining doublings at all.
+//   * Scalars are taken out of Montgomery form and folded to sign-magnitude (s > r/2 -> r - s with the
+//     point negated), so the "negative small" witness values (r - x) cost as little as small ones,
+//     and zero digits are skipped.
+//   * entries (bucket, table index, sign) are counting-sorted per MSM (global-atomic histogram,
+//     exclusive scan, scatter); one thread then sums one bucket with XYZZ mixed additions.  Buckets
+//     longer than HEAVY_T entries (skewed witness columns: thousands of 0/1 cells) are summed by a
+//     whole workgroup each.
+//   * bucket reduction sum_b b*B_b: 256 threads per MSM, running sums over groups of buckets, then a
+//     weighted tree in LDS; the result is normalised to affine in the same kernel.
+// All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
+#include <cstring>
+
+#include "ctx.hpp"
+
+using namespace zk;
+
+namespace {
+
+constexpr int HEAVY_T = 192;       // bucket length above which a workgroup sums the bucket
+constexpr int RED_THREADS = 256;   // threads of the bucket-reduction kernel
+
+// (r-1)/2 as canonical limbs: scalars above it are negated
+__device__ __forceinline__ bool fr_gt_half(const Fr &s) {
+  const u32 H[8] = {0xf8000000u, 0xa1f0fac9u, 0x3cdcb848u, 0x9419f424u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+  // compare s > H from the top limb
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    if (s.l[i] > H[i]) return true;
+    if (s.l[i] < H[i]) return false;
+  }
+  return false;
+}
+
+struct Digits {
+  int c, windows;
+};
+
+// signed-window digits of the sign-magnitude scalar.  Calls f(w, bucket (1..2^(c-1)), negative)
+template <class F>
+__device__ __forceinline__ void for_each_digit(const Fr &mont, int c, int windows, F f) {
+  Fr s = fp_from_mont<FrP>(mont);
+  bool neg = fr_gt_half(s);
+  if (neg) s = fp_neg<FrP>(s);  // r - s  (s != 0 here)
+  u32 carry = 0;
+  const u32 mask = (1u << c) - 1, halfv = 1u << (c - 1);
+  for (int w = 0; w < windows; ++w) {
+    const int bit = w * c;
+    const int limb = bit >> 5, sh = bit & 31;
+    u32 v = limb < 8 ? s.l[limb] >> sh : 0u;
+    if (sh + c > 32 && limb + 1 < 8) v |= s.l[limb + 1] << (32 - sh);
+    v = (v & mask) + carry;
+    bool dneg = false;
+    if (v > halfv) {
+      v = (1u << c) - v;
+      dneg = true;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    if (v) f(w, v, neg != dneg);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_msm_hist(const Fr *__restrict__ scalars, size_t n, size_t n_cols, int c, int windows,
+                                                  unsigned *__restrict__ hist /* [n_cols][K+1] */, unsigned K1) {
+  const size_t total = n * n_cols;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t col = g / n;
+    unsigned *h = hist + col * K1;
+    for_each_digit(scalars[g], c, windows, [&](int, u32 b, bool) { atomicAdd(&h[b], 1u); });
+  }
+}
+
+// per column exclusive scan of hist[1..K] -> off[0..K]: bucket value v (1..K) owns sorted entries
+// [off[v-1], off[v]); cursor[v] starts at off[v-1].  One block per column.
+__global__ void __launch_bounds__(256) k_msm_scan(const unsigned *__restrict__ hist, unsigned *__restrict__ off,
+                                                  unsigned *__restrict__ cursor, unsigned K1) {
+  __shared__ unsigned part[256];
+  const unsigned *h = hist + (size_t)blockIdx.x * K1;
+  unsigned *o = off + (size_t)blockIdx.x * K1;
+  unsigned *cu = cursor + (size_t)blockIdx.x * K1;
+  const unsigned K = K1 - 1;
+  const unsigned per = (K + 255) / 256;
+  const unsigned lo = threadIdx.x * per, hi = min(lo + per, K);
+  unsigned s = 0;
+  for (unsigned b = lo; b < hi; ++b) s += h[b + 1];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  // exclusive scan of part (simple serial by one wave lane 0 is fine: 256 values)
+  if (threadIdx.x == 0) {
+    unsigned acc = 0;
+    for (int i = 0; i < 256; ++i) {
+      unsigned t = part[i];
+      part[i] = acc;
+      acc += t;
+    }
+  }
+  __syncthreads();
+  unsigned acc = part[threadIdx.x];
+  for (unsigned b = lo; b < hi; ++b) {
+    o[b] = acc;       // start of bucket b+1
+    cu[b + 1] = acc;  // scatter cursor of bucket b+1
+    acc += h[b + 1];
+  }
+  if (hi == K) o[K] = acc;  // total (every thread past the end writes the same value)
+}
+
+__global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scalars, size_t n, size_t n_cols, int c, int windows,
+                                                     unsigned *__restrict__ cursor, unsigned K1, unsigned *__restrict__ entries,
+                                                     size_t col_entries) {
+  const size_t total = n * n_cols;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t col = g / n;
+    const unsigned i = (unsigned)(g - col * n);
+    unsigned *cu = cursor + col * K1;
+    unsigned *e = entries + col * col_entries;
+    for_each_digit(scalars[g], c, windows, [&](int w, u32 b, bool neg) {
+      const unsigned pos = atomicAdd(&cu[b], 1u);
+      e[pos] = ((unsigned)w * (unsigned)n + i) | (neg ? 0x80000000u : 0u);
+    });
+  }
+}
+
+// one thread per (column, bucket): XYZZ accumulation of the bucket's entries
+__global__ void __launch_bounds__(256) k_msm_accumulate(const unsigned *__restrict__ off, const unsigned *__restrict__ entries,
+                                                        size_t col_entries, const G1Affine *__restrict__ table, unsigned K,
+                                                        size_t n_cols, G1X *__restrict__ buckets, unsigned *__restrict__ heavy_count,
+                                                        unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
+  const size_t total = (size_t)K * n_cols;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t col = g / K;
+    const unsigned b = (unsigned)(g - col * K);  // bucket value b+1
+    const unsigned *o = off + col * (K + 1);
+    const unsigned lo = o[b], hi = o[b + 1];
+    if (hi - lo > (unsigned)HEAVY_T) {
+      const unsigned slot = atomicAdd(heavy_count, 1u);
+      if (slot < heavy_cap) {
+        heavy_list[2 * slot] = (unsigned)col;
+        heavy_list[2 * slot + 1] = b;
+      }
+      continue;
+    }
+    const unsigned *e = entries + col * col_entries;
+    G1X acc = G1X::identity();
+    for (unsigned k = lo; k < hi; ++k) {
+      const unsigned en = e[k];
+      const G1Affine p = table[en & 0x7fffffffu];
+      g1x_add_affine(acc, p, (en >> 31) != 0);
+    }
+    buckets[g] = acc;
+  }
+}
+
+// one workgroup per heavy bucket: 256 partial sums, LDS tree
+__global__ void __launch_bounds__(256) k_msm_accumulate_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ entries,
+                                                              size_t col_entries, const G1Affine *__restrict__ table, unsigned K,
+                                                              G1X *__restrict__ buckets, const unsigned *__restrict__ heavy_count,
+                                                              const unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
+  __shared__ G1X sh[256];
+  unsigned cnt = *heavy_count;
+  if (cnt > heavy_cap) cnt = heavy_cap;
+  for (unsigned h = blockIdx.x; h < cnt; h += gridDim.x) {
+    const size_t col = heavy_list[2 * h];
+    const unsigned b = heavy_list[2 * h + 1];
+    const unsigned *o = off + col * (K + 1);
+    const unsigned lo = o[b], hi = o[b + 1];
+    const unsigned *e = entries + col * col_entries;
+    G1X acc = G1X::identity();
+    for (unsigned k = lo + threadIdx.x; k < hi; k += 256) {
+      const unsigned en = e[k];
+      const G1Affine p = table[en & 0x7fffffffu];
+      g1x_add_affine(acc, p, (en >> 31) != 0);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        G1X a = sh[threadIdx.x];
+        g1x_add(a, sh[threadIdx.x + s]);
+        sh[threadIdx.x] = a;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[col * K + b] = sh[0];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ G1X g1x_mul_pow2(G1X p, int k) {
+  for (int i = 0; i < k; ++i) p = g1x_dbl(p);
+  return p;
+}
+
+// sum_{j=1..K} j * B_j for one MSM per block (RED_THREADS threads), result -> affine.
+// Level 1: thread q owns buckets q*g+1 .. q*g+g (g = K/RED_THREADS, >= 1): S_q = sum B, T_q = sum s*B_{qg+s}.
+//   total = sum_q T_q + g * sum_q q*S_q.
+// Level 2: weighted tree over q in LDS: node = (S, W = sum (q - lo) S_q, T);  merge(L, Rn) of width m:
+//   S = SL + SR, W = WL + WR + m*SR, T = TL + TR.
+__global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restrict__ buckets, unsigned K, G1Affine *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char red_lds[];
+  G1X *shS = (G1X *)red_lds;
+  G1X *shW = shS + RED_THREADS;
+  const size_t col = blockIdx.x;
+  const G1X *B = buckets + col * K;
+  const unsigned q = threadIdx.x;
+  unsigned g = K / RED_THREADS;
+  unsigned nthr = RED_THREADS;
+  if (g == 0) {
+    g = 1;
+    nthr = K;
+  }
+  G1X S = G1X::identity(), T = G1X::identity();
+  if (q < nthr) {
+    for (int s = (int)g - 1; s >= 0; --s) {
+      g1x_add(S, B[(size_t)q * g + s]);
+      g1x_add(T, S);
+    }
+  }
+  // tree over S with weights q, and plain sum of T.  T is summed through shW in a first sweep.
+  shW[q] = T;
+  __syncthreads();
+  for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)q < s) {
+      G1X a = shW[q];
+      g1x_add(a, shW[q + s]);
+      shW[q] = a;
+    }
+    __syncthreads();
+  }
+  G1X Tsum = shW[0];
+  __syncthreads();
+  shS[q] = S;
+  shW[q] = G1X::identity();
+  __syncthreads();
+  int logm = 0;
+  for (int m = 1; m < RED_THREADS; m <<= 1, ++logm) {
+    // nodes of width m at positions multiple of m; merge pairs (2m*t, 2m*t + m)
+    if ((q & (2 * m - 1)) == 0) {
+      G1X SL = shS[q], WL = shW[q];
+      const G1X SR = shS[q + m], WR = shW[q + m];
+      g1x_add(WL, WR);
+      g1x_add(WL, g1x_mul_pow2(SR, logm));
+      g1x_add(SL, SR);
+      shS[q] = SL;
+      shW[q] = WL;
+    }
+    __syncthreads();
+  }
+  if (q == 0) {
+    G1X W = shW[0];
+    int logg = 0;
+    while ((1u << logg) < g) ++logg;
+    W = g1x_mul_pow2(W, logg);
+    g1x_add(W, Tsum);
+    out[col] = g1x_to_affine(W);
+  }
+}
+
+// table[w][i] = 2^(c*w) * P_i
+__global__ void __launch_bounds__(256) k_basis_table(const G1Affine *__restrict__ bases, size_t n, int c, int windows,
+                                                     G1Affine *__restrict__ table) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p = bases[i];
+  table[i] = p;
+  G1X cur = g1x_from_affine(p);
+  for (int w = 1; w < windows; ++w) {
+    cur = g1x_mul_pow2(cur, c);
+    G1Affine a = g1x_to_affine(cur);
+    table[(size_t)w * n + i] = a;
+    cur = g1x_from_affine(a);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_g1_add(const G1Affine *__restrict__ a, const G1Affine *__restrict__ b,
+                                                G1Affine *__restrict__ out, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1X acc = g1x_from_affine(a[i]);
+  g1x_add_affine(acc, b[i], false);
+  out[i] = g1x_to_affine(acc);
+}
+
+__global__ void __launch_bounds__(256) k_g1_mul(const G1Affine *__restrict__ p, const Fr *__restrict__ k,
+                                                G1Affine *__restrict__ out, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr s = fp_from_mont<FrP>(k[i]);
+  const G1Affine base = p[i];
+  G1X acc = G1X::identity();
+  for (int bit = 255; bit >= 0; --bit) {
+    acc = g1x_dbl(acc);
+    if ((s.l[bit >> 5] >> (bit & 31)) & 1) g1x_add_affine(acc, base, false);
+  }
+  out[i] = g1x_to_affine(acc);
+}
+
+int default_window_bits(size_t n) {
+  if (n <= 64) return 5;
+  if (n <= 1024) return 8;
+  if (n <= 4096) return 11;
+  if (n <= 16384) return 13;
+  if (n <= 131072) return 14;
+  return 16;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t n, int window_bits, zkfhe_basis **out) {
+  ZK_ARG(ctx, out != nullptr && bases_host != nullptr && n > 0);
+  ZK_ARG(ctx, window_bits == 0 || (window_bits >= 2 && window_bits <= 16));
+  const int c = window_bits ? window_bits : default_window_bits(n);
+  const int windows = (254 + c - 1) / c;
+  ZK_ARG(ctx, (size_t)windows * n < ((size_t)1 << 31));
+  zkfhe_basis *b = new zkfhe_basis();
+  b->n = n;
+  b->c = c;
+  b->windows = windows;
+  hipError_t e = hipMalloc((void **)&b->table, (size_t)windows * n * sizeof(G1Affine));
+  if (e != hipSuccess) {
+    delete b;
+    return zk_fail(ctx, e == hipErrorOutOfMemory ? ZKFHE_ENOMEM : ZKFHE_EHIP, "hipMalloc(basis table)", e, __FILE__, __LINE__);
+  }
+  void *tmp;
+  int rc = zk_scratch(ctx, 0, n * sizeof(G1Affine), &tmp);
+  if (rc) return rc;
+  ZK_HIP(ctx, hipMemcpyAsync(tmp, bases_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+  k_basis_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)tmp, n, c, windows, b->table);
+  ZK_LAUNCH_CHECK(ctx);
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = b;
+  return ZKFHE_OK;
+}
+
+int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis) {
+  if (!basis) return ZKFHE_OK;
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(basis->table);
+  delete basis;
+  return ZKFHE_OK;
+}
+
+size_t zkfhe_basis_len(const zkfhe_basis *basis) { return basis ? basis->n : 0; }
+
+int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols, zkfhe_g1_affine *out_dev) {
+  ZK_ARG(ctx, basis != nullptr);
+  if (!n_cols) return ZKFHE_OK;
+  ZK_ARG(ctx, scalars_dev != nullptr && out_dev != nullptr);
+  const size_t n = basis->n;
+  const int c = basis->c, W = basis->windows;
+  const unsigned K = 1u << (c - 1), K1 = K + 1;
+  const size_t col_entries = n * (size_t)W;
+  const size_t heavy_cap = (n_cols * col_entries) / HEAVY_T + 1;
+  // scratch 1: hist | off | cursor | heavy_count | heavy_list     scratch 2: entries     scratch 0: buckets
+  const size_t words = 3 * n_cols * K1 + 4 + 2 * heavy_cap;
+  void *p1, *p2, *p0;
+  int rc = zk_scratch(ctx, 1, words * sizeof(unsigned), &p1);
+  if (rc) return rc;
+  rc = zk_scratch(ctx, 2, n_cols * col_entries * sizeof(unsigned), &p2);
+  if (rc) return rc;
+  rc = zk_scratch(ctx, 0, n_cols * (size_t)K * sizeof(G1X), &p0);
+  if (rc) return rc;
+  unsigned *hist = (unsigned *)p1;
+  unsigned *off = hist + n_cols * K1;
+  unsigned *cursor = off + n_cols * K1;
+  unsigned *heavy_count = cursor + n_cols * K1;
+  unsigned *heavy_list = heavy_count + 4;
+  unsigned *entries = (unsigned *)p2;
+  G1X *buckets = (G1X *)p0;
+  ZK_HIP(ctx, hipMemsetAsync(hist, 0, n_cols * K1 * sizeof(unsigned), ctx->stream));
+  ZK_HIP(ctx, hipMemsetAsync(heavy_count, 0, 4 * sizeof(unsigned), ctx->stream));
+  const size_t total = n * n_cols;
+  unsigned grid = zk_blocks(total, 256);
+  const unsigned cap = (unsigned)ctx->num_cu * 16;
+  if (grid > cap) grid = cap;
+  k_msm_hist<<<grid, 256, 0, ctx->stream>>>((const Fr *)scalars_dev, n, n_cols, c, W, hist, K1);
+  ZK_LAUNCH_CHECK(ctx);
+  k_msm_scan<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(hist, off, cursor, K1);
+  ZK_LAUNCH_CHECK(ctx);
+  k_msm_scatter<<<grid, 256, 0, ctx->stream>>>((const Fr *)scalars_dev, n, n_cols, c, W, cursor, K1, entries, col_entries);
+  ZK_LAUNCH_CHECK(ctx);
+  const size_t nb = (size_t)K * n_cols;
+  unsigned gridb = zk_blocks(nb, 256);
+  k_msm_accumulate<<<gridb, 256, 0, ctx->stream>>>(off, entries, col_entries, basis->table, K, n_cols, buckets, heavy_count,
+                                                   heavy_list, (unsigned)heavy_cap);
+  ZK_LAUNCH_CHECK(ctx);
+  unsigned gridh = (unsigned)(heavy_cap < 1024 ? heavy_cap : 1024);
+  k_msm_accumulate_heavy<<<gridh, 256, 0, ctx->stream>>>(off, entries, col_entries, basis->table, K, buckets, heavy_count, heavy_list,
+                                                         (unsigned)heavy_cap);
+  ZK_LAUNCH_CHECK(ctx);
+  static bool red_attr = false;
+  const int red_lds = 2 * RED_THREADS * (int)sizeof(G1X);
+  if (!red_attr) {
+    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, red_lds));
+    red_attr = true;
+  }
+  k_msm_reduce<<<(unsigned)n_cols, RED_THREADS, red_lds, ctx->stream>>>(buckets, K, (G1Affine *)out_dev);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_g1_add<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)a, (const G1Affine *)b, (G1Affine *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+int zkfhe_g1_mul(zkfhe_ctx *ctx, const zkfhe_g1_affine *p, const zkfhe_fr *k, zkfhe_g1_affine *out, size_t n) {
+  if (!n) return ZKFHE_OK;
+  k_g1_mul<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)p, (const Fr *)k, (G1Affine *)out, n);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+// Batched NTT / iNTT / coset NTT over BN254 Fr for gfx950.
+//
+// Replaces halo2_proofs `arithmetic::best_fft` and `EvaluationDomain::{lagrange_to_coeff,
+// coeff_to_extended, extended_to_coeff}` (third-party; reached from reference examples/bfv.rs:311;
+// semantics restated in oracle/oracle.c orc_fft / orc_ntt / orc_coset_ntt).  The DFT is unique, so
+// the algorithm is free: this is an autosort Stockham transform, natural order in and out, with no
+// bit-reversal pass.
+//
+// Tile kernel (2^3 <= n <= 2^13): ONE workgroup per column, n/8 threads, 8 coefficients per thread
+// held in VGPRs (64 VGPRs of data).  Each pass is a radix-8 (or final radix-4/2) butterfly done
+// entirely in registers; between passes the column is transposed through LDS.  A 2^13 column is
+// 256 KiB -- more than the 160 KiB LDS -- so the transpose moves the low and the high 16 bytes of
+// every element in two rounds of ds_write_b128 / ds_read_b128 (144 KiB with the +1/8 padding that
+// keeps the stride-8 writes of the first pass bank-conflict-free).  HBM traffic is the
+// algorithmic minimum: every coefficient is read once and written once, both as full 2 KiB-per-wave
+// coalesced runs; twiddles come from an omega^j table that all columns share (L2 resident).
+//
+// Larger n: log2(n/2^13) radix-2 DIF stages over the whole vector (coalesced), then the tile kernel on
+// each contiguous 2^13 block with a strided scatter to natural order (round-1 implementation; the
+// prover itself never needs it, see zkfhe_coset_ntt_batch which keeps the extended domain coset-major).
+#include <cstring>
+
+#include "ctx.hpp"
+#include "ntt_tile.cuh"
+
+using namespace zk;
+
+int zk_launch_tile_3(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_4(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_5(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_6(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_7(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_8(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_9(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_10(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_11(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_12(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+int zk_launch_tile_13(zkfhe_ctx *ctx, const zk::TileArgs &a, unsigned tiles, unsigned cols);
+
+namespace {
+
+// one radix-2 DIF stage over vectors of length n (all columns): pairs (j, j+half) inside blocks of 2*half
+//   a' = a + b ; b' = (a - b) * omega_n^(j * n/(2*half)),  j = index inside the half
+__global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t n_cols, int log_n, int log_half,
+                                                   const Fr *__restrict__ tw_n /* omega_n^j, j < n/2 */) {
+  const size_t half = (size_t)1 << log_half;
+  const size_t per_col = (size_t)1 << (log_n - 1);
+  const size_t total = n_cols * per_col;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = g >> (log_n - 1);
+    const size_t i = g & (per_col - 1);
+    const size_t j = i & (half - 1);
+    const size_t blk = i >> log_half;
+    Fr *p = data + (c << log_n) + (blk << (log_half + 1)) + j;
+    Fr x = p[0], y = p[half];
+    Fr s = x + y, d = x - y;
+    const size_t e = j << (log_n - 1 - log_half);
+    p[0] = s;
+    p[half] = e ? d * tw_n[e] : d;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pow_table(Fr base, Fr *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr r = Fr::one();
+    Fr b = base;
+    for (size_t e = i; e; e >>= 1) {
+      if (e & 1) r = r * b;
+      b = fp_sqr<FrP>(b);
+    }
+    out[i] = r;
+  }
+}
+
+// out[i] = start * base^i
+__global__ void __launch_bounds__(256) k_pow_table_scaled(Fr start, Fr base, Fr *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr r = start;
+    Fr b = base;
+    for (size_t e = i; e; e >>= 1) {
+      if (e & 1) r = r * b;
+      b = fp_sqr<FrP>(b);
+    }
+    out[i] = r;
+  }
+}
+
+// extended_to_coeff combine: for each (column, i2 < n): the 2^lef values A[k1][i2] (k1-major rows of
+// length n) hold, after the row iNTTs (scaled by n^-1), (1/n) sum_k2 F[k1][k2] w^(-i2 k2).  Then
+// coefficient i1*n + i2 = g^-(i1*n+i2) * 2^-lef * sum_k1 A[k1][i2] * w_ext^(-k1 (i1*n + i2))
+//                       = scale[i1*n+i2] * sum_k1 (A[k1][i2] * w_ext^(-k1 i2)) * w_E^(-k1 i1),  E = 2^lef.
+// LEF in {1,2,3}.
+template <int LEF>
+__global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows, Fr *__restrict__ out, size_t n_cols, int log_n,
+                                                     const Fr *__restrict__ tw_ext_inv /* w_ext^-j, j < n*E */,
+                                                     const Fr *__restrict__ scale /* 2^-lef g^-j, j < n*E */) {
+  constexpr int E = 1 << LEF;
+  const size_t n = (size_t)1 << log_n;
+  const size_t total = n_cols * n;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = g >> log_n, i2 = g & (n - 1);
+    const Fr *src = rows + c * n * E;
+    Fr v[E];
+#pragma unroll
+    for (int k1 = 0; k1 < E; ++k1) {
+      Fr x = src[(size_t)k1 * n + i2];
+      v[k1] = k1 ? x * tw_ext_inv[(size_t)k1 * i2] : x;
+    }
+    // DFT_E with root w_E^-1 = w_ext^-(n)
+    Fr o[E];
+#pragma unroll
+    for (int i1 = 0; i1 < E; ++i1) {
+      Fr acc = v[0];
+#pragma unroll
+      for (int k1 = 1; k1 < E; ++k1) {
+        const int e = (k1 * i1) & (E - 1);
+        acc = acc + (e ? v[k1] * tw_ext_inv[(size_t)e * n] : v[k1]);
+      }
+      o[i1] = acc;
+    }
+    Fr *dst = out + c * n * E;
+#pragma unroll
+    for (int i1 = 0; i1 < E; ++i1) dst[(size_t)i1 * n + i2] = o[i1] * scale[(size_t)i1 * n + i2];
+  }
+}
+
+int launch_tile_dyn(zkfhe_ctx *ctx, int log_tile, const TileArgs &a, unsigned tiles, unsigned cols) {
+  switch (log_tile) {
+    case 3: return zk_launch_tile_3(ctx, a, tiles, cols);
+    case 4: return zk_launch_tile_4(ctx, a, tiles, cols);
+    case 5: return zk_launch_tile_5(ctx, a, tiles, cols);
+    case 6: return zk_launch_tile_6(ctx, a, tiles, cols);
+    case 7: return zk_launch_tile_7(ctx, a, tiles, cols);
+    case 8: return zk_launch_tile_8(ctx, a, tiles, cols);
+    case 9: return zk_launch_tile_9(ctx, a, tiles, cols);
+    case 10: return zk_launch_tile_10(ctx, a, tiles, cols);
+    case 11: return zk_launch_tile_11(ctx, a, tiles, cols);
+    case 12: return zk_launch_tile_12(ctx, a, tiles, cols);
+    case 13: return zk_launch_tile_13(ctx, a, tiles, cols);
+  }
+  return zk_fail_msg(ctx, ZKFHE_EINVAL, "tile size out of range");
+}
+
+}  // namespace
+
+int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
+  auto it = ctx->domains.find(log_n);
+  if (it == ctx->domains.end()) {
+    NttDomain d;
+    d.log_n = log_n;
+    const size_t n = (size_t)1 << log_n;
+    d.omega = zk_fr_root_of_unity(log_n);
+    d.omega_inv = fp_inv<FrP>(d.omega);
+    d.n_inv = fp_inv<FrP>(zk_fr_from_u64((uint64_t)n));
+    ZK_HIP(ctx, hipMalloc((void **)&d.fwd, n * sizeof(Fr)));
+    ZK_HIP(ctx, hipMalloc((void **)&d.inv, n * sizeof(Fr)));
+    unsigned grid = zk_blocks(n, 256);
+    if (grid > 4096) grid = 4096;
+    k_pow_table<<<grid, 256, 0, ctx->stream>>>(d.omega, d.fwd, n);
+    ZK_LAUNCH_CHECK(ctx);
+    k_pow_table<<<grid, 256, 0, ctx->stream>>>(d.omega_inv, d.inv, n);
+    ZK_LAUNCH_CHECK(ctx);
+    it = ctx->domains.emplace(log_n, d).first;
+  }
+  *out = &it->second;
+  return ZKFHE_OK;
+}
+
+#define MAX_TILE_LOG 13
+
+extern "C" {
+
+int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse) {
+  ZK_ARG(ctx, log_n >= 1 && log_n <= 26);
+  if (!n_cols) return ZKFHE_OK;
+  ZK_ARG(ctx, cols_dev != nullptr);
+  ZK_ARG(ctx, n_cols < 65536);
+  Fr *data = (Fr *)cols_dev;
+  const size_t n = (size_t)1 << log_n;
+  const NttDomain *dom;
+  int rc = zk_domain(ctx, log_n, &dom);
+  if (rc) return rc;
+  // n^-1 lives in device memory next to nothing else: keep a tiny scratch copy per call
+  Fr *ninv_dev = nullptr;
+  if (inverse) {
+    void *p;
+    rc = zk_scratch(ctx, 3, 64, &p);
+    if (rc) return rc;
+    ninv_dev = (Fr *)p;
+    ZK_HIP(ctx, hipMemcpyAsync(ninv_dev, &dom->n_inv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (log_n < 3) {
+    // tiny transforms: DIF stages then a bit-reversed gather is overkill; do log_n DIF stages and fix order on 2/4 points
+    // n = 2: one stage is the whole transform (bitrev of 1 bit is identity).  n = 4: outputs 1 and 2 swapped.
+    const Fr *tw = inverse ? dom->inv : dom->fwd;
+    for (int s = log_n - 1; s >= 0; --s) {
+      k_dif_stage<<<zk_blocks(n_cols * (n / 2), 256), 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+      ZK_LAUNCH_CHECK(ctx);
+    }
+    if (log_n == 2 || inverse) {
+      // finish on the host side of the stream with a trivial kernel-free path: reuse tile kernel is impossible (< 8);
+      // use the scale kernel for n^-1 and a swap through scratch.
+      void *p;
+      rc = zk_scratch(ctx, 0, n_cols * n * sizeof(Fr), &p);
+      if (rc) return rc;
+      Fr *tmp = (Fr *)p;
+      ZK_HIP(ctx, hipMemcpyAsync(tmp, data, n_cols * n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+      if (log_n == 2) {
+        // swap elements 1 and 2 of every column: strided 2D copies
+        ZK_HIP(ctx, hipMemcpy2DAsync(data + 1, 4 * sizeof(Fr), tmp + 2, 4 * sizeof(Fr), sizeof(Fr), n_cols, hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(ctx, hipMemcpy2DAsync(data + 2, 4 * sizeof(Fr), tmp + 1, 4 * sizeof(Fr), sizeof(Fr), n_cols, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      if (inverse) {
+        rc = zkfhe_fr_scale(ctx, (const zkfhe_fr *)data, (const zkfhe_fr *)&dom->n_inv, (zkfhe_fr *)data, n_cols * n);
+        if (rc) return rc;
+      }
+    }
+    return ZKFHE_OK;
+  }
+  if (log_n <= MAX_TILE_LOG) {
+    TileArgs a{};
+    a.in = data;
+    a.out = data;
+    a.col_stride_in = a.col_stride_out = n;
+    a.tw = inverse ? dom->inv : dom->fwd;
+    a.pre = nullptr;
+    a.post = ninv_dev;
+    a.log_tiles = 0;
+    a.in_len = (int)n;
+    a.out_natural_tiles = 1;
+    return launch_tile_dyn(ctx, log_n, a, 1, (unsigned)n_cols);
+  }
+  // large: DIF stages down to 2^13 blocks, then tile NTT per block with bit-reversed strided scatter
+  const int log_tiles = log_n - MAX_TILE_LOG;
+  const Fr *tw = inverse ? dom->inv : dom->fwd;
+  for (int s = log_n - 1; s >= MAX_TILE_LOG; --s) {
+    size_t work = n_cols * (n / 2);
+    unsigned grid = zk_blocks(work, 256);
+    unsigned cap = (unsigned)ctx->num_cu * 16;
+    if (grid > cap) grid = cap;
+    k_dif_stage<<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+    ZK_LAUNCH_CHECK(ctx);
+  }
+  const NttDomain *tdom;
+  rc = zk_domain(ctx, MAX_TILE_LOG, &tdom);
+  if (rc) return rc;
+  void *p;
+  rc = zk_scratch(ctx, 0, n_cols * n * sizeof(Fr), &p);
+  if (rc) return rc;
+  TileArgs a{};
+  a.in = data;
+  a.out = (Fr *)p;
+  a.col_stride_in = a.col_stride_out = n;
+  a.tw = inverse ? tdom->inv : tdom->fwd;
+  a.post = ninv_dev;
+  a.log_tiles = log_tiles;
+  a.in_len = 1 << MAX_TILE_LOG;
+  a.out_natural_tiles = 0;
+  rc = launch_tile_dyn(ctx, MAX_TILE_LOG, a, 1u << log_tiles, (unsigned)n_cols);
+  if (rc) return rc;
+  ZK_HIP(ctx, hipMemcpyAsync(data, p, n_cols * n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  return ZKFHE_OK;
+}
+
+int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n,
+                          int log_ext_factor, const zkfhe_fr *g_host, int inverse) {
+  ZK_ARG(ctx, log_n >= 3 && log_n <= MAX_TILE_LOG);
+  ZK_ARG(ctx, log_ext_factor >= 1 && log_ext_factor <= 3);
+  ZK_ARG(ctx, g_host != nullptr);
+  if (!n_cols) return ZKFHE_OK;
+  ZK_ARG(ctx, in_dev != nullptr && out_dev != nullptr && n_cols < 65536);
+  const int lef = log_ext_factor, E = 1 << lef;
+  const size_t n = (size_t)1 << log_n, ne = n * E;
+  Fr g;
+  memcpy(&g, g_host, 32);
+  const NttDomain *dom, *edom;
+  int rc = zk_domain(ctx, log_n, &dom);
+  if (rc) return rc;
+  rc = zk_domain(ctx, log_n + lef, &edom);
+  if (rc) return rc;
+  void *p;
+  if (!inverse) {
+    // row k1: NTT_n of x[i] * (g * w_ext^k1)^i.  pre table: [k1][i]
+    rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
+    if (rc) return rc;
+    Fr *pre = (Fr *)p;
+    Fr shift = g;
+    for (int k1 = 0; k1 < E; ++k1) {
+      k_pow_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(shift, pre + (size_t)k1 * n, n);
+      ZK_LAUNCH_CHECK(ctx);
+      shift = shift * edom->omega;
+    }
+    TileArgs a{};
+    a.in = (const Fr *)in_dev;
+    a.out = (Fr *)out_dev;
+    a.col_stride_in = n;
+    a.col_stride_out = ne;
+    a.tw = dom->fwd;
+    a.pre = pre;
+    a.pre_tile_stride = n;
+    a.post = nullptr;
+    a.log_tiles = lef;
+    a.in_len = (int)n;
+    a.out_natural_tiles = 1;
+    // every tile of a column reads the SAME n input coefficients: in tile stride must be 0.
+    // k_ntt_tile addresses tiles at in + b*N, so launch one grid row per k1 with shifted out/pre pointers.
+    for (int k1 = 0; k1 < E; ++k1) {
+      TileArgs ak = a;
+      ak.out = (Fr *)out_dev + (size_t)k1 * n;
+      ak.pre = pre + (size_t)k1 * n;
+      ak.pre_tile_stride = 0;
+      rc = launch_tile_dyn(ctx, log_n, ak, 1, (unsigned)n_cols);
+      if (rc) return rc;
+    }
+    return ZKFHE_OK;
+  }
+  // inverse: rows iNTT (size n, scaled by n^-1) into scratch, then combine across k1
+  rc = zk_scratch(ctx, 0, n_cols * ne * sizeof(Fr), &p);
+  if (rc) return rc;
+  Fr *rows = (Fr *)p;
+  void *q;
+  rc = zk_scratch(ctx, 3, 64, &q);
+  if (rc) return rc;
+  ZK_HIP(ctx, hipMemcpyAsync(q, &dom->n_inv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  TileArgs a{};
+  a.in = (const Fr *)in_dev;
+  a.out = rows;
+  a.col_stride_in = ne;
+  a.col_stride_out = ne;
+  a.tw = dom->inv;
+  a.post = (const Fr *)q;
+  a.log_tiles = lef;
+  a.in_len = (int)n;
+  a.out_natural_tiles = 1;
+  rc = launch_tile_dyn(ctx, log_n, a, (unsigned)E, (unsigned)n_cols);
+  if (rc) return rc;
+  // scale[j] = 2^-lef * g^-j
+  rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
+  if (rc) return rc;
+  Fr *scale = (Fr *)p;
+  Fr einv = fp_inv<FrP>(zk_fr_from_u64((uint64_t)E));
+  Fr ginv = fp_inv<FrP>(g);
+  k_pow_table_scaled<<<zk_blocks(ne, 256), 256, 0, ctx->stream>>>(einv, ginv, scale, ne);
+  ZK_LAUNCH_CHECK(ctx);
+  unsigned grid = zk_blocks(n_cols * n, 256);
+  if (lef == 1) k_ext_combine<1><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv, scale);
+  else if (lef == 2) k_ext_combine<2><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv, scale);
+  else k_ext_combine<3><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv, scale);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+}  // extern "C"
