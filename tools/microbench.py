@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks behind the roofline numbers in DESIGN.md: Fr modmul/s (ALU bound of every kernel),
+element-wise Fr mul GB/s (HBM-bound reference point), NTT and MSM sweeps.  Run on the GPU box."""
+import json
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    from oracle import binding as orc
+    ctx = zk.Context(0)
+    rng = np.random.default_rng(1)
+    res = {}
+    # modmul throughput: n independent chains of `iters` squarings
+    n, iters = 1 << 20, 512
+    raw = np.frombuffer(rng.bytes(32 * n), dtype=np.uint64).reshape(n, 4).copy()
+    raw[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+    d = ctx.to_device(raw)
+    o = ctx.alloc(n * 32)
+    for _ in range(2):
+        ctx._check(ctx.lib.zkfhe_fr_sqr_chain(ctx.h, d.at(0), o.at(0), n, iters))
+    ts = []
+    for _ in range(5):
+        ctx.timer_start()
+        ctx._check(ctx.lib.zkfhe_fr_sqr_chain(ctx.h, d.at(0), o.at(0), n, iters))
+        ts.append(ctx.timer_stop_ms())
+    ms = float(np.median(ts))
+    res["modmul_per_s"] = n * iters / (ms * 1e-3)
+    # element-wise mul: 96 B per element
+    for _ in range(2):
+        ctx.fr_binop_dev("mul", d, d, o, n)
+    ts = []
+    for _ in range(10):
+        ctx.timer_start()
+        ctx.fr_binop_dev("mul", d, d, o, n)
+        ts.append(ctx.timer_stop_ms())
+    ms = float(np.median(ts))
+    res["fr_mul_elementwise_GBs"] = 64.0 * n / (ms * 1e-3) / 1e9  # a==b: 32 B read + 32 B write
+    ts = []
+    for _ in range(10):
+        ctx.timer_start()
+        ctx.fr_binop_dev("add", d, d, o, n)
+        ts.append(ctx.timer_stop_ms())
+    res["fr_add_elementwise_GBs"] = 64.0 * n / (float(np.median(ts)) * 1e-3) / 1e9
+    # NTT sweep, 256 columns
+    res["ntt"] = {}
+    for log_n in (10, 12, 13, 15, 16):
+        cols = 256 if log_n <= 13 else 32
+        buf = ctx.alloc(cols * (32 << log_n))
+        ctx._check(ctx.lib.zkfhe_memset_dev(ctx.h, buf.at(0), 1, buf.nbytes))
+        for _ in range(2):
+            ctx.ntt_dev(buf, cols, log_n, False)
+        ts = []
+        for _ in range(10):
+            ctx.timer_start()
+            ctx.ntt_dev(buf, cols, log_n, False)
+            ts.append(ctx.timer_stop_ms())
+        ms = float(np.median(ts))
+        res["ntt"]["2^%d x %d" % (log_n, cols)] = {"ms": ms, "GBs_algorithmic": 64.0 * cols * (1 << log_n) / (ms * 1e-3) / 1e9,
+                                                  "modmul_per_s": cols * (1 << log_n) / 2 * log_n / (ms * 1e-3)}
+        buf.free()
+    # MSM sweep: uniform scalars, n = 8192
+    nn = 8192
+    bases = orc.g1_powers(orc.ints_to_mont([5])[0], orc.ints_to_mont([77])[0], nn)
+    res["msm"] = {}
+    for c in (10, 11, 12, 13, 14):
+        B = zk.Basis(ctx, bases, c)
+        for cols in (1, 16, 197):
+            raw = np.frombuffer(rng.bytes(32 * nn * cols), dtype=np.uint64).reshape(-1, 4).copy()
+            raw[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+            ds = ctx.to_device(raw)
+            do = ctx.alloc(cols * 64)
+            for _ in range(2):
+                ctx.msm_dev(B, ds, cols, do)
+            ts = []
+            for _ in range(5):
+                ctx.timer_start()
+                ctx.msm_dev(B, ds, cols, do)
+                ts.append(ctx.timer_stop_ms())
+            ms = float(np.median(ts))
+            res["msm"]["c=%d cols=%d" % (c, cols)] = {"ms": ms, "us_per_msm": ms * 1e3 / cols}
+            ds.free(), do.free()
+        B.destroy()
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
