@@ -193,3 +193,87 @@ def g1_powers(start, step, n):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def fr_scale(a, s):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_fr_scale(_p(a), _p(np.ascontiguousarray(s, dtype=np.uint64)), _p(out), ctypes.c_size_t(a.size // 4))
+    return out
+
+
+def fr_add_scalar(a, s):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_fr_add_scalar(_p(a), _p(np.ascontiguousarray(s, dtype=np.uint64)), _p(out), ctypes.c_size_t(a.size // 4))
+    return out
+
+
+def fr_axpy(acc, x, s):
+    """acc += s * x (in place on acc)"""
+    assert acc.flags["C_CONTIGUOUS"] and acc.dtype == np.uint64
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    lib().orc_fr_axpy(_p(acc), _p(x), _p(np.ascontiguousarray(s, dtype=np.uint64)), ctypes.c_size_t(x.size // 4))
+    return acc
+
+
+def fr_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_fr_mul_vec(_p(a), _p(b), _p(out), ctypes.c_size_t(a.size // 4))
+    return out
+
+
+def fr_add(a, b):
+    return fe_binop("add", a, b)
+
+
+def fr_sub(a, b):
+    return fe_binop("sub", a, b)
+
+
+def fr_prefix_prod(a, init):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty((a.shape[0] + 1, 4), dtype=np.uint64)
+    lib().orc_fr_prefix_prod(_p(a), _p(np.ascontiguousarray(init, dtype=np.uint64)), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fr_powers(start, base, n):
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_fr_powers(_p(np.ascontiguousarray(start, dtype=np.uint64)), _p(np.ascontiguousarray(base, dtype=np.uint64)), _p(out), ctypes.c_size_t(n))
+    return out
+
+
+def fr_div_linear(p, root):
+    p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(p)
+    lib().orc_fr_div_linear(_p(p), ctypes.c_size_t(p.shape[0]), _p(np.ascontiguousarray(root, dtype=np.uint64)), _p(out))
+    return out
+
+
+def fr_lincomb(cols, scalars):
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(n_cols, 4)
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_fr_lincomb(_p(cols), ctypes.c_size_t(n_cols), ctypes.c_size_t(n), _p(s), _p(out))
+    return out
+
+
+def fr_horner_batch(cols, xs):
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    xs = np.ascontiguousarray(xs, dtype=np.uint64).reshape(n_cols, 4)
+    out = np.empty((n_cols, 4), dtype=np.uint64)
+    lib().orc_fr_horner_batch(_p(cols), ctypes.c_size_t(n_cols), ctypes.c_size_t(n), _p(xs), _p(out))
+    return out
+
+
+def coset_ntt_cols(cols, log_ext, g):
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    n_cols, n_in = cols.shape[0], cols.shape[1]
+    out = np.empty((n_cols, 1 << log_ext, 4), dtype=np.uint64)
+    lib().orc_coset_ntt_cols(_p(cols), ctypes.c_size_t(n_cols), ctypes.c_size_t(n_in), _p(out), log_ext, _p(np.ascontiguousarray(g, dtype=np.uint64)))
+    return out

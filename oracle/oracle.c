@@ -71,6 +71,59 @@ EXPORT void orc_fr_horner(const fe_t *poly, size_t n, const fe_t *x, fe_t *out) 
   *out = acc;
 }
 
+
+/* ---- vector helpers used by the oracle prover (oracle/halo2_ref.py) ---- */
+EXPORT void orc_fr_scale(const fe_t *a, const fe_t *s, fe_t *out, size_t n) {
+#pragma omp parallel for if (n > 4096)
+  for (size_t i = 0; i < n; ++i) fe_mul(&FR, &out[i], &a[i], s);
+}
+EXPORT void orc_fr_add_scalar(const fe_t *a, const fe_t *s, fe_t *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) fe_add(&FR, &out[i], &a[i], s);
+}
+/* acc[i] += s * x[i] */
+EXPORT void orc_fr_axpy(fe_t *acc, const fe_t *x, const fe_t *s, size_t n) {
+#pragma omp parallel for if (n > 4096)
+  for (size_t i = 0; i < n; ++i) { fe_t t; fe_mul(&FR, &t, &x[i], s); fe_add(&FR, &acc[i], &acc[i], &t); }
+}
+EXPORT void orc_fr_mul_vec(const fe_t *a, const fe_t *b, fe_t *out, size_t n) {
+#pragma omp parallel for if (n > 4096)
+  for (size_t i = 0; i < n; ++i) fe_mul(&FR, &out[i], &a[i], &b[i]);
+}
+/* out[0] = init, out[i+1] = out[i] * a[i]  (out has n+1 entries) */
+EXPORT void orc_fr_prefix_prod(const fe_t *a, const fe_t *init, fe_t *out, size_t n) {
+  out[0] = *init;
+  for (size_t i = 0; i < n; ++i) fe_mul(&FR, &out[i + 1], &out[i], &a[i]);
+}
+/* out[i] = start * base^i */
+EXPORT void orc_fr_powers(const fe_t *start, const fe_t *base, fe_t *out, size_t n) {
+  fe_t cur = *start;
+  for (size_t i = 0; i < n; ++i) { out[i] = cur; fe_mul(&FR, &cur, &cur, base); }
+}
+/* q(X) = (p(X) - p(root)) / (X - root);  q has n-1 coefficients, out[n-1] = 0 */
+EXPORT void orc_fr_div_linear(const fe_t *p, size_t n, const fe_t *root, fe_t *out) {
+  fe_t carry; fe_zero(&carry);
+  fe_zero(&out[n - 1]);
+  for (size_t i = n - 1; i >= 1; --i) {
+    fe_t t; fe_mul(&FR, &t, &carry, root);
+    fe_add(&FR, &carry, &p[i], &t);
+    out[i - 1] = carry;
+  }
+}
+/* out = sum_j s[j] * cols[j]  (cols: n_cols x n contiguous) */
+EXPORT void orc_fr_lincomb(const fe_t *cols, size_t n_cols, size_t n, const fe_t *s, fe_t *out) {
+#pragma omp parallel for if (n > 1024)
+  for (size_t i = 0; i < n; ++i) {
+    fe_t acc; fe_zero(&acc);
+    for (size_t j = 0; j < n_cols; ++j) { fe_t t; fe_mul(&FR, &t, &cols[j * n + i], &s[j]); fe_add(&FR, &acc, &acc, &t); }
+    out[i] = acc;
+  }
+}
+/* many Horner evaluations: out[j] = cols[j](x[j]) */
+EXPORT void orc_fr_horner_batch(const fe_t *cols, size_t n_cols, size_t n, const fe_t *x, fe_t *out) {
+#pragma omp parallel for schedule(dynamic)
+  for (size_t j = 0; j < n_cols; ++j) orc_fr_horner(cols + j * n, n, &x[j], &out[j]);
+}
+
 /* ---- NTT ---- */
 static const uint64_t ROOT_OF_UNITY_CANON[4] = {  /* 7^((r-1)/2^28), canonical form; SURVEY section 4 KAT 4 */
   0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};
@@ -155,6 +208,13 @@ EXPORT void orc_coset_ntt(const fe_t *in, size_t n_in, fe_t *out, int log_ext, c
   }
 }
 
+/* batched forward coset extension: n_cols coefficient vectors of n_in -> n_cols x 2^log_ext */
+EXPORT void orc_coset_ntt_cols(const fe_t *in, size_t n_cols, size_t n_in, fe_t *out, int log_ext, const fe_t *g) {
+  size_t ne = (size_t)1 << log_ext;
+#pragma omp parallel for schedule(dynamic)
+  for (size_t c = 0; c < n_cols; ++c) orc_coset_ntt(in + c * n_in, n_in, out + c * ne, log_ext, g, 0);
+}
+
 /* ---- G1 ---- */
 EXPORT void orc_g1_add(const g1a_t *a, const g1a_t *b, g1a_t *out, size_t n) {
   for (size_t i = 0; i < n; ++i) {
@@ -166,6 +226,7 @@ EXPORT void orc_g1_add(const g1a_t *a, const g1a_t *b, g1a_t *out, size_t n) {
 
 /* out[i] = k[i] * p[i]; k in Montgomery Fr form */
 EXPORT void orc_g1_mul(const g1a_t *p, const fe_t *k, g1a_t *out, size_t n) {
+#pragma omp parallel for schedule(dynamic, 16) if (n > 64)
   for (size_t i = 0; i < n; ++i) {
     fe_t kc; fe_from_mont(&FR, &kc, &k[i]);
     g1j_t r; g1j_mul(&r, &p[i], kc.l);
