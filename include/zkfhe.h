@@ -130,6 +130,60 @@ int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint
 int zkfhe_witness_div_mod(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, uint64_t q, zkfhe_fr *div_dev,
                           zkfhe_fr *rem_dev, size_t n);
 
+/* ---- BFV circuit: witness tables, keygen, prove (reference examples/bfv.rs + halo2-scaffold run_eth) ---- */
+/* Runtime form of the compile-time constants at examples/bfv.rs:27-30. */
+typedef struct { uint64_t n; uint64_t q; uint64_t t; uint64_t b; } zkfhe_bfv_params;
+/* configs/<name>.json "params" + "break_points" (README.md:38).  With n_break_* == 0 and replay == 0 the
+ * break points are computed (keygen stage); with replay != 0 they are replayed (prover stage). */
+typedef struct {
+  uint32_t k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits;
+  const uint32_t *bp_gate0; uint32_t n_bp_gate0;
+  const uint32_t *bp_gate1; uint32_t n_bp_gate1;
+  const uint32_t *bp_rlc;   uint32_t n_bp_rlc;
+  int replay;
+} zkfhe_bfv_config;
+
+typedef struct zkfhe_bfv_tables zkfhe_bfv_tables;
+/* Host-only (no GPU): runs the circuit (examples/bfv.rs:63-304) on the JSON input text (CircuitInput,
+ * examples/bfv.rs:50-61) with RLC challenge `gamma` (32-byte LE canonical Fr) and places the cell streams
+ * into columns.  keygen_mode != 0 also produces the fixed columns and the copy constraints. */
+int zkfhe_bfv_build_tables(const char *input_json, const zkfhe_bfv_params *params, const zkfhe_bfv_config *config,
+                           const uint8_t gamma[32], int keygen_mode, zkfhe_bfv_tables **out, char *err, size_t err_len);
+void zkfhe_bfv_tables_free(zkfhe_bfv_tables *t);
+/* what: 0 n_advice, 1 n_fixed, 2 n rows, 3 n_instance, 4 n_copies, 5/6/7 number of break points gate0/gate1/rlc,
+ *       8/9/10 cells in the phase-0 / phase-1 gate / RLC stream, 11 lookup cells */
+size_t zkfhe_bfv_tables_count(const zkfhe_bfv_tables *t, int what);
+/* canonical (non-Montgomery) 4 x u64 values */
+int zkfhe_bfv_tables_copy_advice(const zkfhe_bfv_tables *t, uint64_t *out);     /* n_advice * n * 4 */
+int zkfhe_bfv_tables_copy_fixed(const zkfhe_bfv_tables *t, uint64_t *out);      /* n_fixed * n * 4  */
+int zkfhe_bfv_tables_copy_instance(const zkfhe_bfv_tables *t, uint64_t *out);   /* n_instance * 4   */
+int zkfhe_bfv_tables_copy_copies(const zkfhe_bfv_tables *t, uint64_t *out);     /* n_copies * 2 (cell = perm_col * n + row) */
+int zkfhe_bfv_tables_copy_break_points(const zkfhe_bfv_tables *t, int which, uint32_t *out);
+
+/* Unsafe seeded test SRS (the reference's gen_srs is an unsafe seeded setup as well, README.md:34): s derived
+ * from the seed, g[i] = s^i G, g_lagrange[i] = L_i(s) G, both computed on the GPU and kept as MSM bases. */
+typedef struct zkfhe_srs zkfhe_srs;
+int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out);
+int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs);
+
+/* keygen (README.md:28-38): circuit structure from the (empty) input, fixed + sigma polynomials, their
+ * commitments, the vk digest; everything the prover needs stays resident in HBM. */
+typedef struct zkfhe_bfv_pk zkfhe_bfv_pk;
+int zkfhe_bfv_keygen(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const zkfhe_bfv_params *params,
+                     const zkfhe_bfv_config *config, zkfhe_bfv_pk **out);
+int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk);
+/* 32-byte LE vk digest; counts of fixed / sigma commitments; the commitments as canonical affine (x||y, 64 B each) */
+int zkfhe_bfv_pk_info(const zkfhe_bfv_pk *pk, uint8_t vk_digest[32], uint32_t *n_fixed, uint32_t *n_sigma);
+int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t *sigma_out);
+int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count);
+
+/* prove (README.md:42-44): witness generation + create_proof.  seed: 32 bytes for the blinding stream.
+ * proof_out must hold proof_cap bytes; *proof_len receives the length.  instances_out (may be NULL): canonical
+ * 32-byte LE scalars, *n_instances in/out.  timings_ms (may be NULL): [witness, commit, quotient, open, total]. */
+int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk, const char *input_json,
+                    const uint8_t seed[32], uint8_t *proof_out, size_t proof_cap, size_t *proof_len,
+                    uint8_t *instances_out, size_t *n_instances, float *timings_ms);
+
 const char *zkfhe_version(void);
 
 #ifdef __cplusplus

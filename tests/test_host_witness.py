@@ -1,0 +1,76 @@
+"""Host (C++) witness generator behind the C ABI vs the oracle restatement and the reference's pinned layout.
+CPU only: zkfhe_bfv_build_tables does not touch the GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zk_fhe_amd as zk
+from oracle import binding as orc
+from oracle import circuit_ref as C
+from oracle import halo2_ref as H
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden", "bfv")
+PRM = (1024, 536870909, 7, 19)
+GAMMA = 0x0123456789ABCDEF0FEDCBA9876543210123456789ABCDEF0FEDCBA987654321 % H.R
+
+
+def ints(arr):
+    return orc.arr_to_ints(np.ascontiguousarray(arr).reshape(-1, 4))
+
+
+@pytest.fixture(scope="module")
+def pinned():
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    return cfgj, zk.BfvConfig.from_pinning(cfgj), H.Config.from_pinning(cfgj)
+
+
+@pytest.mark.parametrize("fname", ["bfv.in", "bfv_empty.in"])
+def test_tables_match_oracle_and_pinned_layout(pinned, fname):
+    cfgj, zcfg, hcfg = pinned
+    text = open(os.path.join(G, fname)).read()
+    # keygen stage: break points are COMPUTED and must equal the reference's configs/bfv.json
+    zcfg_nobp = zk.BfvConfig(zcfg.k, zcfg.n_gate0, zcfg.n_gate1, zcfg.n_lookup, zcfg.n_rlc, zcfg.unusable_rows, zcfg.lookup_bits)
+    t = zk.bfv_build_tables(text, PRM, zcfg_nobp, GAMMA, keygen_mode=True)
+    assert t["break_points"]["gate0"] == cfgj["break_points"]["gate"][0]
+    assert t["break_points"]["gate1"] == cfgj["break_points"]["gate"][1]
+    assert t["break_points"]["rlc"] == cfgj["break_points"]["rlc"]
+    assert t["cells"] == (23558, 1231992, 32764) and t["lookups"] == 286756
+    assert t["instance"].shape[0] == 5121
+    # oracle on the same input and challenge
+    prm = C.BfvParams()
+    inp = json.loads(text)
+    ctx0, pub, st = C.bfv_phase0(inp, prm)
+    ctx_gate, ctx_rlc = C.bfv_phase1(st, prm, GAMMA)
+    A = H.assign(hcfg, ctx0, ctx_gate, ctx_rlc, pub)
+    got_adv = ints(t["advice"])
+    want_adv = [v for col in A.advice for v in col]
+    assert got_adv == want_adv
+    assert ints(t["fixed"]) == [v for col in A.fixed for v in col]
+    assert ints(t["instance"]) == A.instance
+    n = hcfg.n
+    want_cp = sorted((min(a[0] * n + a[1], b[0] * n + b[1]), max(a[0] * n + a[1], b[0] * n + b[1])) for a, b in A.copies)
+    got_cp = sorted((int(min(a, b)), int(max(a, b))) for a, b in t["copies"])
+    assert got_cp == want_cp
+    # prover stage: replaying the pinned break points, values only
+    t2 = zk.bfv_build_tables(text, PRM, zcfg, GAMMA, keygen_mode=False, replay=True)
+    assert np.array_equal(t2["advice"], t["advice"])
+    assert t2["copies"].shape[0] == 0
+
+
+def test_bad_inputs_fail_with_status():
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    zcfg = zk.BfvConfig.from_pinning(cfgj)
+    inp = json.load(open(os.path.join(G, "bfv.in")))
+    bad = dict(inp)
+    bad["pk0"] = inp["pk0"][:-1]  # wrong degree -> assert_eq!(deg, N-1) of examples/bfv.rs:82
+    with pytest.raises(zk.ZkfheError):
+        zk.bfv_build_tables(json.dumps(bad), PRM, zcfg, 1, True)
+    bad = dict(inp)
+    bad["u"] = ["536870910"] + inp["u"][1:]  # coeff > modulus -> assert of src/poly.rs:28
+    with pytest.raises(zk.ZkfheError):
+        zk.bfv_build_tables(json.dumps(bad), PRM, zcfg, 1, True)
+    with pytest.raises(zk.ZkfheError):
+        zk.bfv_build_tables("{not json", PRM, zcfg, 1, True)

@@ -26,6 +26,11 @@ EXPORTS = [
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
     "zkfhe_g1_add", "zkfhe_g1_mul",
     "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",
+    "zkfhe_bfv_build_tables", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
+    "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
+    "zkfhe_bfv_tables_copy_break_points",
+    "zkfhe_srs_create", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove",
     "zkfhe_version",
 ]
 
@@ -303,3 +308,101 @@ class Context:
 
 def version():
     return load_library().zkfhe_version().decode()
+
+
+# ----------------------------------------------------------------------------- BFV circuit (host layer)
+class BfvParamsC(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("q", ctypes.c_uint64), ("t", ctypes.c_uint64), ("b", ctypes.c_uint64)]
+
+
+class BfvConfigC(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_uint32), ("n_gate0", ctypes.c_uint32), ("n_gate1", ctypes.c_uint32), ("n_lookup", ctypes.c_uint32),
+                ("n_rlc", ctypes.c_uint32), ("unusable_rows", ctypes.c_uint32), ("lookup_bits", ctypes.c_uint32),
+                ("bp_gate0", ctypes.POINTER(ctypes.c_uint32)), ("n_bp_gate0", ctypes.c_uint32),
+                ("bp_gate1", ctypes.POINTER(ctypes.c_uint32)), ("n_bp_gate1", ctypes.c_uint32),
+                ("bp_rlc", ctypes.POINTER(ctypes.c_uint32)), ("n_bp_rlc", ctypes.c_uint32),
+                ("replay", ctypes.c_int)]
+
+
+class BfvConfig:
+    """configs/<name>.json: column counts + break points (the reference's pinning, README.md:38)."""
+
+    def __init__(self, k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits=8, break_points=None):
+        self.k, self.n_gate0, self.n_gate1, self.n_lookup, self.n_rlc = k, n_gate0, n_gate1, n_lookup, n_rlc
+        self.unusable_rows, self.lookup_bits = unusable_rows, lookup_bits
+        self.break_points = break_points  # dict gate0/gate1/rlc or None
+
+    @staticmethod
+    def from_pinning(cfg_json):
+        p = cfg_json["params"]
+        bp = cfg_json.get("break_points")
+        bpd = None
+        if bp:
+            bpd = {"gate0": bp["gate"][0], "gate1": bp["gate"][1], "rlc": bp["rlc"]}
+        return BfvConfig(p["degree"], p["num_range_advice"][0], p["num_range_advice"][1], p["num_lookup_advice"][1],
+                         p["num_rlc_columns"], p["unusable_rows"], p["lookup_bits"], bpd)
+
+    def to_c(self, replay):
+        c = BfvConfigC(self.k, self.n_gate0, self.n_gate1, self.n_lookup, self.n_rlc, self.unusable_rows, self.lookup_bits)
+        self._keep = []
+        if self.break_points:
+            for name in ("gate0", "gate1", "rlc"):
+                arr = (ctypes.c_uint32 * len(self.break_points[name]))(*self.break_points[name])
+                self._keep.append(arr)
+                setattr(c, "bp_" + name, ctypes.cast(arr, ctypes.POINTER(ctypes.c_uint32)))
+                setattr(c, "n_bp_" + name, len(self.break_points[name]))
+        c.replay = 1 if (replay and self.break_points) else 0
+        return c
+
+
+def _bfv_sigs(lib):
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.zkfhe_bfv_build_tables.argtypes = [ctypes.c_char_p, ctypes.POINTER(BfvParamsC), ctypes.POINTER(BfvConfigC), ctypes.c_char_p, ci,
+                                           ctypes.POINTER(vp), ctypes.c_char_p, sz]
+    lib.zkfhe_bfv_tables_free.argtypes = [vp]
+    lib.zkfhe_bfv_tables_free.restype = None
+    lib.zkfhe_bfv_tables_count.argtypes = [vp, ci]
+    lib.zkfhe_bfv_tables_count.restype = sz
+    for f in ("advice", "fixed", "instance", "copies"):
+        getattr(lib, "zkfhe_bfv_tables_copy_" + f).argtypes = [vp, vp]
+    lib.zkfhe_bfv_tables_copy_break_points.argtypes = [vp, ci, vp]
+
+
+def bfv_build_tables(input_json_text, params, config, gamma, keygen_mode, replay=False):
+    """Host-only witness tables (no GPU). params = (N, Q, T, B); gamma = python int. Returns a dict of numpy arrays."""
+    lib = load_library()
+    _bfv_sigs(lib)
+    prm = BfvParamsC(*params)
+    cfg = config.to_c(replay)
+    h = ctypes.c_void_p()
+    err = ctypes.create_string_buffer(512)
+    rc = lib.zkfhe_bfv_build_tables(input_json_text.encode(), ctypes.byref(prm), ctypes.byref(cfg), int(gamma).to_bytes(32, "little"),
+                                    int(bool(keygen_mode)), ctypes.byref(h), err, 512)
+    if rc != 0:
+        raise ZkfheError("zkfhe_bfv_build_tables failed (%d): %s" % (rc, err.value.decode()))
+    cnt = lambda w: int(lib.zkfhe_bfv_tables_count(h, w))  # noqa: E731
+    n_adv, n_fix, n, n_inst, n_cp = cnt(0), cnt(1), cnt(2), cnt(3), cnt(4)
+    out = {"n": n, "cells": (cnt(8), cnt(9), cnt(10)), "lookups": cnt(11)}
+    adv = np.empty((n_adv, n, 4), dtype=np.uint64)
+    lib.zkfhe_bfv_tables_copy_advice(h, adv.ctypes.data_as(ctypes.c_void_p))
+    out["advice"] = adv
+    if n_fix:
+        fx = np.empty((n_fix, n, 4), dtype=np.uint64)
+        lib.zkfhe_bfv_tables_copy_fixed(h, fx.ctypes.data_as(ctypes.c_void_p))
+        out["fixed"] = fx
+    inst = np.empty((n_inst, 4), dtype=np.uint64)
+    lib.zkfhe_bfv_tables_copy_instance(h, inst.ctypes.data_as(ctypes.c_void_p))
+    out["instance"] = inst
+    cp = np.empty((n_cp, 2), dtype=np.uint64)
+    if n_cp:
+        lib.zkfhe_bfv_tables_copy_copies(h, cp.ctypes.data_as(ctypes.c_void_p))
+    out["copies"] = cp
+    bps = {}
+    for i, name in enumerate(("gate0", "gate1", "rlc")):
+        a = np.empty(cnt(5 + i), dtype=np.uint32)
+        if a.size:
+            lib.zkfhe_bfv_tables_copy_break_points(h, i, a.ctypes.data_as(ctypes.c_void_p))
+        bps[name] = a.tolist()
+    out["break_points"] = bps
+    lib.zkfhe_bfv_tables_free(h)
+    return out

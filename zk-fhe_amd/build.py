@@ -34,6 +34,10 @@ def units():
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".hip") and f != "ntt_tile_inst.hip":
             u.append((os.path.join(CSRC, f), os.path.join(OUT, f[:-4] + ".o"), []))
+    host = os.path.join(HERE, "host")
+    for f in sorted(os.listdir(host)):
+        if f.endswith((".cpp", ".hip")) and not f.endswith("_main.cpp"):
+            u.append((os.path.join(host, f), os.path.join(OUT, "host_" + f.rsplit(".", 1)[0] + ".o"), []))
     for k in TILE_SIZES:
         u.append((os.path.join(CSRC, "ntt_tile_inst.hip"), os.path.join(OUT, "ntt_tile_%d.o" % k), ["-DZK_TILE_LOGN=%d" % k]))
     return u
@@ -41,7 +45,7 @@ def units():
 
 def newest_header():
     t = 0.0
-    for d in (CSRC, os.path.join(HERE, "..", "include")):
+    for d in (CSRC, os.path.join(HERE, "host"), os.path.join(HERE, "..", "include")):
         for f in os.listdir(d):
             if f.endswith((".cuh", ".hpp", ".h")):
                 t = max(t, os.path.getmtime(os.path.join(d, f)))

@@ -162,8 +162,11 @@ __device__ __forceinline__ void zk_mac_s(u64 &acc, u32 &top, u32 a, u32 b_sgpr) 
       : "vcc");
 }
 
+#endif
+
 template <class P>
-__device__ __forceinline__ Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
   u32 m[8];
   u32 r[8];
   u64 acc = 0;
@@ -198,10 +201,7 @@ __device__ __forceinline__ Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
   for (int i = 0; i < 8; ++i) o.l[i] = r[i];
   fp_reduce_once<P>(o.l);
   return o;
-}
 #else
-template <class P>
-ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
   u32 t[9];
   for (int i = 0; i < 9; ++i) t[i] = 0;
   for (int i = 0; i < 8; ++i) {
@@ -228,8 +228,8 @@ ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
   for (int i = 0; i < 8; ++i) r.l[i] = t[i];
   fp_reduce_once<P>(r.l);
   return r;
-}
 #endif
+}
 
 template <class P>
 ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {

@@ -1,0 +1,198 @@
+// Blake2b (RFC 7693) and the Fiat-Shamir transcript of the prover.
+//
+// The reference's scaffold uses snark-verifier's PoseidonTranscript; this build uses halo2_proofs' own
+// `Blake2bWrite/Blake2bRead` transcript shape instead (personalisation "Halo2-Transcript", prefix bytes
+// 0 = challenge, 1 = point, 2 = scalar) -- a documented deviation: byte parity with the Rust
+// reference is impossible anyway.  Mirrors oracle/halo2_ref.py `Transcript` / `Rng`.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fe.hpp"
+
+namespace zkhost {
+
+class Blake2b {
+ public:
+  Blake2b(size_t outlen, const char *personal) {
+    static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                   0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    for (int i = 0; i < 8; ++i) h[i] = IV[i];
+    h[0] ^= 0x01010000ULL ^ (uint64_t)outlen;
+    uint8_t p[16] = {0};
+    if (personal) memcpy(p, personal, std::min<size_t>(16, strlen(personal)));
+    uint64_t p0, p1;
+    memcpy(&p0, p, 8);
+    memcpy(&p1, p + 8, 8);
+    h[6] ^= p0;
+    h[7] ^= p1;
+    out_len = outlen;
+  }
+  void update(const void *data, size_t len) {
+    const uint8_t *in = (const uint8_t *)data;
+    while (len) {
+      if (buf_len == 128) {
+        t += 128;
+        compress(false);
+        buf_len = 0;
+      }
+      size_t take = std::min(len, (size_t)128 - buf_len);
+      memcpy(buf + buf_len, in, take);
+      buf_len += take;
+      in += take;
+      len -= take;
+    }
+  }
+  // finalises a COPY: the running state can keep absorbing (halo2's squeeze clones the hasher)
+  void digest(uint8_t *out) const {
+    Blake2b c = *this;
+    c.t += c.buf_len;
+    memset(c.buf + c.buf_len, 0, 128 - c.buf_len);
+    c.compress(true);
+    uint8_t full[64];
+    memcpy(full, c.h, 64);
+    memcpy(out, full, out_len);
+  }
+
+ private:
+  uint64_t h[8];
+  uint64_t t = 0;
+  uint8_t buf[128];
+  size_t buf_len = 0;
+  size_t out_len;
+  static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+  void compress(bool last) {
+    static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                   0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    static const uint8_t S[12][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    uint64_t m[16], v[16];
+    memcpy(m, buf, 128);
+    for (int i = 0; i < 8; ++i) {
+      v[i] = h[i];
+      v[i + 8] = IV[i];
+    }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+      v[a] = v[a] + v[b] + x;
+      v[d] = rotr(v[d] ^ v[a], 32);
+      v[c] = v[c] + v[d];
+      v[b] = rotr(v[b] ^ v[c], 24);
+      v[a] = v[a] + v[b] + y;
+      v[d] = rotr(v[d] ^ v[a], 16);
+      v[c] = v[c] + v[d];
+      v[b] = rotr(v[b] ^ v[c], 63);
+    };
+    for (int r = 0; r < 12; ++r) {
+      const uint8_t *s = S[r];
+      G(0, 4, 8, 12, m[s[0]], m[s[1]]);
+      G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+      G(2, 6, 10, 14, m[s[4]], m[s[5]]);
+      G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+      G(0, 5, 10, 15, m[s[8]], m[s[9]]);
+      G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+      G(2, 7, 8, 13, m[s[12]], m[s[13]]);
+      G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+  }
+};
+
+// 64 little-endian bytes -> value mod r  (Fr::from_bytes_wide)
+inline U256 from_bytes_wide(const uint8_t b[64]) {
+  // value = lo + hi * 2^256, each 256-bit; reduce with Montgomery arithmetic: lo*1 + hi*R  (R = 2^256 mod r)
+  U256 lo, hi;
+  memcpy(lo.l, b, 32);
+  memcpy(hi.l, b + 32, 32);
+  auto reduce = [](U256 v) {
+    while (!(v < fe::MOD)) fe::sub_raw(v, v, fe::MOD);
+    return v;
+  };
+  lo = reduce(lo);
+  hi = reduce(hi);
+  // hi * 2^256 mod r = from_mont^-1 ... : to_mont(hi) = hi * R mod r, as a canonical number
+  const U256 hiR = fe::from_fr_raw(fe::to_mont(hi));
+  return fe::add(lo, hiR);
+}
+
+class Rng {  // blinding stream: Blake2b-512(person "zkfhe-rng", seed[32] || counter_le64) mod r
+ public:
+  explicit Rng(const uint8_t seed32[32]) { memcpy(seed, seed32, 32); }
+  U256 next() {
+    Blake2b h(64, "zkfhe-rng");
+    uint8_t msg[40];
+    memcpy(msg, seed, 32);
+    for (int i = 0; i < 8; ++i) msg[32 + i] = (uint8_t)(ctr >> (8 * i));
+    ++ctr;
+    h.update(msg, 40);
+    uint8_t d[64];
+    h.digest(d);
+    return from_bytes_wide(d);
+  }
+  uint64_t ctr = 0;
+
+ private:
+  uint8_t seed[32];
+};
+
+struct AffinePoint {  // canonical coordinates; identity = (0,0)
+  U256 x, y;
+  bool is_identity() const { return x.is_zero() && y.is_zero(); }
+};
+
+class Transcript {
+ public:
+  Transcript() : h(64, "Halo2-Transcript") {}
+  std::vector<uint8_t> out;
+
+  void common_point(const AffinePoint &p) {
+    uint8_t b[65];
+    b[0] = 1;
+    memcpy(b + 1, p.x.l, 32);
+    memcpy(b + 33, p.y.l, 32);
+    h.update(b, 65);
+  }
+  void common_scalar(const U256 &s) {
+    uint8_t b[33];
+    b[0] = 2;
+    memcpy(b + 1, s.l, 32);
+    h.update(b, 33);
+  }
+  void write_point(const AffinePoint &p) {
+    common_point(p);
+    uint8_t b[32];
+    if (p.is_identity()) {
+      memset(b, 0, 32);
+      b[31] |= 0x40;
+    } else {
+      memcpy(b, p.x.l, 32);
+      if (p.y.l[0] & 1) b[31] |= 0x80;
+    }
+    out.insert(out.end(), b, b + 32);
+  }
+  void write_scalar(const U256 &s) {
+    common_scalar(s);
+    const uint8_t *b = (const uint8_t *)s.l;
+    out.insert(out.end(), b, b + 32);
+  }
+  U256 squeeze() {
+    const uint8_t z = 0;
+    h.update(&z, 1);
+    uint8_t d[64];
+    h.digest(d);
+    return from_bytes_wide(d);
+  }
+
+ private:
+  Blake2b h;
+};
+
+}  // namespace zkhost
