@@ -1,0 +1,94 @@
+"""GPU prover (zkfhe_bfv_keygen / zkfhe_bfv_prove) vs the CPU oracle prover: byte-identical proofs for the same
+seed, and the oracle verifier (real pairing check) accepts them.  Run on the MI355X box: pytest -m gpu."""
+import json
+import os
+
+import pytest
+
+from oracle import circuit_ref as C
+from oracle import halo2_ref as H
+from tests.test_proof_oracle import synth_input
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden", "bfv")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    c = zk.Context(0)
+    yield c
+    c.close()
+
+
+def first_diff(a, b):
+    for i in range(0, min(len(a), len(b)), 32):
+        if a[i:i + 32] != b[i:i + 32]:
+            return i // 32
+    return None if len(a) == len(b) else min(len(a), len(b)) // 32
+
+
+def test_toy_proof_bytes_match_oracle(ctx):
+    import zk_fhe_amd as zk
+    prm = C.BfvParams(N=8)
+    inp = synth_input(8, prm.Q, prm.T, prm.B, 1)
+    circ = H.BfvCircuit(inp, prm)
+    hcfg = H.auto_config(9, 9, circ)
+    srs_o = H.make_srs(9)
+    pk_o, _ = H.keygen_circuit(hcfg, circ, srs_o)
+    proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, circ, b"seed-1")
+    assert H.verify(H.VerifyingKey(pk_o), srs_o, inst_o, proof_o)
+    srs = zk.Srs(ctx, 9)
+    zcfg = zk.BfvConfig(9, hcfg.n_gate0, hcfg.n_gate1, hcfg.n_lookup, hcfg.n_rlc, 9)
+    pk = zk.BfvProvingKey(ctx, srs, json.dumps(inp), (8, prm.Q, prm.T, prm.B), zcfg)
+    info = pk.info()
+    assert info["break_points"] == pk_o.break_points
+    assert info["fixed_commit"] == pk_o.fixed_commit
+    assert info["sigma_commit"] == pk_o.sigma_commit
+    assert info["vk_digest"] == pk_o.vk_digest
+    proof, inst, tm = pk.prove(json.dumps(inp), b"seed-1")
+    assert inst == inst_o
+    assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
+    assert H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof)
+    # a different seed changes the bytes but still verifies; a wrong witness is refused
+    proof2, _, _ = pk.prove(json.dumps(inp), b"seed-2")
+    assert proof2 != proof and H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof2)
+    bad = dict(inp)
+    c0 = list(bad["c0"])
+    c0[1] = str((int(c0[1]) + 1) % prm.Q)
+    bad["c0"] = c0
+    with pytest.raises(zk.ZkfheError):
+        pk.prove(json.dumps(bad), b"seed-1")
+    pk.destroy()
+    srs.destroy()
+
+
+def test_bfv_in_k13_proof_bytes_match_oracle(ctx):
+    """BASELINE config 2: the reference's data/bfv/bfv.in, k = 13, pinned configs/bfv.json layout."""
+    import zk_fhe_amd as zk
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    hcfg = H.Config.from_pinning(cfgj)
+    bp = {"gate0": cfgj["break_points"]["gate"][0], "gate1": cfgj["break_points"]["gate"][1], "rlc": cfgj["break_points"]["rlc"]}
+    prm = C.BfvParams()
+    text_empty = open(os.path.join(G, "bfv_empty.in")).read()
+    text = open(os.path.join(G, "bfv.in")).read()
+    srs = zk.Srs(ctx, 13)
+    zcfg = zk.BfvConfig.from_pinning(cfgj)
+    zcfg_nobp = zk.BfvConfig(zcfg.k, zcfg.n_gate0, zcfg.n_gate1, zcfg.n_lookup, zcfg.n_rlc, zcfg.unusable_rows, zcfg.lookup_bits)
+    pk = zk.BfvProvingKey(ctx, srs, text_empty, (1024, prm.Q, prm.T, prm.B), zcfg_nobp)
+    info = pk.info()
+    assert info["break_points"] == bp  # keygen recomputes the reference's 158 pinned break points
+    proof, inst, tm = pk.prove(text, b"seed-1")
+    print("GPU prove timings [witness, commit, quotient, open, total] ms:", tm)
+    assert len(inst) == 5121
+    srs_o = H.make_srs(13)
+    pk_o, _ = H.keygen_circuit(hcfg, H.BfvCircuit(json.loads(text_empty), prm), srs_o, bp)
+    assert info["vk_digest"] == pk_o.vk_digest
+    assert H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof), "oracle verifier (pairing check) rejects the GPU proof"
+    proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, H.BfvCircuit(json.loads(text), prm), b"seed-1")
+    assert inst == inst_o
+    assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
+    pk.destroy()
+    srs.destroy()

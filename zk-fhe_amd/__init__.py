@@ -406,3 +406,84 @@ def bfv_build_tables(input_json_text, params, config, gamma, keygen_mode, replay
     out["break_points"] = bps
     lib.zkfhe_bfv_tables_free(h)
     return out
+
+
+# ----------------------------------------------------------------------------- SRS / keygen / prove (GPU)
+class Srs:
+    def __init__(self, ctx, k, seed=b"zkfhe-unsafe-srs"):
+        lib = ctx.lib
+        lib.zkfhe_srs_create.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        lib.zkfhe_srs_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.ctx, self.k = ctx, k
+        h = ctypes.c_void_p()
+        ctx._check(lib.zkfhe_srs_create(ctx.h, k, bytes(seed), len(seed), ctypes.byref(h)))
+        self.h = h
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.zkfhe_srs_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class BfvProvingKey:
+    """zkfhe_bfv_keygen: fixed + sigma polynomials, commitments and extended-domain tables resident in HBM."""
+
+    def __init__(self, ctx, srs, input_json_text, params, config, replay=False):
+        lib = ctx.lib
+        vp = ctypes.c_void_p
+        lib.zkfhe_bfv_keygen.argtypes = [vp, vp, ctypes.c_char_p, ctypes.POINTER(BfvParamsC), ctypes.POINTER(BfvConfigC), ctypes.POINTER(vp)]
+        lib.zkfhe_bfv_pk_destroy.argtypes = [vp, vp]
+        lib.zkfhe_bfv_pk_info.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        lib.zkfhe_bfv_pk_commitments.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+        lib.zkfhe_bfv_pk_break_points.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_uint32)]
+        lib.zkfhe_bfv_prove.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                        ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_float)]
+        self.ctx, self.srs, self.params, self.config = ctx, srs, params, config
+        prm = BfvParamsC(*params)
+        cfg = config.to_c(replay)
+        h = vp()
+        ctx._check(lib.zkfhe_bfv_keygen(ctx.h, srs.h, input_json_text.encode(), ctypes.byref(prm), ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+
+    def info(self):
+        d = ctypes.create_string_buffer(32)
+        nf, ns = ctypes.c_uint32(), ctypes.c_uint32()
+        self.ctx.lib.zkfhe_bfv_pk_info(self.h, d, ctypes.byref(nf), ctypes.byref(ns))
+        fx = ctypes.create_string_buffer(64 * nf.value)
+        sg = ctypes.create_string_buffer(64 * ns.value)
+        self.ctx.lib.zkfhe_bfv_pk_commitments(self.h, fx, sg)
+
+        def pts(buf, cnt):
+            out = []
+            for i in range(cnt):
+                x = int.from_bytes(buf.raw[64 * i:64 * i + 32], "little")
+                y = int.from_bytes(buf.raw[64 * i + 32:64 * i + 64], "little")
+                out.append(None if (x == 0 and y == 0) else (x, y))
+            return out
+        bps = {}
+        for i, name in enumerate(("gate0", "gate1", "rlc")):
+            cnt = ctypes.c_uint32(0)
+            self.ctx.lib.zkfhe_bfv_pk_break_points(self.h, i, None, ctypes.byref(cnt))
+            arr = (ctypes.c_uint32 * max(1, cnt.value))()
+            self.ctx.lib.zkfhe_bfv_pk_break_points(self.h, i, arr, ctypes.byref(cnt))
+            bps[name] = list(arr)[: cnt.value]
+        return {"vk_digest": int.from_bytes(d.raw, "little"), "fixed_commit": pts(fx, nf.value), "sigma_commit": pts(sg, ns.value),
+                "break_points": bps}
+
+    def prove(self, input_json_text, seed):
+        seed = bytes(seed).ljust(32, b"\x00")[:32]
+        cap = 1 << 20
+        buf = ctypes.create_string_buffer(cap)
+        plen = ctypes.c_size_t()
+        ninst = ctypes.c_size_t(1 << 16)
+        ibuf = ctypes.create_string_buffer(32 * ninst.value)
+        tm = (ctypes.c_float * 5)()
+        self.ctx._check(self.ctx.lib.zkfhe_bfv_prove(self.ctx.h, self.srs.h, self.h, input_json_text.encode(), seed, buf, cap, ctypes.byref(plen),
+                                                     ibuf, ctypes.byref(ninst), tm))
+        inst = [int.from_bytes(ibuf.raw[32 * i:32 * i + 32], "little") for i in range(ninst.value)]
+        return buf.raw[: plen.value], inst, list(tm)
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.zkfhe_bfv_pk_destroy(self.ctx.h, self.h)
+            self.h = None

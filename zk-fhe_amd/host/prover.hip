@@ -1,0 +1,965 @@
+// SRS, keygen and create_proof for the BFV circuit on one MI355X (include/zkfhe.h "BFV circuit").
+//
+// Replaces halo2-scaffold `run_eth` {gen_srs, keygen_vk/keygen_pk, gen_snark_shplonk -> create_proof}
+// (third-party, reached from reference examples/bfv.rs:311; protocol restated in oracle/halo2_ref.py,
+// which this file must match byte for byte for the same seed).  Host side: witness generation
+// (bfv_circuit.hpp), Fiat-Shamir transcript, blinding stream, lookup permutation (counting sort of 8-bit
+// values).  Device side: everything that touches a full column -- Montgomery conversion, MSM commits,
+// (i)NTT / coset NTT, grand products, quotient evaluation, evaluations at x, SHPLONK polynomials.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/zkfhe.h"
+#include "bfv_circuit.hpp"
+#include "prover_kernels.cuh"
+#include "transcript.hpp"
+
+using namespace zkhost;
+using zk::Fr;
+using zk::G1Affine;
+
+namespace zkhost {
+CircuitConfig config_from_c(const zkfhe_bfv_config *c);
+BfvParams params_from_c(const zkfhe_bfv_params *p);
+}  // namespace zkhost
+
+static const uint64_t DELTA_CANON[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL, 0x09226b6e22c6f0caULL};
+static const uint64_t COSET_G = 7;
+
+#define CK(x)                 \
+  do {                        \
+    int rc__ = (x);           \
+    if (rc__) return rc__;    \
+  } while (0)
+
+struct zkfhe_srs {
+  uint32_t k = 0;
+  zkfhe_basis *g = nullptr, *g_lagrange = nullptr;
+};
+
+namespace {
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+Fr mont(const U256 &v) { return fe::to_mont(v); }
+Fr mont_u64(uint64_t v) { return fe::to_mont(fe::from_u64(v)); }
+U256 canon(const Fr &f) { return fe::from_mont(f); }
+Fr fr_pow(Fr b, uint64_t e) {
+  Fr r = Fr::one();
+  while (e) {
+    if (e & 1) r = r * b;
+    b = b * b;
+    e >>= 1;
+  }
+  return r;
+}
+Fr fr_inv(const Fr &a) { return zk::fp_inv<zk::FrP>(a); }
+
+AffinePoint point_canon(const G1Affine &p) {
+  AffinePoint a;
+  zk::Fq x = zk::fp_from_mont<zk::FqP>(p.x), y = zk::fp_from_mont<zk::FqP>(p.y);
+  memcpy(a.x.l, x.l, 32);
+  memcpy(a.y.l, y.l, 32);
+  return a;
+}
+
+struct DevBuf {
+  zkfhe_ctx *ctx = nullptr;
+  void *p = nullptr;
+  size_t bytes = 0;
+  int alloc(zkfhe_ctx *c, size_t b) {
+    ctx = c;
+    bytes = b;
+    return zkfhe_dev_alloc(c, b, &p);
+  }
+  void release() {
+    if (p) zkfhe_dev_free(ctx, p);
+    p = nullptr;
+  }
+  Fr *fr() const { return (Fr *)p; }
+};
+
+unsigned grid_for(zkfhe_ctx *ctx, size_t work) {
+  size_t b = (work + 255) / 256;
+  size_t cap = (size_t)ctx->num_cu * 16;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// upload canonical values and convert to Montgomery on the device
+int upload_canon(zkfhe_ctx *ctx, Fr *dst, const U256 *src, size_t count) {
+  ZK_HIP(ctx, hipMemcpyAsync(dst, src, count * 32, hipMemcpyHostToDevice, ctx->stream));
+  return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)dst, (zkfhe_fr *)dst, count);
+}
+
+// commit `n_cols` columns (device, Montgomery) and return canonical affine points
+int commit_cols(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
+  CK(zkfhe_msm_batch(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_affine *)dev_out));
+  std::vector<G1Affine> h(n_cols);
+  CK(zkfhe_download(ctx, h.data(), dev_out, n_cols * sizeof(G1Affine)));
+  out.resize(n_cols);
+  for (size_t i = 0; i < n_cols; ++i) out[i] = point_canon(h[i]);
+  return ZKFHE_OK;
+}
+
+struct GpuPolyMul : PolyMulBackend {
+  zkfhe_ctx *ctx;
+  explicit GpuPolyMul(zkfhe_ctx *c) : ctx(c) {}
+  std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) override {
+    const size_t n = a.size();
+    DevBuf da, db, dout;
+    if (da.alloc(ctx, n * 8) || db.alloc(ctx, n * 8) || dout.alloc(ctx, (2 * n - 1) * 32)) throw std::runtime_error("device allocation failed");
+    std::vector<U256> host(2 * n - 1);
+    int rc = zkfhe_upload(ctx, da.p, a.data(), n * 8);
+    if (!rc) rc = zkfhe_upload(ctx, db.p, b.data(), n * 8);
+    if (!rc) rc = zkfhe_witness_poly_mul_u64(ctx, (const uint64_t *)da.p, (const uint64_t *)db.p, n, (zkfhe_fr *)dout.p);
+    if (!rc) rc = zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)dout.p, (zkfhe_fr *)dout.p, 2 * n - 1);
+    if (!rc) rc = zkfhe_download(ctx, host.data(), dout.p, (2 * n - 1) * 32);
+    da.release();
+    db.release();
+    dout.release();
+    if (rc) throw std::runtime_error(std::string("GPU poly mul failed: ") + zkfhe_last_error(ctx));
+    std::vector<BigInt> out(2 * n - 1);
+    for (size_t i = 0; i < out.size(); ++i) out[i] = fe::to_bigint(host[i]);
+    return out;
+  }
+};
+
+}  // namespace
+
+// ================================================================================================= pk
+struct zkfhe_bfv_pk {
+  CircuitConfig cfg;
+  BfvParams prm;
+  DevBuf fixed_l, sigma_l, fixed_ext, sigma_ext, l_ext, xs_ext, dpow;
+  std::vector<AffinePoint> fixed_commit, sigma_commit;
+  U256 vk_digest;
+  // per-proof workspace (one proof at a time per pk)
+  DevBuf adv_l, la_l, ls_l, lz_l, pz_l, inst_l, tmp_c, adv_ext, pz_ext, lz_ext, la_ext, ls_ext, inst_ext, partials, h_ext, h_c, misc, points;
+  DevBuf num, den, small;
+  bool ws_ready = false;
+};
+
+extern "C" {
+
+int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
+  ZK_ARG(ctx, out != nullptr && k >= 3 && k <= 20);
+  const size_t n = (size_t)1 << k;
+  Blake2b h(64, "zkfhe-srs");
+  h.update(seed, seed_len);
+  uint8_t d[64];
+  h.digest(d);
+  const Fr s = mont(from_bytes_wide(d));
+  const NttDomain *dom;
+  CK(zk_domain(ctx, (int)k, &dom));
+  DevBuf sc, pts;
+  CK(sc.alloc(ctx, n * 32));
+  CK(pts.alloc(ctx, n * 64));
+  G1Affine gen;
+  gen.x = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 1; return t; }());
+  gen.y = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 2; return t; }());
+  std::vector<G1Affine> host(n);
+  zkfhe_srs *srs = new zkfhe_srs();
+  srs->k = k;
+  const unsigned gr = (unsigned)((n + 255) / 256);
+  for (int which = 0; which < 2; ++which) {
+    if (which == 0) {
+      zkp::k_powers<<<gr, 256, 0, ctx->stream>>>(Fr::one(), s, sc.fr(), n);
+      ZK_LAUNCH_CHECK(ctx);
+    } else {
+      zkp::k_srs_den<<<gr, 256, 0, ctx->stream>>>(dom->fwd, s, mont_u64(n), sc.fr(), n);
+      ZK_LAUNCH_CHECK(ctx);
+      CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)sc.p, n));
+      zkp::k_srs_li<<<gr, 256, 0, ctx->stream>>>(dom->fwd, fr_pow(s, n) - Fr::one(), sc.fr(), n);
+      ZK_LAUNCH_CHECK(ctx);
+    }
+    zkp::k_fill_point<<<gr, 256, 0, ctx->stream>>>(gen, (G1Affine *)pts.p, n);
+    ZK_LAUNCH_CHECK(ctx);
+    CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, n));
+    CK(zkfhe_download(ctx, host.data(), pts.p, n * 64));
+    CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), n, 0, which == 0 ? &srs->g : &srs->g_lagrange));
+  }
+  sc.release();
+  pts.release();
+  *out = srs;
+  return ZKFHE_OK;
+}
+
+int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {
+  if (!srs) return ZKFHE_OK;
+  zkfhe_basis_destroy(ctx, srs->g);
+  zkfhe_basis_destroy(ctx, srs->g_lagrange);
+  delete srs;
+  return ZKFHE_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int alloc_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
+  const CircuitConfig &c = pk->cfg;
+  const size_t n = c.n(), ne = 4 * n, col = n * 32, ecol = ne * 32;
+  CK(pk->adv_l.alloc(ctx, c.n_advice() * col));
+  CK(pk->la_l.alloc(ctx, c.n_lookup * col + 32));
+  CK(pk->ls_l.alloc(ctx, c.n_lookup * col + 32));
+  CK(pk->lz_l.alloc(ctx, c.n_lookup * col + 32));
+  CK(pk->pz_l.alloc(ctx, c.n_chunks() * col));
+  CK(pk->inst_l.alloc(ctx, col));
+  CK(pk->tmp_c.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * col));
+  CK(pk->adv_ext.alloc(ctx, c.n_advice() * ecol));
+  CK(pk->pz_ext.alloc(ctx, c.n_chunks() * ecol));
+  CK(pk->lz_ext.alloc(ctx, c.n_lookup * ecol + 32));
+  CK(pk->la_ext.alloc(ctx, c.n_lookup * ecol + 32));
+  CK(pk->ls_ext.alloc(ctx, c.n_lookup * ecol + 32));
+  CK(pk->inst_ext.alloc(ctx, ecol));
+  CK(pk->partials.alloc(ctx, 96 * ecol));
+  CK(pk->h_ext.alloc(ctx, ecol));
+  CK(pk->h_c.alloc(ctx, ecol));
+  CK(pk->misc.alloc(ctx, 32 * col));
+  CK(pk->points.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * 64 + 64));
+  CK(pk->num.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
+  CK(pk->den.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
+  CK(pk->small.alloc(ctx, 1 << 20));
+  pk->ws_ready = true;
+  return ZKFHE_OK;
+}
+
+// coefficient form of `count` Lagrange columns (copy into tmp, iNTT), then coset-extend into ext
+int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, const Fr *lagr, size_t count, Fr *ext) {
+  if (!count) return ZKFHE_OK;
+  const size_t n = pk->cfg.n();
+  const Fr g = mont_u64(COSET_G);
+  ZK_HIP(ctx, hipMemcpyAsync(pk->tmp_c.p, lagr, count * n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)pk->tmp_c.p, count, (int)pk->cfg.k, 1));
+  return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)pk->tmp_c.p, (zkfhe_fr *)ext, count, (int)pk->cfg.k, 2, (const zkfhe_fr *)&g, 0);
+}
+
+int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const BfvParams &prm, CircuitConfig cfg, bool replay,
+                zkfhe_bfv_pk **out) {
+  const size_t n = cfg.n();
+  ZK_ARG(ctx, srs->k == cfg.k);
+  // ---- circuit structure (host)
+  const CircuitInput in = CircuitInput::parse_json(input_json);
+  Context ctx0(CTX_PHASE0, false, true), ctx_gate(CTX_GATE1, false, true), ctx_rlc(CTX_RLC1, true, true);
+  std::vector<Cell> make_public;
+  BfvState st = bfv_phase0(ctx0, in, prm, make_public);
+  bfv_phase1(st, prm, ctx_gate, ctx_rlc, fe::zero());
+  Assigner as(cfg, true);
+  as.place(ctx0, replay);
+  as.place(ctx_gate, replay);
+  as.place(ctx_rlc, replay);
+  as.place_lookups(ctx_gate);
+  as.finish_structure(ctx0, ctx_gate, ctx_rlc, make_public);
+  cfg.bp_gate0 = as.t.bp_gate0;
+  cfg.bp_gate1 = as.t.bp_gate1;
+  cfg.bp_rlc = as.t.bp_rlc;
+  zkfhe_bfv_pk *pk = new zkfhe_bfv_pk();
+  pk->cfg = cfg;
+  pk->prm = prm;
+  // ---- sigma: union-find over cell ids, each class sorted by id is one cycle
+  const size_t cells = (size_t)cfg.n_perm() * n;
+  std::vector<uint32_t> parent(cells);
+  for (size_t i = 0; i < cells; ++i) parent[i] = (uint32_t)i;
+  auto find = [&](uint32_t x) {
+    uint32_t root = x;
+    while (parent[root] != root) root = parent[root];
+    while (parent[x] != root) {
+      uint32_t nx = parent[x];
+      parent[x] = root;
+      x = nx;
+    }
+    return root;
+  };
+  for (const auto &cp : as.t.copies) {
+    uint32_t ra = find((uint32_t)cp.first), rb = find((uint32_t)cp.second);
+    if (ra != rb) {
+      if (ra < rb) parent[rb] = ra;
+      else parent[ra] = rb;
+    }
+  }
+  // the root of a class is its smallest id; walk ids in ascending order and chain each member to the previous one
+  std::vector<uint32_t> target(cells), last_of(cells, 0xffffffffu), first_of(cells);
+  for (size_t i = 0; i < cells; ++i) target[i] = (uint32_t)i;
+  for (size_t i = 0; i < cells; ++i) {
+    const uint32_t r = find((uint32_t)i);
+    if (last_of[r] == 0xffffffffu) first_of[r] = (uint32_t)i;
+    else target[last_of[r]] = (uint32_t)i;
+    last_of[r] = (uint32_t)i;
+  }
+  for (size_t i = 0; i < cells; ++i)
+    if (parent[i] == i && last_of[i] != 0xffffffffu) target[last_of[i]] = first_of[i];
+  // ---- device: fixed + sigma in Lagrange form
+  const NttDomain *dom;
+  CK(zk_domain(ctx, (int)cfg.k, &dom));
+  CK(pk->fixed_l.alloc(ctx, (size_t)cfg.n_fixed() * n * 32));
+  CK(pk->sigma_l.alloc(ctx, cells * 32));
+  CK(pk->dpow.alloc(ctx, (size_t)cfg.n_perm() * 32));
+  for (unsigned c = 0; c < cfg.n_fixed(); ++c) {
+    ZK_HIP(ctx, hipMemcpyAsync(pk->fixed_l.fr() + (size_t)c * n, as.t.fixed[c].data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)pk->fixed_l.p, (zkfhe_fr *)pk->fixed_l.p, (size_t)cfg.n_fixed() * n));
+  U256 dcan;
+  memcpy(dcan.l, DELTA_CANON, 32);
+  zkp::k_powers<<<1, 256, 0, ctx->stream>>>(Fr::one(), mont(dcan), pk->dpow.fr(), cfg.n_perm());
+  ZK_LAUNCH_CHECK(ctx);
+  DevBuf tgt;
+  CK(tgt.alloc(ctx, cells * 4));
+  CK(zkfhe_upload(ctx, tgt.p, target.data(), cells * 4));
+  zkp::k_sigma_values<<<(unsigned)((cells + 255) / 256), 256, 0, ctx->stream>>>((const uint32_t *)tgt.p, pk->dpow.fr(), dom->fwd, pk->sigma_l.fr(),
+                                                                                 cells, (int)cfg.k);
+  ZK_LAUNCH_CHECK(ctx);
+  // ---- commitments
+  CK(alloc_workspace(ctx, pk));
+  CK(commit_cols(ctx, srs->g_lagrange, pk->fixed_l.fr(), cfg.n_fixed(), (G1Affine *)pk->points.p, pk->fixed_commit));
+  CK(commit_cols(ctx, srs->g_lagrange, pk->sigma_l.fr(), cfg.n_perm(), (G1Affine *)pk->points.p, pk->sigma_commit));
+  // ---- extended-domain evaluations kept resident
+  CK(pk->fixed_ext.alloc(ctx, (size_t)cfg.n_fixed() * 4 * n * 32));
+  CK(pk->sigma_ext.alloc(ctx, cells * 4 * 32));
+  CK(pk->l_ext.alloc(ctx, 3 * 4 * n * 32));
+  CK(pk->xs_ext.alloc(ctx, 4 * n * 32));
+  CK(extend_cols(ctx, pk, pk->fixed_l.fr(), cfg.n_fixed(), pk->fixed_ext.fr()));
+  CK(extend_cols(ctx, pk, pk->sigma_l.fr(), cfg.n_perm(), pk->sigma_ext.fr()));
+  {
+    std::vector<U256> l(3 * n, fe::zero());
+    const size_t u = cfg.u();
+    l[0] = fe::one();
+    l[n + u] = fe::one();
+    for (size_t i = 0; i < u; ++i) l[2 * n + i] = fe::one();
+    CK(upload_canon(ctx, pk->misc.fr(), l.data(), 3 * n));
+    CK(extend_cols(ctx, pk, pk->misc.fr(), 3, pk->l_ext.fr()));
+  }
+  {
+    const Fr wext = zk_fr_root_of_unity((int)cfg.k + 2);
+    Fr shift = mont_u64(COSET_G);
+    for (int k1 = 0; k1 < 4; ++k1) {
+      zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(shift, dom->omega, pk->xs_ext.fr() + (size_t)k1 * n, n);
+      ZK_LAUNCH_CHECK(ctx);
+      shift = shift * wext;
+    }
+  }
+  CK(zkfhe_sync(ctx));
+  tgt.release();
+  // ---- vk digest
+  Blake2b h(64, "zkfhe-vk");
+  const uint32_t hdr[7] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits};
+  h.update(hdr, sizeof(hdr));
+  for (const auto &p : pk->fixed_commit) {
+    h.update(p.x.l, 32);
+    h.update(p.y.l, 32);
+  }
+  for (const auto &p : pk->sigma_commit) {
+    h.update(p.x.l, 32);
+    h.update(p.y.l, 32);
+  }
+  uint8_t d[64];
+  h.digest(d);
+  pk->vk_digest = from_bytes_wide(d);
+  *out = pk;
+  return ZKFHE_OK;
+}
+
+// counting-sort restatement of halo2's permute_expression_pair for 8-bit tables
+void permute_lookup(const std::vector<U256> &input, size_t u, unsigned table_size, std::vector<U256> &a_perm, std::vector<U256> &s_perm) {
+  std::vector<size_t> cnt(table_size, 0);
+  for (size_t i = 0; i < u; ++i) {
+    const U256 &v = input[i];
+    if (v.l[1] | v.l[2] | v.l[3] || v.l[0] >= table_size) throw std::runtime_error("lookup input not in table");
+    ++cnt[v.l[0]];
+  }
+  // table multiset over usable rows: values 0..table_size-1 once each, and 0 for the remaining rows
+  std::vector<size_t> left(table_size, 1);
+  left[0] = u - (table_size - 1);
+  a_perm.assign(u, fe::zero());
+  s_perm.assign(u, fe::zero());
+  std::vector<size_t> holes;
+  size_t pos = 0;
+  for (unsigned v = 0; v < table_size; ++v)
+    for (size_t k = 0; k < cnt[v]; ++k, ++pos) {
+      a_perm[pos] = fe::from_u64(v);
+      if (k == 0) {
+        if (!left[v]) throw std::runtime_error("lookup input not in table");
+        --left[v];
+        s_perm[pos] = fe::from_u64(v);
+      } else {
+        holes.push_back(pos);
+      }
+    }
+  size_t hi = 0;
+  for (unsigned v = 0; v < table_size; ++v)
+    for (size_t k = 0; k < left[v]; ++k) s_perm[holes[hi++]] = fe::from_u64(v);
+}
+
+struct OpenItem {
+  const Fr *lagr;        // device pointer, Lagrange form
+  int n_rot;
+  int rot[4];            // rotation ids: 0,1,2,3, 4 = last (w^u), 5 = -1
+  U256 ev[4];            // canonical evaluations
+};
+
+int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const char *input_json, const uint8_t seed[32],
+               std::vector<uint8_t> &proof, std::vector<U256> &instances, float *timings) {
+  const CircuitConfig &cfg = pk->cfg;
+  const size_t n = cfg.n(), u = cfg.u(), ne = 4 * n;
+  const unsigned k = cfg.k;
+  const double t_start = now_ms();
+  Rng rng(seed);
+  Transcript tr;
+  const NttDomain *dom;
+  CK(zk_domain(ctx, (int)k, &dom));
+  GpuPolyMul gpu_mul(ctx);
+  struct BackendGuard {
+    explicit BackendGuard(PolyMulBackend *b) { poly_mul_backend() = b; }
+    ~BackendGuard() { poly_mul_backend() = nullptr; }
+  } guard(&gpu_mul);
+  // ------------------------------------------------------------ phase 0 witness
+  const CircuitInput in = CircuitInput::parse_json(input_json);
+  Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
+  std::vector<Cell> make_public;
+  BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
+  Assigner as(cfg, false);
+  as.place(ctx0, true);
+  instances.clear();
+  for (const Cell &c : make_public) instances.push_back(c.value);
+  tr.common_scalar(pk->vk_digest);
+  for (const U256 &v : instances) tr.common_scalar(v);
+  auto blind_and_upload = [&](unsigned c_lo, unsigned c_hi) -> int {
+    for (unsigned c = c_lo; c < c_hi; ++c) {
+      std::vector<U256> &col = as.t.advice[c];
+      for (size_t r = u; r < n; ++r) col[r] = rng.next();
+      ZK_HIP(ctx, hipMemcpyAsync(pk->adv_l.fr() + (size_t)c * n, col.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(pk->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(pk->adv_l.fr() + (size_t)c_lo * n),
+                            (size_t)(c_hi - c_lo) * n);
+  };
+  std::vector<AffinePoint> adv_commit(cfg.n_advice()), pts;
+  CK(blind_and_upload(0, cfg.n_gate0));
+  CK(commit_cols(ctx, srs->g_lagrange, pk->adv_l.fr(), cfg.n_gate0, (G1Affine *)pk->points.p, pts));
+  for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = pts[c]);
+  const U256 gamma_rlc = tr.squeeze();
+  // ------------------------------------------------------------ phase 1 witness
+  bfv_phase1(st, pk->prm, ctx_gate, ctx_rlc, gamma_rlc);
+  as.place(ctx_gate, true);
+  as.place(ctx_rlc, true);
+  as.place_lookups(ctx_gate);
+  std::vector<std::vector<U256>> lookup_inputs(cfg.n_lookup);
+  for (unsigned i = 0; i < cfg.n_lookup; ++i)
+    lookup_inputs[i].assign(as.t.advice[cfg.adv_lookup0() + i].begin(), as.t.advice[cfg.adv_lookup0() + i].begin() + u);
+  const double t_wit = now_ms();
+  CK(blind_and_upload(cfg.n_gate0, cfg.n_advice()));
+  CK(commit_cols(ctx, srs->g_lagrange, pk->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)pk->points.p, pts));
+  for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
+  tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
+  // ------------------------------------------------------------ lookups: permuted input / table
+  std::vector<AffinePoint> la_commit, ls_commit;
+  if (cfg.n_lookup) {
+    std::vector<U256> colA(n), colS(n), ap, sp;
+    for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+      permute_lookup(lookup_inputs[i], u, 1u << cfg.lookup_bits, ap, sp);
+      std::copy(ap.begin(), ap.end(), colA.begin());
+      std::copy(sp.begin(), sp.end(), colS.begin());
+      for (size_t r = u; r < n; ++r) colA[r] = rng.next();
+      for (size_t r = u; r < n; ++r) colS[r] = rng.next();
+      CK(zkfhe_upload(ctx, pk->la_l.fr() + (size_t)i * n, colA.data(), n * 32));
+      CK(zkfhe_upload(ctx, pk->ls_l.fr() + (size_t)i * n, colS.data(), n * 32));
+    }
+    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)pk->la_l.p, (zkfhe_fr *)pk->la_l.p, (size_t)cfg.n_lookup * n));
+    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)pk->ls_l.p, (zkfhe_fr *)pk->ls_l.p, (size_t)cfg.n_lookup * n));
+    CK(commit_cols(ctx, srs->g_lagrange, pk->la_l.fr(), cfg.n_lookup, (G1Affine *)pk->points.p, la_commit));
+    CK(commit_cols(ctx, srs->g_lagrange, pk->ls_l.fr(), cfg.n_lookup, (G1Affine *)pk->points.p, ls_commit));
+    for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+      tr.write_point(la_commit[i]);
+      tr.write_point(ls_commit[i]);
+    }
+  }
+  const U256 beta_c = tr.squeeze(), gamma_c = tr.squeeze();
+  const Fr beta = mont(beta_c), gamma = mont(gamma_c);
+  // ------------------------------------------------------------ permutation grand products
+  {
+    std::vector<U256> inst_col(n, fe::zero());
+    std::copy(instances.begin(), instances.end(), inst_col.begin());
+    CK(upload_canon(ctx, pk->inst_l.fr(), inst_col.data(), n));
+  }
+  U256 dcan;
+  memcpy(dcan.l, DELTA_CANON, 32);
+  Fr *beta_delta_dev = (Fr *)pk->small.p;  // [n_perm]
+  zkp::k_powers<<<1, 256, 0, ctx->stream>>>(beta, mont(dcan), beta_delta_dev, cfg.n_perm());
+  ZK_LAUNCH_CHECK(ctx);
+  zkp::PermArgs pa;
+  pa.adv = pk->adv_l.fr();
+  pa.constcol = pk->fixed_l.fr() + (size_t)cfg.fix_const() * n;
+  pa.inst = pk->inst_l.fr();
+  pa.sigma = pk->sigma_l.fr();
+  pa.wpow = dom->fwd;
+  pa.beta_delta = beta_delta_dev;
+  pa.beta = beta;
+  pa.gamma = gamma;
+  pa.n_advice = cfg.n_advice();
+  pa.n_perm = cfg.n_perm();
+  pa.chunk = cfg.chunk();
+  pa.n_chunks = cfg.n_chunks();
+  pa.n = n;
+  const size_t nch = cfg.n_chunks();
+  zkp::k_perm_num_den<<<grid_for(ctx, nch * n), 256, 0, ctx->stream>>>(pa, pk->num.fr(), pk->den.fr());
+  ZK_LAUNCH_CHECK(ctx);
+  CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)pk->den.p, nch * n));
+  CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)pk->num.p, (const zkfhe_fr *)pk->den.p, (zkfhe_fr *)pk->num.p, nch * n));
+  Fr *totals_dev = (Fr *)pk->small.p + 4096;
+  zkp::k_prefix_product<<<(unsigned)nch, 1024, 0, ctx->stream>>>(pk->num.fr(), pk->pz_l.fr(), totals_dev, n, (unsigned)u);
+  ZK_LAUNCH_CHECK(ctx);
+  {
+    std::vector<Fr> totals(nch), carry(nch);
+    CK(zkfhe_download(ctx, totals.data(), totals_dev, nch * 32));
+    Fr acc = Fr::one();
+    for (size_t j = 0; j < nch; ++j) {
+      carry[j] = acc;
+      acc = acc * totals[j];
+    }
+    if (!(acc == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "permutation argument does not close: a copy constraint is violated");
+    CK(zkfhe_upload(ctx, totals_dev, carry.data(), nch * 32));
+    zkp::k_scale_rows<<<grid_for(ctx, nch * (u + 1)), 256, 0, ctx->stream>>>(pk->pz_l.fr(), totals_dev, n, (unsigned)(u + 1), (unsigned)nch);
+    ZK_LAUNCH_CHECK(ctx);
+    // blinding rows u+1 .. n-1 (drawn per chunk, in order)
+    const size_t nb = n - u - 1;
+    std::vector<U256> blind(nch * nb);
+    for (auto &b : blind) b = rng.next();
+    Fr *bdev = pk->misc.fr();
+    CK(upload_canon(ctx, bdev, blind.data(), blind.size()));
+    ZK_HIP(ctx, hipMemcpy2DAsync(pk->pz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nch, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  // ------------------------------------------------------------ lookup grand products
+  if (cfg.n_lookup) {
+    const size_t nl = cfg.n_lookup;
+    zkp::k_lookup_num_den<<<grid_for(ctx, nl * n), 256, 0, ctx->stream>>>(pk->adv_l.fr() + (size_t)cfg.adv_lookup0() * n,
+                                                                          pk->fixed_l.fr() + (size_t)cfg.fix_table() * n, pk->la_l.fr(), pk->ls_l.fr(),
+                                                                          beta, gamma, (unsigned)nl, n, pk->num.fr(), pk->den.fr());
+    ZK_LAUNCH_CHECK(ctx);
+    CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)pk->den.p, nl * n));
+    CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)pk->num.p, (const zkfhe_fr *)pk->den.p, (zkfhe_fr *)pk->num.p, nl * n));
+    zkp::k_prefix_product<<<(unsigned)nl, 1024, 0, ctx->stream>>>(pk->num.fr(), pk->lz_l.fr(), totals_dev, n, (unsigned)u);
+    ZK_LAUNCH_CHECK(ctx);
+    std::vector<Fr> totals(nl);
+    CK(zkfhe_download(ctx, totals.data(), totals_dev, nl * 32));
+    for (size_t i = 0; i < nl; ++i)
+      if (!(totals[i] == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup argument does not close");
+    const size_t nb = n - u - 1;
+    std::vector<U256> blind(nl * nb);
+    for (auto &b : blind) b = rng.next();
+    Fr *bdev = pk->misc.fr();
+    CK(upload_canon(ctx, bdev, blind.data(), blind.size()));
+    ZK_HIP(ctx, hipMemcpy2DAsync(pk->lz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nl, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  std::vector<AffinePoint> pz_commit, lz_commit;
+  CK(commit_cols(ctx, srs->g_lagrange, pk->pz_l.fr(), nch, (G1Affine *)pk->points.p, pz_commit));
+  for (const auto &p : pz_commit) tr.write_point(p);
+  if (cfg.n_lookup) {
+    CK(commit_cols(ctx, srs->g_lagrange, pk->lz_l.fr(), cfg.n_lookup, (G1Affine *)pk->points.p, lz_commit));
+    for (const auto &p : lz_commit) tr.write_point(p);
+  }
+  // ------------------------------------------------------------ vanishing: random polynomial (coefficient form)
+  Fr *rand_c = pk->misc.fr() + 8 * n, *rand_l = pk->misc.fr() + 9 * n, *H_c = pk->misc.fr() + 10 * n, *H_l = pk->misc.fr() + 11 * n;
+  {
+    std::vector<U256> rc(n);
+    for (auto &v : rc) v = rng.next();
+    CK(upload_canon(ctx, rand_c, rc.data(), n));
+  }
+  std::vector<AffinePoint> rand_commit;
+  CK(commit_cols(ctx, srs->g, rand_c, 1, (G1Affine *)pk->points.p, rand_commit));
+  tr.write_point(rand_commit[0]);
+  const Fr y = mont(tr.squeeze());
+  const double t_commit = now_ms();
+  // ------------------------------------------------------------ quotient
+  CK(extend_cols(ctx, pk, pk->adv_l.fr(), cfg.n_advice(), pk->adv_ext.fr()));
+  CK(extend_cols(ctx, pk, pk->pz_l.fr(), nch, pk->pz_ext.fr()));
+  CK(extend_cols(ctx, pk, pk->lz_l.fr(), cfg.n_lookup, pk->lz_ext.fr()));
+  CK(extend_cols(ctx, pk, pk->la_l.fr(), cfg.n_lookup, pk->la_ext.fr()));
+  CK(extend_cols(ctx, pk, pk->ls_l.fr(), cfg.n_lookup, pk->ls_ext.fr()));
+  CK(extend_cols(ctx, pk, pk->inst_l.fr(), 1, pk->inst_ext.fr()));
+  {
+    // expression groups, in the folding order of oracle/halo2_ref.py expressions_at
+    std::vector<zkp::QGroup> groups;
+    std::vector<size_t> last_e;  // global index of the last expression of each group
+    size_t e = 0;
+    auto push = [&](int type, int first, int count, size_t n_expr) {
+      groups.push_back(zkp::QGroup{type, first, count, 0});
+      e += n_expr;
+      last_e.push_back(e - 1);
+    };
+    for (unsigned j = 0; j < cfg.n_gate(); j += 8) push(zkp::QG_GATE, (int)j, (int)std::min(8u, cfg.n_gate() - j), std::min(8u, cfg.n_gate() - j));
+    if (cfg.n_rlc) push(zkp::QG_RLC, 0, (int)cfg.n_rlc, cfg.n_rlc);
+    push(zkp::QG_PERM_HEAD, 0, 2, 2);
+    for (unsigned j = 1; j < nch; j += 32) push(zkp::QG_PERM_C, (int)j, (int)std::min<size_t>(32, nch - j), std::min<size_t>(32, nch - j));
+    for (unsigned j = 0; j < nch; j += 4) push(zkp::QG_PERM_D, (int)j, (int)std::min<size_t>(4, nch - j), std::min<size_t>(4, nch - j));
+    for (unsigned i = 0; i < cfg.n_lookup; i += 3) push(zkp::QG_LOOKUP, (int)i, (int)std::min(3u, cfg.n_lookup - i), 5 * std::min(3u, cfg.n_lookup - i));
+    const size_t E = e, G = groups.size();
+    if (G > 96) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
+    std::vector<Fr> ypow(G);
+    for (size_t g = 0; g < G; ++g) ypow[g] = fr_pow(y, E - 1 - last_e[g]);
+    zkp::QGroup *groups_dev = (zkp::QGroup *)((char *)pk->small.p + 256 * 1024);
+    Fr *ypow_dev = (Fr *)((char *)pk->small.p + 384 * 1024);
+    Fr *zinv_dev = (Fr *)((char *)pk->small.p + 512 * 1024);
+    CK(zkfhe_upload(ctx, groups_dev, groups.data(), G * sizeof(zkp::QGroup)));
+    CK(zkfhe_upload(ctx, ypow_dev, ypow.data(), G * 32));
+    const Fr wext = zk_fr_root_of_unity((int)k + 2);
+    const Fr gn = fr_pow(mont_u64(COSET_G), n), i4 = fr_pow(wext, n);
+    Fr zinv[4], cur = gn;
+    for (int t = 0; t < 4; ++t) {
+      zinv[t] = fr_inv(cur - Fr::one());
+      cur = cur * i4;
+    }
+    CK(zkfhe_upload(ctx, zinv_dev, zinv, 4 * 32));
+    zkp::QArgs qa;
+    qa.adv = pk->adv_ext.fr();
+    qa.fix = pk->fixed_ext.fr();
+    qa.sig = pk->sigma_ext.fr();
+    qa.pz = pk->pz_ext.fr();
+    qa.lz = pk->lz_ext.fr();
+    qa.la = pk->la_ext.fr();
+    qa.ls = pk->ls_ext.fr();
+    qa.inst = pk->inst_ext.fr();
+    qa.lext = pk->l_ext.fr();
+    qa.xs = pk->xs_ext.fr();
+    qa.beta_delta = beta_delta_dev;
+    qa.groups = groups_dev;
+    qa.partials = pk->partials.fr();
+    qa.y = y;
+    qa.beta = beta;
+    qa.gamma = gamma;
+    qa.gamma_rlc = mont(gamma_rlc);
+    qa.log_n = k;
+    qa.u = (unsigned)u;
+    qa.n_gate = cfg.n_gate();
+    qa.n_rlc = cfg.n_rlc;
+    qa.adv_rlc0 = cfg.adv_rlc0();
+    qa.fix_qrlc0 = cfg.fix_qrlc0();
+    qa.fix_const = cfg.fix_const();
+    qa.fix_table = cfg.fix_table();
+    qa.adv_lookup0 = cfg.adv_lookup0();
+    qa.n_advice = cfg.n_advice();
+    qa.n_perm = cfg.n_perm();
+    qa.chunk = cfg.chunk();
+    qa.n_chunks = cfg.n_chunks();
+    dim3 grid((unsigned)((ne + 255) / 256), (unsigned)G);
+    zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
+    ZK_LAUNCH_CHECK(ctx);
+    zkp::k_quotient_combine<<<(unsigned)((ne + 255) / 256), 256, 0, ctx->stream>>>(pk->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, pk->h_ext.fr());
+    ZK_LAUNCH_CHECK(ctx);
+    const Fr g = mont_u64(COSET_G);
+    CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)pk->h_ext.p, (zkfhe_fr *)pk->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));
+  }
+  std::vector<AffinePoint> h_commit;
+  CK(commit_cols(ctx, srs->g, pk->h_c.fr(), 3, (G1Affine *)pk->points.p, h_commit));
+  {
+    // the quotient must have degree < 3n: a non-zero top quarter means a violated constraint
+    std::vector<U256> top(8);
+    CK(zkfhe_download(ctx, top.data(), pk->h_c.fr() + 3 * n, 8 * 32));
+    for (const auto &v : top)
+      if (!v.is_zero()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "quotient degree too high: a constraint is violated");
+  }
+  for (const auto &p : h_commit) tr.write_point(p);
+  const U256 x_c = tr.squeeze();
+  const Fr x = mont(x_c);
+  const double t_quot = now_ms();
+  // ------------------------------------------------------------ evaluations at x * w^rot (barycentric, Lagrange form)
+  const Fr xn = fr_pow(x, n);
+  {
+    // H(X) = h0 + x^n h1 + x^2n h2, and the random polynomial, in Lagrange form
+    const Fr sc[3] = {Fr::one(), xn, xn * xn};
+    const Fr *ptrs[3] = {pk->h_c.fr(), pk->h_c.fr() + n, pk->h_c.fr() + 2 * n};
+    const Fr **ptrs_dev = (const Fr **)((char *)pk->small.p + 640 * 1024);
+    Fr *sc_dev = (Fr *)((char *)pk->small.p + 648 * 1024);
+    CK(zkfhe_upload(ctx, ptrs_dev, ptrs, sizeof(ptrs)));
+    CK(zkfhe_upload(ctx, sc_dev, sc, sizeof(sc)));
+    zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
+    ZK_LAUNCH_CHECK(ctx);
+    ZK_HIP(ctx, hipMemcpyAsync(H_l, H_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(rand_l, rand_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)H_l, 1, (int)k, 0));
+    CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)rand_l, 1, (int)k, 0));
+  }
+  // rotation ids: 0,1,2,3 -> w^r ; 4 -> w^u ("last") ; 5 -> w^-1
+  Fr pts_rot[6];
+  {
+    const Fr w = dom->omega;
+    pts_rot[0] = x;
+    pts_rot[1] = x * w;
+    pts_rot[2] = pts_rot[1] * w;
+    pts_rot[3] = pts_rot[2] * w;
+    pts_rot[4] = x * fr_pow(w, u);
+    pts_rot[5] = x * dom->omega_inv;
+  }
+  Fr *bw = pk->misc.fr();  // [6][n] barycentric weights
+  {
+    Fr *pts_dev = (Fr *)((char *)pk->small.p + 656 * 1024);
+    CK(zkfhe_upload(ctx, pts_dev, pts_rot, sizeof(pts_rot)));
+    zkp::k_bary_den<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, pts_dev, 6, n, bw);
+    ZK_LAUNCH_CHECK(ctx);
+    CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)bw, 6 * n));
+    const Fr c = (xn - Fr::one()) * dom->n_inv;
+    zkp::k_bary_weights<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, c, 6 * n, n, bw);
+    ZK_LAUNCH_CHECK(ctx);
+  }
+  std::vector<OpenItem> items;
+  auto add_item = [&](const Fr *lagr, std::initializer_list<int> rots) {
+    OpenItem it;
+    it.lagr = lagr;
+    it.n_rot = 0;
+    for (int r : rots) it.rot[it.n_rot++] = r;
+    items.push_back(it);
+  };
+  for (unsigned c = 0; c < cfg.n_advice(); ++c) {
+    const Fr *p = pk->adv_l.fr() + (size_t)c * n;
+    if (c < cfg.n_gate()) add_item(p, {0, 1, 2, 3});
+    else if (c < cfg.adv_rlc0()) add_item(p, {0});
+    else add_item(p, {0, 1, 2});
+  }
+  for (unsigned c = 0; c < cfg.n_fixed(); ++c) add_item(pk->fixed_l.fr() + (size_t)c * n, {0});
+  const size_t idx_H = items.size();
+  add_item(H_l, {0});
+  add_item(rand_l, {0});
+  for (unsigned c = 0; c < cfg.n_perm(); ++c) add_item(pk->sigma_l.fr() + (size_t)c * n, {0});
+  for (unsigned j = 0; j < nch; ++j) {
+    if (j + 1 != nch) add_item(pk->pz_l.fr() + (size_t)j * n, {0, 1, 4});
+    else add_item(pk->pz_l.fr() + (size_t)j * n, {0, 1});
+  }
+  for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+    add_item(pk->lz_l.fr() + (size_t)i * n, {0, 1});
+    add_item(pk->la_l.fr() + (size_t)i * n, {0, 5});
+    add_item(pk->ls_l.fr() + (size_t)i * n, {0});
+  }
+  {
+    std::vector<zkp::EvalJob> jobs(items.size());
+    for (size_t i = 0; i < items.size(); ++i) {
+      jobs[i].col = items[i].lagr;
+      jobs[i].n_rot = items[i].n_rot;
+      for (int r = 0; r < 4; ++r) jobs[i].rot[r] = r < items[i].n_rot ? items[i].rot[r] : 0;
+    }
+    DevBuf jd, od;
+    CK(jd.alloc(ctx, jobs.size() * sizeof(zkp::EvalJob)));
+    CK(od.alloc(ctx, jobs.size() * 4 * 32));
+    CK(zkfhe_upload(ctx, jd.p, jobs.data(), jobs.size() * sizeof(zkp::EvalJob)));
+    zkp::k_eval_jobs<<<(unsigned)jobs.size(), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, od.fr());
+    ZK_LAUNCH_CHECK(ctx);
+    CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)od.p, (zkfhe_fr *)od.p, jobs.size() * 4));
+    std::vector<U256> ev(jobs.size() * 4);
+    CK(zkfhe_download(ctx, ev.data(), od.p, ev.size() * 32));
+    for (size_t i = 0; i < items.size(); ++i)
+      for (int r = 0; r < items[i].n_rot; ++r) items[i].ev[r] = ev[i * 4 + r];
+    jd.release();
+    od.release();
+  }
+  for (size_t i = 0; i < items.size(); ++i) {
+    if (i == idx_H) continue;  // implied by the identity, not written
+    for (int r = 0; r < items[i].n_rot; ++r) tr.write_scalar(items[i].ev[r]);
+  }
+  // ------------------------------------------------------------ SHPLONK (Lagrange form; commitments are basis independent)
+  const Fr yq = mont(tr.squeeze());
+  struct SetInfo {
+    std::vector<int> rots;
+    std::vector<size_t> members;
+  };
+  std::vector<SetInfo> sets;
+  for (size_t i = 0; i < items.size(); ++i) {
+    std::vector<int> key(items[i].rot, items[i].rot + items[i].n_rot);
+    size_t s = 0;
+    for (; s < sets.size(); ++s)
+      if (sets[s].rots == key) break;
+    if (s == sets.size()) sets.push_back(SetInfo{key, {}});
+    sets[s].members.push_back(i);
+  }
+  const size_t ns = sets.size();
+  std::vector<int> all_rots;
+  for (const auto &s : sets)
+    for (int r : s.rots)
+      if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
+  Fr *F = pk->misc.fr() + 12 * n;  // [ns][n]
+  if (ns > 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many rotation sets");
+  std::vector<zkp::ShSet> shsets(ns);
+  {
+    size_t max_m = 0;
+    for (const auto &s : sets) max_m = std::max(max_m, s.members.size());
+    DevBuf pd, sd;
+    CK(pd.alloc(ctx, max_m * sizeof(void *)));
+    CK(sd.alloc(ctx, max_m * 32));
+    for (size_t j = 0; j < ns; ++j) {
+      const auto &mem = sets[j].members;
+      std::vector<const Fr *> ptrs(mem.size());
+      std::vector<Fr> pw(mem.size());
+      Fr cur = Fr::one();
+      const size_t np = sets[j].rots.size();
+      std::vector<Fr> comb(np, Fr::zero());
+      for (size_t m = 0; m < mem.size(); ++m) {
+        ptrs[m] = items[mem[m]].lagr;
+        pw[m] = cur;
+        for (size_t t = 0; t < np; ++t) comb[t] = comb[t] + cur * mont(items[mem[m]].ev[t]);
+        cur = cur * yq;
+      }
+      CK(zkfhe_upload(ctx, pd.p, ptrs.data(), mem.size() * sizeof(void *)));
+      CK(zkfhe_upload(ctx, sd.p, pw.data(), mem.size() * 32));
+      zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>((const Fr *const *)pd.p, (const Fr *)sd.p, (unsigned)mem.size(), n, F + j * n);
+      ZK_LAUNCH_CHECK(ctx);
+      CK(zkfhe_sync(ctx));
+      // r_j: interpolation through (pts, comb), ascending coefficients
+      zkp::ShSet &S = shsets[j];
+      for (int t = 0; t < 4; ++t) S.rc[t] = S.pts[t] = Fr::zero();
+      S.n_pts = (int)np;
+      for (size_t t = 0; t < np; ++t) S.pts[t] = pts_rot[sets[j].rots[t]];
+      for (size_t i = 0; i < np; ++i) {
+        std::vector<Fr> num(1, Fr::one());
+        Fr den = Fr::one();
+        for (size_t t = 0; t < np; ++t) {
+          if (t == i) continue;
+          std::vector<Fr> nxt(num.size() + 1, Fr::zero());
+          for (size_t q = 0; q < num.size(); ++q) {
+            nxt[q + 1] = nxt[q + 1] + num[q];
+            nxt[q] = nxt[q] - S.pts[t] * num[q];
+          }
+          num = nxt;
+          den = den * (S.pts[i] - S.pts[t]);
+        }
+        const Fr scl = comb[i] * fr_inv(den);
+        for (size_t q = 0; q < num.size(); ++q) S.rc[q] = S.rc[q] + num[q] * scl;
+      }
+    }
+    pd.release();
+    sd.release();
+  }
+  const Fr v = mont(tr.squeeze());
+  {
+    Fr cur = Fr::one();
+    for (size_t j = 0; j < ns; ++j) {
+      shsets[j].vj = cur;
+      shsets[j].coef = Fr::zero();
+      shsets[j].r_u = Fr::zero();
+      cur = cur * v;
+    }
+  }
+  zkp::ShSet *sets_dev = (zkp::ShSet *)((char *)pk->small.p + 700 * 1024);
+  Fr *zs = pk->misc.fr() + 20 * n;   // [ns][n]
+  Fr *hq = pk->misc.fr() + 28 * n;   // [n]
+  Fr *Wq = pk->misc.fr() + 29 * n;   // [n]
+  Fr *dinv = pk->misc.fr() + 30 * n; // [n]
+  CK(zkfhe_upload(ctx, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
+  zkp::k_sh_zs<<<grid_for(ctx, ns * n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, dom->fwd, n, zs);
+  ZK_LAUNCH_CHECK(ctx);
+  CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)zs, ns * n));
+  zkp::k_sh_h<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, zs, dom->fwd, n, hq);
+  ZK_LAUNCH_CHECK(ctx);
+  std::vector<AffinePoint> hq_commit, w_commit;
+  CK(commit_cols(ctx, srs->g_lagrange, hq, 1, (G1Affine *)pk->points.p, hq_commit));
+  tr.write_point(hq_commit[0]);
+  const Fr uu = mont(tr.squeeze());
+  {
+    Fr ztu = Fr::one();
+    for (int r : all_rots) ztu = ztu * (uu - pts_rot[r]);
+    for (size_t j = 0; j < ns; ++j) {
+      Fr zdiff = Fr::one();
+      for (int r : all_rots)
+        if (std::find(sets[j].rots.begin(), sets[j].rots.end(), r) == sets[j].rots.end()) zdiff = zdiff * (uu - pts_rot[r]);
+      shsets[j].coef = shsets[j].vj * zdiff;
+      Fr ru = shsets[j].rc[3];
+      ru = ru * uu + shsets[j].rc[2];
+      ru = ru * uu + shsets[j].rc[1];
+      ru = ru * uu + shsets[j].rc[0];
+      shsets[j].r_u = ru;
+    }
+    CK(zkfhe_upload(ctx, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
+    zkp::k_sh_den<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(dom->fwd, uu, n, dinv);
+    ZK_LAUNCH_CHECK(ctx);
+    CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)dinv, n));
+    zkp::k_sh_w<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, hq, ztu, dinv, n, Wq);
+    ZK_LAUNCH_CHECK(ctx);
+  }
+  CK(commit_cols(ctx, srs->g_lagrange, Wq, 1, (G1Affine *)pk->points.p, w_commit));
+  tr.write_point(w_commit[0]);
+  proof = tr.out;
+  const double t_end = now_ms();
+  if (timings) {
+    timings[0] = (float)(t_wit - t_start);
+    timings[1] = (float)(t_commit - t_wit);
+    timings[2] = (float)(t_quot - t_commit);
+    timings[3] = (float)(t_end - t_quot);
+    timings[4] = (float)(t_end - t_start);
+  }
+  return ZKFHE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkfhe_bfv_keygen(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const zkfhe_bfv_params *params,
+                     const zkfhe_bfv_config *config, zkfhe_bfv_pk **out) {
+  ZK_ARG(ctx, srs && input_json && params && config && out);
+  try {
+    return keygen_impl(ctx, srs, input_json, params_from_c(params), config_from_c(config), config->replay != 0, out);
+  } catch (const std::exception &e) {
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, e.what());
+  }
+}
+
+int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
+  if (!pk) return ZKFHE_OK;
+  zkfhe_sync(ctx);
+  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow, &pk->adv_l, &pk->la_l,
+                    &pk->ls_l, &pk->lz_l, &pk->pz_l, &pk->inst_l, &pk->tmp_c, &pk->adv_ext, &pk->pz_ext, &pk->lz_ext, &pk->la_ext, &pk->ls_ext,
+                    &pk->inst_ext, &pk->partials, &pk->h_ext, &pk->h_c, &pk->misc, &pk->points, &pk->num, &pk->den, &pk->small};
+  for (DevBuf *b : bufs) b->release();
+  delete pk;
+  return ZKFHE_OK;
+}
+
+int zkfhe_bfv_pk_info(const zkfhe_bfv_pk *pk, uint8_t vk_digest[32], uint32_t *n_fixed, uint32_t *n_sigma) {
+  if (!pk) return ZKFHE_EINVAL;
+  if (vk_digest) memcpy(vk_digest, pk->vk_digest.l, 32);
+  if (n_fixed) *n_fixed = (uint32_t)pk->fixed_commit.size();
+  if (n_sigma) *n_sigma = (uint32_t)pk->sigma_commit.size();
+  return ZKFHE_OK;
+}
+
+int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t *sigma_out) {
+  if (!pk) return ZKFHE_EINVAL;
+  for (size_t i = 0; i < pk->fixed_commit.size() && fixed_out; ++i) {
+    memcpy(fixed_out + 64 * i, pk->fixed_commit[i].x.l, 32);
+    memcpy(fixed_out + 64 * i + 32, pk->fixed_commit[i].y.l, 32);
+  }
+  for (size_t i = 0; i < pk->sigma_commit.size() && sigma_out; ++i) {
+    memcpy(sigma_out + 64 * i, pk->sigma_commit[i].x.l, 32);
+    memcpy(sigma_out + 64 * i + 32, pk->sigma_commit[i].y.l, 32);
+  }
+  return ZKFHE_OK;
+}
+
+int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count) {
+  if (!pk || !count) return ZKFHE_EINVAL;
+  const auto &v = which == 0 ? pk->cfg.bp_gate0 : which == 1 ? pk->cfg.bp_gate1 : pk->cfg.bp_rlc;
+  if (out && *count >= v.size()) memcpy(out, v.data(), v.size() * 4);
+  *count = (uint32_t)v.size();
+  return ZKFHE_OK;
+}
+
+int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk, const char *input_json, const uint8_t seed[32],
+                    uint8_t *proof_out, size_t proof_cap, size_t *proof_len, uint8_t *instances_out, size_t *n_instances, float *timings_ms) {
+  ZK_ARG(ctx, srs && pk && input_json && seed && proof_out && proof_len);
+  try {
+    std::vector<uint8_t> proof;
+    std::vector<U256> inst;
+    int rc = prove_impl(ctx, srs, const_cast<zkfhe_bfv_pk *>(pk), input_json, seed, proof, inst, timings_ms);
+    if (rc) return rc;
+    if (proof.size() > proof_cap) return zk_fail_msg(ctx, ZKFHE_EINVAL, "proof buffer too small");
+    memcpy(proof_out, proof.data(), proof.size());
+    *proof_len = proof.size();
+    if (n_instances) {
+      if (instances_out && *n_instances >= inst.size()) memcpy(instances_out, inst.data(), inst.size() * 32);
+      *n_instances = inst.size();
+    }
+    return ZKFHE_OK;
+  } catch (const std::exception &e) {
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, e.what());
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+// Device kernels of the prover steps P1, P4-P10: everything between the column NTT/MSM
+// primitives of csrc/ and the host-side transcript.  All polynomials stay resident in HBM; the
+// extended (quotient) domain is kept COSET-MAJOR ([k1][k2], see zkfhe_coset_ntt_batch), so a rotation by
+// omega is an index shift inside a row and X^n - 1 is constant per row.
+#pragma once
+#include "../csrc/ctx.hpp"
+
+namespace zkp {
+
+using zk::Fr;
+
+// ------------------------------------------------------------------------------------------- small utilities
+// out[i] = start * base^i
+__global__ void __launch_bounds__(256) k_powers(Fr start, Fr base, Fr *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr r = start, b = base;
+    for (size_t e = i; e; e >>= 1) {
+      if (e & 1) r = r * b;
+      b = zk::fp_sqr<zk::FrP>(b);
+    }
+    out[i] = r;
+  }
+}
+
+// SRS: den[i] = n (s - w^i)   (inverted by the caller);  then li[i] = w^i (s^n - 1) * inv[i]
+__global__ void __launch_bounds__(256) k_srs_den(const Fr *__restrict__ wpow, Fr s, Fr nn, Fr *__restrict__ out, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (s - wpow[i]) * nn;
+}
+__global__ void __launch_bounds__(256) k_srs_li(const Fr *__restrict__ wpow, Fr snm1, Fr *__restrict__ inv_inout, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) inv_inout[i] = wpow[i] * snm1 * inv_inout[i];
+}
+__global__ void __launch_bounds__(256) k_fill_point(zk::G1Affine p, zk::G1Affine *__restrict__ out, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = p;
+}
+
+// sigma_l[cell] = delta^(col of target) * omega^(row of target)
+__global__ void __launch_bounds__(256) k_sigma_values(const uint32_t *__restrict__ target, const Fr *__restrict__ dpow,
+                                                      const Fr *__restrict__ wpow, Fr *__restrict__ out, size_t cells, int log_n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const uint32_t t = target[i];
+  out[i] = dpow[t >> log_n] * wpow[t & ((1u << log_n) - 1)];
+}
+
+// ------------------------------------------------------------------------------------------- grand products
+struct PermArgs {
+  const Fr *adv;      // [n_advice][n] Lagrange
+  const Fr *constcol; // [n]
+  const Fr *inst;     // [n]
+  const Fr *sigma;    // [n_perm][n]
+  const Fr *wpow;     // omega^i
+  const Fr *beta_delta;  // [n_perm] beta * delta^c
+  Fr beta, gamma;
+  unsigned n_advice, n_perm, chunk, n_chunks;
+  size_t n;
+};
+__device__ __forceinline__ const Fr *perm_col(const PermArgs &a, unsigned c) {
+  return c < a.n_advice ? a.adv + (size_t)c * a.n : (c == a.n_advice ? a.constcol : a.inst);
+}
+// num[j][i] = prod_c (v_c + beta delta^c w^i + gamma), den[j][i] = prod_c (v_c + beta sigma_c + gamma)
+__global__ void __launch_bounds__(256) k_perm_num_den(PermArgs a, Fr *__restrict__ num, Fr *__restrict__ den) {
+  const size_t total = (size_t)a.n_chunks * a.n;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const unsigned j = (unsigned)(g / a.n);
+    const size_t i = g - (size_t)j * a.n;
+    Fr nu = Fr::one(), de = Fr::one();
+    const Fr w = a.wpow[i];
+    for (unsigned c = j * a.chunk; c < (j + 1) * a.chunk && c < a.n_perm; ++c) {
+      const Fr v = perm_col(a, c)[i];
+      nu = nu * (v + a.beta_delta[c] * w + a.gamma);
+      de = de * (v + a.beta * a.sigma[(size_t)c * a.n + i] + a.gamma);
+    }
+    num[g] = nu;
+    den[g] = de;
+  }
+}
+// lookup: num = (a + beta)(s + gamma), den = (a' + beta)(s' + gamma)
+__global__ void __launch_bounds__(256) k_lookup_num_den(const Fr *__restrict__ a_cols, const Fr *__restrict__ table, const Fr *__restrict__ la,
+                                                        const Fr *__restrict__ ls, Fr beta, Fr gamma, unsigned n_lookup, size_t n,
+                                                        Fr *__restrict__ num, Fr *__restrict__ den) {
+  const size_t total = (size_t)n_lookup * n;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g % n;
+    num[g] = (a_cols[g] + beta) * (table[i] + gamma);
+    den[g] = (la[g] + beta) * (ls[g] + gamma);
+  }
+}
+
+// Exclusive running product per column: z[0] = 1, z[i+1] = z[i] * r[i] for i < u; z has u+1 defined entries.
+// One workgroup of 1024 threads per column; thread t owns rows [t*per, (t+1)*per).  `total[col]` = z[u].
+__global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__restrict__ ratio, Fr *__restrict__ z, Fr *__restrict__ total, size_t n,
+                                                         unsigned u) {
+  __shared__ Fr sh[1024];
+  const size_t col = blockIdx.x;
+  const Fr *r = ratio + col * n;
+  Fr *o = z + col * n;
+  const unsigned per = (unsigned)((n + 1023) / 1024);
+  const unsigned lo = threadIdx.x * per;
+  Fr local = Fr::one();
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned i = lo + k;
+    if (i < u) local = local * r[i];
+  }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  // inclusive Hillis-Steele scan of the 1024 partial products
+  for (unsigned d = 1; d < 1024; d <<= 1) {
+    Fr v = sh[threadIdx.x];
+    Fr other = threadIdx.x >= d ? sh[threadIdx.x - d] : Fr::one();
+    __syncthreads();
+    if (threadIdx.x >= d) sh[threadIdx.x] = other * v;
+    __syncthreads();
+  }
+  Fr acc = threadIdx.x ? sh[threadIdx.x - 1] : Fr::one();  // product of everything before this thread's rows
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned i = lo + k;
+    if (i <= u) o[i] = acc;
+    if (i < u) acc = acc * r[i];
+  }
+  if (threadIdx.x == 1023) total[col] = sh[1023];
+}
+// z[col][0..u] *= carry[col]
+__global__ void __launch_bounds__(256) k_scale_rows(Fr *__restrict__ z, const Fr *__restrict__ carry, size_t n, unsigned rows, unsigned n_cols) {
+  const size_t total = (size_t)n_cols * rows;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const unsigned col = (unsigned)(g / rows);
+    const unsigned i = (unsigned)(g - (size_t)col * rows);
+    Fr *p = z + (size_t)col * n + i;
+    *p = *p * carry[col];
+  }
+}
+
+// ------------------------------------------------------------------------------------------- quotient
+enum { QG_GATE = 0, QG_RLC = 1, QG_PERM_HEAD = 2, QG_PERM_C = 3, QG_PERM_D = 4, QG_LOOKUP = 5 };
+struct QGroup {
+  int type, first, count, pad;
+};
+struct QArgs {
+  const Fr *adv, *fix, *sig, *pz, *lz, *la, *ls, *inst, *lext, *xs;  // extended (coset-major) evaluations
+  const Fr *beta_delta;                                               // [n_perm]
+  const QGroup *groups;
+  Fr *partials;  // [n_groups][4n]
+  Fr y, beta, gamma, gamma_rlc;
+  unsigned log_n, u, n_gate, n_rlc, adv_rlc0, fix_qrlc0, fix_const, fix_table, adv_lookup0, n_advice, n_perm, chunk, n_chunks;
+};
+
+__global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
+  const size_t n = (size_t)1 << a.log_n, ne = n << 2;
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= ne) return;
+  const QGroup g = a.groups[blockIdx.y];
+  const size_t row0 = p & ~(n - 1);           // k1 * n
+  const size_t k2 = p & (n - 1);
+  auto at = [&](const Fr *base, unsigned col, unsigned rot) -> Fr { return base[(size_t)col * ne + row0 + ((k2 + rot) & (n - 1))]; };
+  const Fr one = Fr::one();
+  Fr acc = Fr::zero();
+  switch (g.type) {
+    case QG_GATE:
+      for (int j = g.first; j < g.first + g.count; ++j) {
+        const Fr q = at(a.fix, j, 0);
+        Fr e = Fr::zero();
+        if (!q.is_zero()) e = q * (at(a.adv, j, 0) + at(a.adv, j, 1) * at(a.adv, j, 2) - at(a.adv, j, 3));
+        acc = acc * a.y + e;
+      }
+      break;
+    case QG_RLC:
+      for (int j = g.first; j < g.first + g.count; ++j) {
+        const unsigned col = a.adv_rlc0 + j;
+        const Fr q = at(a.fix, a.fix_qrlc0 + j, 0);
+        const Fr e = q * (at(a.adv, col, 0) * a.gamma_rlc + at(a.adv, col, 1) - at(a.adv, col, 2));
+        acc = acc * a.y + e;
+      }
+      break;
+    case QG_PERM_HEAD: {
+      const Fr l0 = a.lext[p], ll = a.lext[ne + p];
+      const Fr z0 = at(a.pz, 0, 0), zm = at(a.pz, a.n_chunks - 1, 0);
+      acc = l0 * (one - z0);
+      acc = acc * a.y + ll * (zm * zm - zm);
+      break;
+    }
+    case QG_PERM_C: {
+      const Fr l0 = a.lext[p];
+      for (int j = g.first; j < g.first + g.count; ++j) acc = acc * a.y + l0 * (at(a.pz, j, 0) - at(a.pz, j - 1, a.u));
+      break;
+    }
+    case QG_PERM_D: {
+      const Fr lact = a.lext[2 * ne + p];
+      const Fr x = a.xs[p];
+      for (int j = g.first; j < g.first + g.count; ++j) {
+        Fr left = at(a.pz, j, 1), right = at(a.pz, j, 0);
+        for (unsigned c = j * a.chunk; c < (j + 1) * a.chunk && c < a.n_perm; ++c) {
+          const Fr v = c < a.n_advice ? at(a.adv, c, 0) : (c == a.n_advice ? at(a.fix, a.fix_const, 0) : a.inst[p]);
+          left = left * (v + a.beta * at(a.sig, c, 0) + a.gamma);
+          right = right * (v + a.beta_delta[c] * x + a.gamma);
+        }
+        acc = acc * a.y + lact * (left - right);
+      }
+      break;
+    }
+    case QG_LOOKUP: {
+      const Fr l0 = a.lext[p], ll = a.lext[ne + p], lact = a.lext[2 * ne + p];
+      const Fr s = at(a.fix, a.fix_table, 0);
+      for (int i = g.first; i < g.first + g.count; ++i) {
+        const Fr z0 = at(a.lz, i, 0), z1 = at(a.lz, i, 1);
+        const Fr av = at(a.adv, a.adv_lookup0 + i, 0);
+        const Fr ap = at(a.la, i, 0), apm = at(a.la, i, (unsigned)(n - 1)), sp = at(a.ls, i, 0);
+        acc = acc * a.y + l0 * (one - z0);
+        acc = acc * a.y + ll * (z0 * z0 - z0);
+        acc = acc * a.y + lact * (z1 * ((ap + a.beta) * (sp + a.gamma)) - z0 * ((av + a.beta) * (s + a.gamma)));
+        acc = acc * a.y + l0 * (ap - sp);
+        acc = acc * a.y + lact * ((ap - sp) * (ap - apm));
+      }
+      break;
+    }
+  }
+  a.partials[(size_t)blockIdx.y * ne + p] = acc;
+}
+
+// h_ext[p] = (sum_g ypow[g] * partials[g][p]) * zinv[k1]
+__global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
+                                                          const Fr *__restrict__ zinv, unsigned log_n, Fr *__restrict__ h_ext) {
+  const size_t n = (size_t)1 << log_n, ne = n << 2;
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= ne) return;
+  Fr acc = Fr::zero();
+  for (unsigned g = 0; g < n_groups; ++g) acc = acc + ypow[g] * partials[(size_t)g * ne + p];
+  h_ext[p] = acc * zinv[p >> log_n];
+}
+
+// ------------------------------------------------------------------------------------------- evaluations
+// barycentric weights: d[r][i] = z_r - w^i (inverted by the caller), then b[r][i] = c * w^i * inv
+__global__ void __launch_bounds__(256) k_bary_den(const Fr *__restrict__ wpow, const Fr *__restrict__ pts, unsigned n_pts, size_t n,
+                                                  Fr *__restrict__ out) {
+  const size_t total = (size_t)n_pts * n;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x)
+    out[g] = pts[g / n] - wpow[g % n];
+}
+__global__ void __launch_bounds__(256) k_bary_weights(const Fr *__restrict__ wpow, Fr c, size_t total, size_t n, Fr *__restrict__ inout) {
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x)
+    inout[g] = inout[g] * wpow[g % n] * c;
+}
+// one workgroup per job: out[job][r] = sum_i col[i] * bw[rot_index[r]][i], up to 4 rotations per job
+struct EvalJob {
+  const Fr *col;
+  int n_rot;
+  int rot[4];  // indices into the weight table
+};
+__global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ jobs, const Fr *__restrict__ bw, size_t n, Fr *__restrict__ out) {
+  __shared__ Fr sh[256];
+  const EvalJob job = jobs[blockIdx.x];
+  Fr acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = Fr::zero();
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const Fr v = job.col[i];
+    for (int r = 0; r < job.n_rot; ++r) acc[r] = acc[r] + v * bw[(size_t)job.rot[r] * n + i];
+  }
+  for (int r = 0; r < job.n_rot; ++r) {
+    sh[threadIdx.x] = acc[r];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * 4 + r] = sh[0];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------- SHPLONK
+// out[i] = sum_m s[m] * ptr[m][i]
+__global__ void __launch_bounds__(256) k_lincomb_ptrs(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, size_t n,
+                                                      Fr *__restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = Fr::zero();
+    for (unsigned k = 0; k < m; ++k) acc = acc + s[k] * ptrs[k][i];
+    out[i] = acc;
+  }
+}
+struct ShSet {
+  Fr rc[4];    // r_j coefficients (ascending), unused ones zero
+  Fr pts[4];   // points of S_j
+  Fr vj;       // v^j
+  Fr coef;     // v^j * Z_{T\S_j}(u)
+  Fr r_u;      // r_j(u)
+  int n_pts, pad[3];
+};
+// zs[j][i] = prod_{p in S_j} (w^i - p)
+__global__ void __launch_bounds__(256) k_sh_zs(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ wpow, size_t n,
+                                               Fr *__restrict__ zs) {
+  const size_t total = (size_t)n_sets * n;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const ShSet &s = sets[g / n];
+    const Fr w = wpow[g % n];
+    Fr acc = Fr::one();
+    for (int t = 0; t < s.n_pts; ++t) acc = acc * (w - s.pts[t]);
+    zs[g] = acc;
+  }
+}
+// hq[i] = sum_j v^j (F_j[i] - r_j(w^i)) * zs_inv[j][i]
+__global__ void __launch_bounds__(256) k_sh_h(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ F, const Fr *__restrict__ zs_inv,
+                                              const Fr *__restrict__ wpow, size_t n, Fr *__restrict__ hq) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const Fr w = wpow[i];
+    Fr acc = Fr::zero();
+    for (unsigned j = 0; j < n_sets; ++j) {
+      const ShSet &s = sets[j];
+      Fr r = s.rc[3];
+      r = r * w + s.rc[2];
+      r = r * w + s.rc[1];
+      r = r * w + s.rc[0];
+      acc = acc + s.vj * (F[(size_t)j * n + i] - r) * zs_inv[(size_t)j * n + i];
+    }
+    hq[i] = acc;
+  }
+}
+// den[i] = w^i - u (inverted by the caller);  W[i] = (sum_j coef_j (F_j[i] - r_j(u)) - ztu * hq[i]) * inv[i]
+__global__ void __launch_bounds__(256) k_sh_den(const Fr *__restrict__ wpow, Fr u, size_t n, Fr *__restrict__ out) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wpow[i] - u;
+}
+__global__ void __launch_bounds__(256) k_sh_w(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ F, const Fr *__restrict__ hq,
+                                              Fr ztu, const Fr *__restrict__ inv, size_t n, Fr *__restrict__ W) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = Fr::zero();
+    for (unsigned j = 0; j < n_sets; ++j) acc = acc + sets[j].coef * (F[(size_t)j * n + i] - sets[j].r_u);
+    W[i] = (acc - ztu * hq[i]) * inv[i];
+  }
+}
+
+}  // namespace zkp
