@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""bench.py -- hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+"""bench.py -- BFV proofs/sec on MI355X (metric of BASELINE.json; contract in the task statement, DESIGN.md "Measurement").
 
-A "step" = one pass of the prover's column hot path over the witness columns of ONE k=13 BFV proof
-(n = 2^13 rows, 197 advice columns as pinned by the reference's configs/bfv.json):
-    commit_lagrange (MSM, 197 x 8192)  +  lagrange_to_coeff (iNTT, 197 x 8192)
-    + coeff_to_extended (coset NTT to 2^15, 197 columns)
-with every input already resident in HBM.  N>1: independent proofs, one replica per rank (weak scaling,
-no data-path collective).
+A "step" = ONE complete proof of zk-fhe's BFV correct-encryption circuit at the reference's configuration
+(k = 13, N = 1024, Q = 536870909, the column layout pinned by the reference's configs/bfv.json): host witness
+generation + the whole create_proof (197 advice commits, lookup / permutation arguments, quotient, evaluations,
+SHPLONK) through zkfhe_bfv_prove.  The proving key, SRS tables and the input texts are resident before the timed
+region (the reference's 10.2 s likewise excludes SRS / pk loading).  Inputs are seeded synthetic BFV
+encryptions of that shape.  N > 1: independent proofs, one replica per rank -- weak scaling, no data-path collective.
 """
 import argparse
 import json
@@ -19,31 +19,35 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K = 13
-N_COLS = 197
 HBM_PEAK_GBS = 8000.0
+Q, T, B, N = 536870909, 7, 19, 1024
 
 
-def synth_columns(rng, n_cols, n):
-    """Synthetic witness-like columns, Montgomery Fr (seeded). Mix: 1/3 uniform Fr, 1/3 8-bit lookup
-    limbs, 1/3 29..70-bit values with some negatives -- the scalar mix of the BFV circuit."""
-    from oracle import binding as orc
-    from oracle import pyref
-    out = np.empty((n_cols, n, 4), dtype=np.uint64)
-    for c in range(n_cols):
-        kind = c % 3
-        if kind == 0:
-            raw = np.frombuffer(rng.bytes(32 * n), dtype=np.uint64).reshape(n, 4).copy()
-            raw[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)  # < 2^252 < r
-        elif kind == 1:
-            raw = np.zeros((n, 4), dtype=np.uint64)
-            raw[:, 0] = rng.integers(0, 256, size=n, dtype=np.uint64)
-        else:
-            raw = np.zeros((n, 4), dtype=np.uint64)
-            raw[:, 0] = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
-            raw[:, 1] = rng.integers(0, 64, size=n, dtype=np.uint64)
-        out[c] = raw
-    return orc.to_mont(out.reshape(-1, 4)).reshape(n_cols, n, 4)
+def synth_bfv_input(seed):
+    """A valid BFV encryption (c0 = pk0*u + floor(Q/T)*m + e0, c1 = pk1*u + e1 in Z_Q[x]/(x^N+1)), as the JSON text the
+    reference's CircuitInput (examples/bfv.rs:50-61) parses.  Formula checked against data/bfv/bfv.in (tests, KAT 1)."""
+    rng = np.random.default_rng(seed)
+    pk0 = rng.integers(0, Q, N, dtype=np.int64)
+    pk1 = rng.integers(0, Q, N, dtype=np.int64)
+    u = rng.choice(np.array([0, 1, Q - 1], dtype=np.int64), N)
+    m = rng.choice(np.array(list(range(0, T // 2 + 1)) + [Q - i for i in range(1, T // 2 + 1)], dtype=np.int64), N)
+    e = np.clip(np.rint(rng.normal(0, 3.2, (2, N))), -B, B).astype(np.int64) % Q
+
+    def negacyclic(a, b):  # big-endian coefficient order in, out; b taken as residues in [0, Q)
+        a, b = a[::-1], b[::-1]
+        out = np.zeros(N, dtype=np.int64)
+        for i in np.nonzero(b)[0]:
+            sh = np.empty(N, dtype=np.int64)
+            sh[i:] = a[: N - i]
+            sh[:i] = (Q - a[N - i:]) % Q
+            out = (out + (sh * int(b[i])) % Q) % Q
+        return out[::-1]
+    c0 = (negacyclic(pk0, u) + (Q // T) * m % Q + e[0]) % Q
+    c1 = (negacyclic(pk1, u) + e[1]) % Q
+    cyclo = np.zeros(N + 1, dtype=np.int64)
+    cyclo[0] = cyclo[N] = 1
+    s = lambda v: [str(int(x)) for x in v]  # noqa: E731
+    return json.dumps(dict(pk0=s(pk0), pk1=s(pk1), m=s(m), u=s(u), e0=s(e[0]), e1=s(e[1]), c0=s(c0), c1=s(c1), cyclo=s(cyclo)))
 
 
 def main():
@@ -64,96 +68,88 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import zk_fhe_amd as zk
-    from oracle import binding as orc
 
     ctx = zk.Context(local_rank)
-    n = 1 << K
-    rng = np.random.default_rng(20240613 + rank)
-    cols_host = synth_columns(rng, N_COLS, n)
-    bases = orc.g1_powers(orc.ints_to_mont([5])[0], orc.ints_to_mont([77])[0], n)
-    basis = zk.Basis(ctx, bases)
-    g = orc.ints_to_mont([7])[0]
-    d_lagr = ctx.to_device(cols_host)                 # resident inputs
-    d_work = ctx.alloc(N_COLS * n * 32)
-    d_ext = ctx.alloc(N_COLS * n * 4 * 32)
-    d_commit = ctx.alloc(N_COLS * 64)
-    nbytes = N_COLS * n * 32
-
-    def step(timers=None):
-        if timers is not None:
-            ctx.timer_start()
-        ctx.msm_dev(basis, d_lagr, N_COLS, d_commit)
-        if timers is not None:
-            timers["msm"].append(ctx.timer_stop_ms())
-        ctx._check(ctx.lib.zkfhe_copy_dev(ctx.h, d_work.at(0), d_lagr.at(0), nbytes))
-        if timers is not None:
-            ctx.timer_start()
-        ctx.ntt_dev(d_work, N_COLS, K, inverse=True)
-        if timers is not None:
-            timers["intt"].append(ctx.timer_stop_ms())
-            ctx.timer_start()
-        ctx.coset_ntt_dev(d_work, d_ext, N_COLS, K, 2, g)
-        if timers is not None:
-            timers["coset"].append(ctx.timer_stop_ms())
+    cfgj = json.load(open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv_config.json")))
+    zcfg = zk.BfvConfig.from_pinning(cfgj)
+    empty = json.dumps({k: ["0"] * (N + 1 if k == "cyclo" else N) for k in ("pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo")})
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, empty, (N, Q, T, B), zcfg, replay=True)
+    inputs = [synth_bfv_input(20240613 + 1000 * rank + i) for i in range(4)]
+    seeds = [b"bench-%d-%d" % (rank, i) for i in range(args.steps + args.warmup + 4)]
 
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        ctx.sync()
 
+    si = 0
     for _ in range(args.warmup):
-        step()
+        pk.prove(inputs[si % 4], seeds[si])
+        si += 1
     barrier()
     t0 = time.perf_counter()
+    stage = np.zeros(5)
+    proof_len = 0
     for _ in range(args.steps):
-        step()
+        proof, inst, tm = pk.prove(inputs[si % 4], seeds[si])
+        stage += np.array(tm)
+        proof_len = len(proof)
+        si += 1
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    stage /= max(1, args.steps)
 
-    # per-kernel-family durations with HIP events on the context's stream (extra, untimed steps)
-    timers = {"msm": [], "intt": [], "coset": []}
-    for _ in range(max(3, min(args.steps, 10))):
-        step(timers)
-    ctx.sync()
-    msm_ms = float(np.median(timers["msm"]))
-    intt_ms = float(np.median(timers["intt"]))
-    coset_ms = float(np.median(timers["coset"]))
+    # dominant kernel (k_msm_accumulate) timed live with HIP events on the library's stream, in a separate untimed pass
+    ctx.prof_enable(True)
+    for _ in range(2):
+        pk.prove(inputs[si % 4], seeds[si % len(seeds)])
+    msm = ctx.prof_read(0)
+    ntt = ctx.prof_read(1)
+    ctx.prof_enable(False)
 
     if rank == 0:
-        # roofline of the dominant stage (MSM): algorithmic bytes = (32 B scalar + 64 B base) per term
-        msm_bytes = 96.0 * n * N_COLS
-        ach = msm_bytes / (msm_ms * 1e-3) / 1e9
-        ntt_ach = 64.0 * n * N_COLS / (intt_ms * 1e-3) / 1e9
+        ach = msm["algorithmic_bytes"] / (msm["total_ms"] * 1e-3) / 1e9
+        ntt_ach = ntt["algorithmic_bytes"] / (ntt["total_ms"] * 1e-3) / 1e9 if ntt["launches"] else None
         cpu = None
-        if not args.no_cpu_baseline:
-            sample_cols = 8
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle prover (Python orchestration + OpenMP C kernels) on ONE proof of the same workload
+            from oracle import binding as orc
+            from oracle import circuit_ref as C
+            from oracle import halo2_ref as H
+            hcfg = H.Config.from_pinning(cfgj)
+            bp = {"gate0": cfgj["break_points"]["gate"][0], "gate1": cfgj["break_points"]["gate"][1], "rlc": cfgj["break_points"]["rlc"]}
+            srs_o = H.make_srs(13)
+            pk_o, _ = H.keygen_circuit(hcfg, H.BfvCircuit(json.loads(empty), C.BfvParams()), srs_o, bp)
             t1 = time.perf_counter()
-            orc.msm(cols_host[:sample_cols], bases)
-            c = orc.ntt(cols_host[:sample_cols], K, True)
-            for i in range(sample_cols):
-                orc.coset_ntt(c[i], K + 2, g)
+            proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, H.BfvCircuit(json.loads(inputs[0]), C.BfvParams()), seeds[0])
             cdt = time.perf_counter() - t1
-            cpu = {"value": (sample_cols / N_COLS) / cdt, "unit": "hot-path passes/s", "cores": orc.num_threads(),
-                   "kind": "port", "sample": "%d of %d columns (MSM + iNTT + coset NTT), oracle C, OpenMP" % (sample_cols, N_COLS)}
+            gpu_proof, _, _ = pk.prove(inputs[0], seeds[0])
+            cpu = {"value": 1.0 / cdt, "unit": "proofs/s", "cores": orc.num_threads(), "kind": "port",
+                   "sample": "1 full k=13 proof by the oracle prover (oracle/halo2_ref.py: Python + OpenMP C); same bytes as the GPU proof: %s"
+                             % (gpu_proof == proof_o)}
         out = {
-            "metric": "BFV k=13 prover column hot-path passes/sec (197 cols: MSM commit + iNTT + coset NTT); full proofs/sec pending prover",
-            "value": world * args.steps / dt, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x8 (256-bit Montgomery integers)", "data": "synthetic",
-            "config": {"workload": "k=13, n=8192, 197 witness columns, one proof per GPU", "window_bits": 13},
-            "roofline": {"bound": "hbm", "kernel": "zkfhe_msm_batch (k_msm_accumulate dominant)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "stages_ms": {"msm": msm_ms, "intt": intt_ms, "coset_ntt": coset_ms},
-                         "ntt_achieved_GBs": ntt_ach},
+            "metric": "BFV proofs/sec (k=13)", "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if world == 1 else None,
+            "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
+            "config": {"workload": "single proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout",
+                       "proof_bytes": proof_len, "stage_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3]},
+                       "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
+                         "launches_per_proof": msm["launches"] / 2,
+                         "ntt_tile": {"achieved": ntt_ach, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    pk.destroy()
+    srs.destroy()
     if world > 1:
         dist.destroy_process_group()
 

@@ -69,6 +69,14 @@ int zkfhe_memset_dev(zkfhe_ctx *ctx, void *dst_dev, int byte, size_t bytes);
 int zkfhe_timer_start(zkfhe_ctx *ctx);
 int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms);   /* waits for the stop event */
 
+/* Per-kernel profiling with HIP events on the context's stream.  While enabled, zkfhe_msm_batch and
+ * zkfhe_ntt_batch bracket their dominant kernel (which 0: k_msm_accumulate, 1: k_ntt_tile) with an event pair
+ * and wait for it, accumulating duration, launch count and ALGORITHMIC bytes (MSM: 96 B per term, NTT: 64 B per
+ * point -- BASELINE.md).  Meant for a separate, untimed pass (it serialises the stream). */
+int zkfhe_prof_enable(zkfhe_ctx *ctx, int on);
+int zkfhe_prof_reset(zkfhe_ctx *ctx);
+int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launches, double *algorithmic_bytes);
+
 /* ---- coefficient-wise Fr arithmetic (device buffers, out may alias a or b) ----------------- */
 int zkfhe_fr_add(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);
 int zkfhe_fr_sub(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);

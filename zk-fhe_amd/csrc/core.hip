@@ -81,6 +81,8 @@ int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
   }
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
+  hipEventCreate(&ctx->pe0);
+  hipEventCreate(&ctx->pe1);
   *out = ctx;
   return ZKFHE_OK;
 }
@@ -149,6 +151,25 @@ int zkfhe_copy_dev(zkfhe_ctx *ctx, void *dst_dev, const void *src_dev, size_t by
 }
 int zkfhe_memset_dev(zkfhe_ctx *ctx, void *dst_dev, int byte, size_t bytes) {
   ZK_HIP(ctx, hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
+  return ZKFHE_OK;
+}
+
+int zkfhe_prof_enable(zkfhe_ctx *ctx, int on) {
+  ctx->prof_on = on != 0;
+  return ZKFHE_OK;
+}
+int zkfhe_prof_reset(zkfhe_ctx *ctx) {
+  for (int i = 0; i < 2; ++i) {
+    ctx->prof_ms[i] = ctx->prof_bytes[i] = 0;
+    ctx->prof_launches[i] = 0;
+  }
+  return ZKFHE_OK;
+}
+int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launches, double *algorithmic_bytes) {
+  ZK_ARG(ctx, which >= 0 && which < 2);
+  if (total_ms) *total_ms = ctx->prof_ms[which];
+  if (launches) *launches = ctx->prof_launches[which];
+  if (algorithmic_bytes) *algorithmic_bytes = ctx->prof_bytes[which];
   return ZKFHE_OK;
 }
 

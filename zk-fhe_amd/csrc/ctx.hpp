@@ -26,6 +26,11 @@ struct zkfhe_ctx {
   int num_cu = 0;
   std::map<int, NttDomain> domains;
   // grow-only scratch arenas (bytes)
+  // profiling (zkfhe_prof_*): [0] = k_msm_accumulate, [1] = k_ntt_tile
+  bool prof_on = false;
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0};
+  uint64_t prof_launches[2] = {0, 0};
   void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[4] = {0, 0, 0, 0};
 };
@@ -52,6 +57,21 @@ int zk_fail_msg(zkfhe_ctx *ctx, int code, const std::string &msg);
   do {                                                                           \
     if (!(cond)) return zk_fail_msg((ctx), ZKFHE_EINVAL, std::string("bad argument: ") + #cond); \
   } while (0)
+
+// profiling brackets: call zk_prof_begin before and zk_prof_end after the kernel launch
+inline void zk_prof_begin(zkfhe_ctx *ctx) {
+  if (ctx->prof_on) (void)hipEventRecord(ctx->pe0, ctx->stream);
+}
+inline void zk_prof_end(zkfhe_ctx *ctx, int which, double bytes) {
+  if (!ctx->prof_on) return;
+  (void)hipEventRecord(ctx->pe1, ctx->stream);
+  (void)hipEventSynchronize(ctx->pe1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->pe0, ctx->pe1);
+  ctx->prof_ms[which] += ms;
+  ctx->prof_bytes[which] += bytes;
+  ctx->prof_launches[which] += 1;
+}
 
 // returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse
 int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);

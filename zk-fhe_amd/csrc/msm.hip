@@ -395,9 +395,11 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   ZK_LAUNCH_CHECK(ctx);
   const size_t nb = (size_t)K * n_cols;
   unsigned gridb = zk_blocks(nb, 256);
+  zk_prof_begin(ctx);
   k_msm_accumulate<<<gridb, 256, 0, ctx->stream>>>(off, entries, col_entries, basis->table, K, n_cols, buckets, heavy_count,
                                                    heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
+  zk_prof_end(ctx, 0, 96.0 * (double)n * (double)n_cols);
   unsigned gridh = (unsigned)(heavy_cap < 1024 ? heavy_cap : 1024);
   k_msm_accumulate_heavy<<<gridh, 256, 0, ctx->stream>>>(off, entries, col_entries, basis->table, K, buckets, heavy_count, heavy_list,
                                                          (unsigned)heavy_cap);

@@ -187,8 +187,10 @@ inline int launch_tile(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsign
     attr_set = true;
   }
   dim3 grid(tiles, cols);
+  zk_prof_begin(ctx);
   k_ntt_tile<LOGN><<<grid, N / 8, lds_bytes, ctx->stream>>>(a);
   ZK_LAUNCH_CHECK(ctx);
+  zk_prof_end(ctx, 1, 64.0 * (double)N * (double)tiles * (double)cols);
   return ZKFHE_OK;
 }
 
