@@ -92,3 +92,31 @@ def test_bfv_in_k13_proof_bytes_match_oracle(ctx):
     assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
     pk.destroy()
     srs.destroy()
+
+
+def test_concurrent_proofs_on_two_streams(ctx):
+    """Two contexts (streams + workspaces) of the same GPU prove against one key at the same time: same bytes as alone."""
+    import threading
+    import zk_fhe_amd as zk
+    prm = C.BfvParams(N=8)
+    inputs = [synth_input(8, prm.Q, prm.T, prm.B, s) for s in (1, 2, 3, 4)]
+    circ = H.BfvCircuit(inputs[0], prm)
+    hcfg = H.auto_config(9, 9, circ)
+    srs = zk.Srs(ctx, 9)
+    pk = zk.BfvProvingKey(ctx, srs, json.dumps(inputs[0]), (8, prm.Q, prm.T, prm.B), zk.BfvConfig(9, hcfg.n_gate0, hcfg.n_gate1, hcfg.n_lookup, hcfg.n_rlc, 9))
+    alone = [pk.prove(json.dumps(i), b"s%d" % k)[0] for k, i in enumerate(inputs)]
+    ctx2 = zk.Context(0)
+    got = [None] * 4
+
+    def work(c, ks):
+        for _ in range(3):
+            for k in ks:
+                got[k] = pk.prove(json.dumps(inputs[k]), b"s%d" % k, ctx=c)[0]
+    t1 = threading.Thread(target=work, args=(ctx, (0, 1)))
+    t2 = threading.Thread(target=work, args=(ctx2, (2, 3)))
+    t1.start(), t2.start()
+    t1.join(), t2.join()
+    assert got == alone
+    pk.destroy()
+    srs.destroy()
+    ctx2.close()

@@ -483,7 +483,10 @@ class BfvProvingKey:
         return {"vk_digest": int.from_bytes(d.raw, "little"), "fixed_commit": pts(fx, nf.value), "sigma_commit": pts(sg, ns.value),
                 "break_points": bps}
 
-    def prove(self, input_json_text, seed):
+    def prove(self, input_json_text, seed, ctx=None):
+        """One proof. `ctx`: the context (stream + workspace) to run on -- several contexts of the same GPU may
+        prove concurrently against this key from different threads (ctypes releases the GIL)."""
+        ctx = ctx or self.ctx
         seed = bytes(seed).ljust(32, b"\x00")[:32]
         cap = 1 << 20
         buf = ctypes.create_string_buffer(cap)
@@ -491,9 +494,10 @@ class BfvProvingKey:
         ninst = ctypes.c_size_t(1 << 16)
         ibuf = ctypes.create_string_buffer(32 * ninst.value)
         tm = (ctypes.c_float * 5)()
-        self.ctx._check(self.ctx.lib.zkfhe_bfv_prove(self.ctx.h, self.srs.h, self.h, input_json_text.encode(), seed, buf, cap, ctypes.byref(plen),
-                                                     ibuf, ctypes.byref(ninst), tm))
-        inst = [int.from_bytes(ibuf.raw[32 * i:32 * i + 32], "little") for i in range(ninst.value)]
+        ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, input_json_text.encode(), seed, buf, cap, ctypes.byref(plen),
+                                           ibuf, ctypes.byref(ninst), tm))
+        raw = ibuf.raw[: 32 * ninst.value]
+        inst = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(ninst.value)]
         return buf.raw[: plen.value], inst, list(tm)
 
     def destroy(self):

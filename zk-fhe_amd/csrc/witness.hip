@@ -71,9 +71,11 @@ int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint
   int log_m = 1;
   while (((size_t)1 << log_m) < 2 * n) ++log_m;
   const size_t m = (size_t)1 << log_m;
-  // own buffer (not a scratch slot: zkfhe_ntt_batch / zkfhe_fr_* use those)
-  Fr *buf = nullptr;
-  ZK_HIP(ctx, hipMalloc((void **)&buf, 2 * m * sizeof(Fr)));
+  // scratch slot 2: zkfhe_ntt_batch / zkfhe_fr_* (called below) use slots 0, 1 and 3 only
+  void *sp;
+  int src = zk_scratch(ctx, 2, 2 * m * sizeof(Fr), &sp);
+  if (src) return src;
+  Fr *buf = (Fr *)sp;
   unsigned grid = zk_blocks(m, 256);
   k_u64_to_fr_padded<<<grid, 256, 0, ctx->stream>>>(a_dev, n, buf, m);
   k_u64_to_fr_padded<<<grid, 256, 0, ctx->stream>>>(b_dev, n, buf + m, m);
@@ -86,8 +88,6 @@ int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint
     e = hipMemcpyAsync(out_dev, buf, (2 * n - 1) * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) rc = zk_fail(ctx, ZKFHE_EHIP, "hipMemcpyAsync", e, __FILE__, __LINE__);
   }
-  hipStreamSynchronize(ctx->stream);
-  hipFree(buf);
   return rc;
 }
 

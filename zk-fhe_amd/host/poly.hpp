@@ -31,7 +31,7 @@ struct PolyMulBackend {
   virtual std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) = 0;
 };
 inline PolyMulBackend *&poly_mul_backend() {
-  static PolyMulBackend *p = nullptr;
+  static thread_local PolyMulBackend *p = nullptr;
   return p;
 }
 

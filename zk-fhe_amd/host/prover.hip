@@ -9,6 +9,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 
 #include "../../include/zkfhe.h"
@@ -39,6 +41,32 @@ struct zkfhe_srs {
   zkfhe_basis *g = nullptr, *g_lagrange = nullptr;
 };
 
+struct DevBuf {
+  zkfhe_ctx *ctx = nullptr;
+  void *p = nullptr;
+  size_t bytes = 0;
+  int alloc(zkfhe_ctx *c, size_t b) {
+    ctx = c;
+    bytes = b;
+    return zkfhe_dev_alloc(c, b, &p);
+  }
+  void release() {
+    if (p) zkfhe_dev_free(ctx, p);
+    p = nullptr;
+  }
+  Fr *fr() const { return (Fr *)p; }
+};
+
+
+struct Workspace {
+  DevBuf adv_l, la_l, ls_l, lz_l, pz_l, inst_l, tmp_c, adv_ext, pz_ext, lz_ext, la_ext, ls_ext, inst_ext, partials, h_ext, h_c, misc, points;
+  DevBuf num, den, small, jobs, evout, polyio;
+  std::vector<DevBuf *> all() {
+    return {&adv_l, &la_l, &ls_l, &lz_l, &pz_l, &inst_l, &tmp_c, &adv_ext, &pz_ext, &lz_ext, &la_ext, &ls_ext, &inst_ext, &partials,
+            &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio};
+  }
+};
+
 namespace {
 
 double now_ms() {
@@ -67,22 +95,6 @@ AffinePoint point_canon(const G1Affine &p) {
   return a;
 }
 
-struct DevBuf {
-  zkfhe_ctx *ctx = nullptr;
-  void *p = nullptr;
-  size_t bytes = 0;
-  int alloc(zkfhe_ctx *c, size_t b) {
-    ctx = c;
-    bytes = b;
-    return zkfhe_dev_alloc(c, b, &p);
-  }
-  void release() {
-    if (p) zkfhe_dev_free(ctx, p);
-    p = nullptr;
-  }
-  Fr *fr() const { return (Fr *)p; }
-};
-
 unsigned grid_for(zkfhe_ctx *ctx, size_t work) {
   size_t b = (work + 255) / 256;
   size_t cap = (size_t)ctx->num_cu * 16;
@@ -107,25 +119,9 @@ int commit_cols(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *cols, size_t
 
 struct GpuPolyMul : PolyMulBackend {
   zkfhe_ctx *ctx;
-  explicit GpuPolyMul(zkfhe_ctx *c) : ctx(c) {}
-  std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) override {
-    const size_t n = a.size();
-    DevBuf da, db, dout;
-    if (da.alloc(ctx, n * 8) || db.alloc(ctx, n * 8) || dout.alloc(ctx, (2 * n - 1) * 32)) throw std::runtime_error("device allocation failed");
-    std::vector<U256> host(2 * n - 1);
-    int rc = zkfhe_upload(ctx, da.p, a.data(), n * 8);
-    if (!rc) rc = zkfhe_upload(ctx, db.p, b.data(), n * 8);
-    if (!rc) rc = zkfhe_witness_poly_mul_u64(ctx, (const uint64_t *)da.p, (const uint64_t *)db.p, n, (zkfhe_fr *)dout.p);
-    if (!rc) rc = zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)dout.p, (zkfhe_fr *)dout.p, 2 * n - 1);
-    if (!rc) rc = zkfhe_download(ctx, host.data(), dout.p, (2 * n - 1) * 32);
-    da.release();
-    db.release();
-    dout.release();
-    if (rc) throw std::runtime_error(std::string("GPU poly mul failed: ") + zkfhe_last_error(ctx));
-    std::vector<BigInt> out(2 * n - 1);
-    for (size_t i = 0; i < out.size(); ++i) out[i] = fe::to_bigint(host[i]);
-    return out;
-  }
+  Workspace *ws;
+  GpuPolyMul(zkfhe_ctx *c, Workspace *w) : ctx(c), ws(w) {}
+  std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) override;
 };
 
 }  // namespace
@@ -137,10 +133,10 @@ struct zkfhe_bfv_pk {
   DevBuf fixed_l, sigma_l, fixed_ext, sigma_ext, l_ext, xs_ext, dpow;
   std::vector<AffinePoint> fixed_commit, sigma_commit;
   U256 vk_digest;
-  // per-proof workspace (one proof at a time per pk)
-  DevBuf adv_l, la_l, ls_l, lz_l, pz_l, inst_l, tmp_c, adv_ext, pz_ext, lz_ext, la_ext, ls_ext, inst_ext, partials, h_ext, h_c, misc, points;
-  DevBuf num, den, small;
-  bool ws_ready = false;
+  // per-context prover workspaces: one proof at a time per zkfhe_ctx, any number of contexts (streams)
+  // may prove concurrently against the same key (everything above is read-only after keygen)
+  std::map<zkfhe_ctx *, Workspace *> workspaces;
+  std::mutex mu;
 };
 
 extern "C" {
@@ -200,42 +196,78 @@ int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {
 
 namespace {
 
-int alloc_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
-  const CircuitConfig &c = pk->cfg;
+std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) {
+  const size_t n = a.size();
+  if (ws->polyio.bytes < 2 * n * 8 + 2 * n * 32) throw std::runtime_error("polynomial too long for the prover workspace");
+  uint64_t *da = (uint64_t *)ws->polyio.p, *db = da + n;
+  Fr *dout = (Fr *)(db + n);
+  std::vector<U256> host(2 * n - 1);
+  int rc = zkfhe_upload(ctx, da, a.data(), n * 8);
+  if (!rc) rc = zkfhe_upload(ctx, db, b.data(), n * 8);
+  if (!rc) rc = zkfhe_witness_poly_mul_u64(ctx, da, db, n, (zkfhe_fr *)dout);
+  if (!rc) rc = zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)dout, (zkfhe_fr *)dout, 2 * n - 1);
+  if (!rc) rc = zkfhe_download(ctx, host.data(), dout, (2 * n - 1) * 32);
+  if (rc) throw std::runtime_error(std::string("GPU poly mul failed: ") + zkfhe_last_error(ctx));
+  std::vector<BigInt> out(2 * n - 1);
+  for (size_t i = 0; i < out.size(); ++i) out[i] = fe::to_bigint(host[i]);
+  return out;
+}
+
+int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
   const size_t n = c.n(), ne = 4 * n, col = n * 32, ecol = ne * 32;
-  CK(pk->adv_l.alloc(ctx, c.n_advice() * col));
-  CK(pk->la_l.alloc(ctx, c.n_lookup * col + 32));
-  CK(pk->ls_l.alloc(ctx, c.n_lookup * col + 32));
-  CK(pk->lz_l.alloc(ctx, c.n_lookup * col + 32));
-  CK(pk->pz_l.alloc(ctx, c.n_chunks() * col));
-  CK(pk->inst_l.alloc(ctx, col));
-  CK(pk->tmp_c.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * col));
-  CK(pk->adv_ext.alloc(ctx, c.n_advice() * ecol));
-  CK(pk->pz_ext.alloc(ctx, c.n_chunks() * ecol));
-  CK(pk->lz_ext.alloc(ctx, c.n_lookup * ecol + 32));
-  CK(pk->la_ext.alloc(ctx, c.n_lookup * ecol + 32));
-  CK(pk->ls_ext.alloc(ctx, c.n_lookup * ecol + 32));
-  CK(pk->inst_ext.alloc(ctx, ecol));
-  CK(pk->partials.alloc(ctx, 96 * ecol));
-  CK(pk->h_ext.alloc(ctx, ecol));
-  CK(pk->h_c.alloc(ctx, ecol));
-  CK(pk->misc.alloc(ctx, 32 * col));
-  CK(pk->points.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * 64 + 64));
-  CK(pk->num.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
-  CK(pk->den.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
-  CK(pk->small.alloc(ctx, 1 << 20));
-  pk->ws_ready = true;
+  CK(ws->adv_l.alloc(ctx, c.n_advice() * col));
+  CK(ws->la_l.alloc(ctx, c.n_lookup * col + 32));
+  CK(ws->ls_l.alloc(ctx, c.n_lookup * col + 32));
+  CK(ws->lz_l.alloc(ctx, c.n_lookup * col + 32));
+  CK(ws->pz_l.alloc(ctx, c.n_chunks() * col));
+  CK(ws->inst_l.alloc(ctx, col));
+  CK(ws->tmp_c.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * col));
+  CK(ws->adv_ext.alloc(ctx, c.n_advice() * ecol));
+  CK(ws->pz_ext.alloc(ctx, c.n_chunks() * ecol));
+  CK(ws->lz_ext.alloc(ctx, c.n_lookup * ecol + 32));
+  CK(ws->la_ext.alloc(ctx, c.n_lookup * ecol + 32));
+  CK(ws->ls_ext.alloc(ctx, c.n_lookup * ecol + 32));
+  CK(ws->inst_ext.alloc(ctx, ecol));
+  CK(ws->partials.alloc(ctx, 96 * ecol));
+  CK(ws->h_ext.alloc(ctx, ecol));
+  CK(ws->h_c.alloc(ctx, ecol));
+  CK(ws->misc.alloc(ctx, 32 * col));
+  CK(ws->points.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * 64 + 64));
+  CK(ws->num.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
+  CK(ws->den.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
+  CK(ws->small.alloc(ctx, 1 << 20));
+  const size_t max_items = (size_t)c.n_advice() + c.n_fixed() + 2 + c.n_perm() + c.n_chunks() + 3 * c.n_lookup;
+  CK(ws->jobs.alloc(ctx, max_items * sizeof(zkp::EvalJob) + max_items * (sizeof(void *) + 32)));
+  CK(ws->evout.alloc(ctx, max_items * 4 * 32));
+  CK(ws->polyio.alloc(ctx, 4 * c.n() * 32));
+  return ZKFHE_OK;
+}
+
+int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
+  std::lock_guard<std::mutex> lock(pk->mu);
+  auto it = pk->workspaces.find(ctx);
+  if (it == pk->workspaces.end()) {
+    Workspace *ws = new Workspace();
+    int rc = alloc_workspace(ctx, pk->cfg, ws);
+    if (rc) {
+      for (DevBuf *b : ws->all()) b->release();
+      delete ws;
+      return rc;
+    }
+    it = pk->workspaces.emplace(ctx, ws).first;
+  }
+  *out = it->second;
   return ZKFHE_OK;
 }
 
 // coefficient form of `count` Lagrange columns (copy into tmp, iNTT), then coset-extend into ext
-int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, const Fr *lagr, size_t count, Fr *ext) {
+int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext) {
   if (!count) return ZKFHE_OK;
   const size_t n = pk->cfg.n();
   const Fr g = mont_u64(COSET_G);
-  ZK_HIP(ctx, hipMemcpyAsync(pk->tmp_c.p, lagr, count * n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-  CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)pk->tmp_c.p, count, (int)pk->cfg.k, 1));
-  return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)pk->tmp_c.p, (zkfhe_fr *)ext, count, (int)pk->cfg.k, 2, (const zkfhe_fr *)&g, 0);
+  ZK_HIP(ctx, hipMemcpyAsync(ws->tmp_c.p, lagr, count * n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)ws->tmp_c.p, count, (int)pk->cfg.k, 1));
+  return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->tmp_c.p, (zkfhe_fr *)ext, count, (int)pk->cfg.k, 2, (const zkfhe_fr *)&g, 0);
 }
 
 int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const BfvParams &prm, CircuitConfig cfg, bool replay,
@@ -313,24 +345,25 @@ int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, co
                                                                                  cells, (int)cfg.k);
   ZK_LAUNCH_CHECK(ctx);
   // ---- commitments
-  CK(alloc_workspace(ctx, pk));
-  CK(commit_cols(ctx, srs->g_lagrange, pk->fixed_l.fr(), cfg.n_fixed(), (G1Affine *)pk->points.p, pk->fixed_commit));
-  CK(commit_cols(ctx, srs->g_lagrange, pk->sigma_l.fr(), cfg.n_perm(), (G1Affine *)pk->points.p, pk->sigma_commit));
+  Workspace *ws;
+  CK(get_workspace(ctx, pk, &ws));
+  CK(commit_cols(ctx, srs->g_lagrange, pk->fixed_l.fr(), cfg.n_fixed(), (G1Affine *)ws->points.p, pk->fixed_commit));
+  CK(commit_cols(ctx, srs->g_lagrange, pk->sigma_l.fr(), cfg.n_perm(), (G1Affine *)ws->points.p, pk->sigma_commit));
   // ---- extended-domain evaluations kept resident
   CK(pk->fixed_ext.alloc(ctx, (size_t)cfg.n_fixed() * 4 * n * 32));
   CK(pk->sigma_ext.alloc(ctx, cells * 4 * 32));
   CK(pk->l_ext.alloc(ctx, 3 * 4 * n * 32));
   CK(pk->xs_ext.alloc(ctx, 4 * n * 32));
-  CK(extend_cols(ctx, pk, pk->fixed_l.fr(), cfg.n_fixed(), pk->fixed_ext.fr()));
-  CK(extend_cols(ctx, pk, pk->sigma_l.fr(), cfg.n_perm(), pk->sigma_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, pk->fixed_l.fr(), cfg.n_fixed(), pk->fixed_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, pk->sigma_l.fr(), cfg.n_perm(), pk->sigma_ext.fr()));
   {
     std::vector<U256> l(3 * n, fe::zero());
     const size_t u = cfg.u();
     l[0] = fe::one();
     l[n + u] = fe::one();
     for (size_t i = 0; i < u; ++i) l[2 * n + i] = fe::one();
-    CK(upload_canon(ctx, pk->misc.fr(), l.data(), 3 * n));
-    CK(extend_cols(ctx, pk, pk->misc.fr(), 3, pk->l_ext.fr()));
+    CK(upload_canon(ctx, ws->misc.fr(), l.data(), 3 * n));
+    CK(extend_cols(ctx, pk, ws, ws->misc.fr(), 3, pk->l_ext.fr()));
   }
   {
     const Fr wext = zk_fr_root_of_unity((int)cfg.k + 2);
@@ -410,7 +443,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Transcript tr;
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
-  GpuPolyMul gpu_mul(ctx);
+  Workspace *ws;
+  CK(get_workspace(ctx, pk, &ws));
+  GpuPolyMul gpu_mul(ctx, ws);
   struct BackendGuard {
     explicit BackendGuard(PolyMulBackend *b) { poly_mul_backend() = b; }
     ~BackendGuard() { poly_mul_backend() = nullptr; }
@@ -430,14 +465,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     for (unsigned c = c_lo; c < c_hi; ++c) {
       std::vector<U256> &col = as.t.advice[c];
       for (size_t r = u; r < n; ++r) col[r] = rng.next();
-      ZK_HIP(ctx, hipMemcpyAsync(pk->adv_l.fr() + (size_t)c * n, col.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+      ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c * n, col.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
     }
-    return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(pk->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(pk->adv_l.fr() + (size_t)c_lo * n),
+    return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
                             (size_t)(c_hi - c_lo) * n);
   };
   std::vector<AffinePoint> adv_commit(cfg.n_advice()), pts;
   CK(blind_and_upload(0, cfg.n_gate0));
-  CK(commit_cols(ctx, srs->g_lagrange, pk->adv_l.fr(), cfg.n_gate0, (G1Affine *)pk->points.p, pts));
+  CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = pts[c]);
   const U256 gamma_rlc = tr.squeeze();
   // ------------------------------------------------------------ phase 1 witness
@@ -450,7 +485,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     lookup_inputs[i].assign(as.t.advice[cfg.adv_lookup0() + i].begin(), as.t.advice[cfg.adv_lookup0() + i].begin() + u);
   const double t_wit = now_ms();
   CK(blind_and_upload(cfg.n_gate0, cfg.n_advice()));
-  CK(commit_cols(ctx, srs->g_lagrange, pk->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)pk->points.p, pts));
+  CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
   tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
   // ------------------------------------------------------------ lookups: permuted input / table
@@ -463,13 +498,13 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       std::copy(sp.begin(), sp.end(), colS.begin());
       for (size_t r = u; r < n; ++r) colA[r] = rng.next();
       for (size_t r = u; r < n; ++r) colS[r] = rng.next();
-      CK(zkfhe_upload(ctx, pk->la_l.fr() + (size_t)i * n, colA.data(), n * 32));
-      CK(zkfhe_upload(ctx, pk->ls_l.fr() + (size_t)i * n, colS.data(), n * 32));
+      CK(zkfhe_upload(ctx, ws->la_l.fr() + (size_t)i * n, colA.data(), n * 32));
+      CK(zkfhe_upload(ctx, ws->ls_l.fr() + (size_t)i * n, colS.data(), n * 32));
     }
-    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)pk->la_l.p, (zkfhe_fr *)pk->la_l.p, (size_t)cfg.n_lookup * n));
-    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)pk->ls_l.p, (zkfhe_fr *)pk->ls_l.p, (size_t)cfg.n_lookup * n));
-    CK(commit_cols(ctx, srs->g_lagrange, pk->la_l.fr(), cfg.n_lookup, (G1Affine *)pk->points.p, la_commit));
-    CK(commit_cols(ctx, srs->g_lagrange, pk->ls_l.fr(), cfg.n_lookup, (G1Affine *)pk->points.p, ls_commit));
+    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, (size_t)cfg.n_lookup * n));
+    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->ls_l.p, (zkfhe_fr *)ws->ls_l.p, (size_t)cfg.n_lookup * n));
+    CK(commit_cols(ctx, srs->g_lagrange, ws->la_l.fr(), cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));
+    CK(commit_cols(ctx, srs->g_lagrange, ws->ls_l.fr(), cfg.n_lookup, (G1Affine *)ws->points.p, ls_commit));
     for (unsigned i = 0; i < cfg.n_lookup; ++i) {
       tr.write_point(la_commit[i]);
       tr.write_point(ls_commit[i]);
@@ -481,17 +516,17 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   {
     std::vector<U256> inst_col(n, fe::zero());
     std::copy(instances.begin(), instances.end(), inst_col.begin());
-    CK(upload_canon(ctx, pk->inst_l.fr(), inst_col.data(), n));
+    CK(upload_canon(ctx, ws->inst_l.fr(), inst_col.data(), n));
   }
   U256 dcan;
   memcpy(dcan.l, DELTA_CANON, 32);
-  Fr *beta_delta_dev = (Fr *)pk->small.p;  // [n_perm]
+  Fr *beta_delta_dev = (Fr *)ws->small.p;  // [n_perm]
   zkp::k_powers<<<1, 256, 0, ctx->stream>>>(beta, mont(dcan), beta_delta_dev, cfg.n_perm());
   ZK_LAUNCH_CHECK(ctx);
   zkp::PermArgs pa;
-  pa.adv = pk->adv_l.fr();
+  pa.adv = ws->adv_l.fr();
   pa.constcol = pk->fixed_l.fr() + (size_t)cfg.fix_const() * n;
-  pa.inst = pk->inst_l.fr();
+  pa.inst = ws->inst_l.fr();
   pa.sigma = pk->sigma_l.fr();
   pa.wpow = dom->fwd;
   pa.beta_delta = beta_delta_dev;
@@ -503,12 +538,12 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   pa.n_chunks = cfg.n_chunks();
   pa.n = n;
   const size_t nch = cfg.n_chunks();
-  zkp::k_perm_num_den<<<grid_for(ctx, nch * n), 256, 0, ctx->stream>>>(pa, pk->num.fr(), pk->den.fr());
+  zkp::k_perm_num_den<<<grid_for(ctx, nch * n), 256, 0, ctx->stream>>>(pa, ws->num.fr(), ws->den.fr());
   ZK_LAUNCH_CHECK(ctx);
-  CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)pk->den.p, nch * n));
-  CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)pk->num.p, (const zkfhe_fr *)pk->den.p, (zkfhe_fr *)pk->num.p, nch * n));
-  Fr *totals_dev = (Fr *)pk->small.p + 4096;
-  zkp::k_prefix_product<<<(unsigned)nch, 1024, 0, ctx->stream>>>(pk->num.fr(), pk->pz_l.fr(), totals_dev, n, (unsigned)u);
+  CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)ws->den.p, nch * n));
+  CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)ws->num.p, (const zkfhe_fr *)ws->den.p, (zkfhe_fr *)ws->num.p, nch * n));
+  Fr *totals_dev = (Fr *)ws->small.p + 4096;
+  zkp::k_prefix_product<<<(unsigned)nch, 1024, 0, ctx->stream>>>(ws->num.fr(), ws->pz_l.fr(), totals_dev, n, (unsigned)u);
   ZK_LAUNCH_CHECK(ctx);
   {
     std::vector<Fr> totals(nch), carry(nch);
@@ -520,26 +555,26 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     }
     if (!(acc == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "permutation argument does not close: a copy constraint is violated");
     CK(zkfhe_upload(ctx, totals_dev, carry.data(), nch * 32));
-    zkp::k_scale_rows<<<grid_for(ctx, nch * (u + 1)), 256, 0, ctx->stream>>>(pk->pz_l.fr(), totals_dev, n, (unsigned)(u + 1), (unsigned)nch);
+    zkp::k_scale_rows<<<grid_for(ctx, nch * (u + 1)), 256, 0, ctx->stream>>>(ws->pz_l.fr(), totals_dev, n, (unsigned)(u + 1), (unsigned)nch);
     ZK_LAUNCH_CHECK(ctx);
     // blinding rows u+1 .. n-1 (drawn per chunk, in order)
     const size_t nb = n - u - 1;
     std::vector<U256> blind(nch * nb);
     for (auto &b : blind) b = rng.next();
-    Fr *bdev = pk->misc.fr();
+    Fr *bdev = ws->misc.fr();
     CK(upload_canon(ctx, bdev, blind.data(), blind.size()));
-    ZK_HIP(ctx, hipMemcpy2DAsync(pk->pz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nch, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpy2DAsync(ws->pz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nch, hipMemcpyDeviceToDevice, ctx->stream));
   }
   // ------------------------------------------------------------ lookup grand products
   if (cfg.n_lookup) {
     const size_t nl = cfg.n_lookup;
-    zkp::k_lookup_num_den<<<grid_for(ctx, nl * n), 256, 0, ctx->stream>>>(pk->adv_l.fr() + (size_t)cfg.adv_lookup0() * n,
-                                                                          pk->fixed_l.fr() + (size_t)cfg.fix_table() * n, pk->la_l.fr(), pk->ls_l.fr(),
-                                                                          beta, gamma, (unsigned)nl, n, pk->num.fr(), pk->den.fr());
+    zkp::k_lookup_num_den<<<grid_for(ctx, nl * n), 256, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n,
+                                                                          pk->fixed_l.fr() + (size_t)cfg.fix_table() * n, ws->la_l.fr(), ws->ls_l.fr(),
+                                                                          beta, gamma, (unsigned)nl, n, ws->num.fr(), ws->den.fr());
     ZK_LAUNCH_CHECK(ctx);
-    CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)pk->den.p, nl * n));
-    CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)pk->num.p, (const zkfhe_fr *)pk->den.p, (zkfhe_fr *)pk->num.p, nl * n));
-    zkp::k_prefix_product<<<(unsigned)nl, 1024, 0, ctx->stream>>>(pk->num.fr(), pk->lz_l.fr(), totals_dev, n, (unsigned)u);
+    CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)ws->den.p, nl * n));
+    CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)ws->num.p, (const zkfhe_fr *)ws->den.p, (zkfhe_fr *)ws->num.p, nl * n));
+    zkp::k_prefix_product<<<(unsigned)nl, 1024, 0, ctx->stream>>>(ws->num.fr(), ws->lz_l.fr(), totals_dev, n, (unsigned)u);
     ZK_LAUNCH_CHECK(ctx);
     std::vector<Fr> totals(nl);
     CK(zkfhe_download(ctx, totals.data(), totals_dev, nl * 32));
@@ -548,36 +583,36 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     const size_t nb = n - u - 1;
     std::vector<U256> blind(nl * nb);
     for (auto &b : blind) b = rng.next();
-    Fr *bdev = pk->misc.fr();
+    Fr *bdev = ws->misc.fr();
     CK(upload_canon(ctx, bdev, blind.data(), blind.size()));
-    ZK_HIP(ctx, hipMemcpy2DAsync(pk->lz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nl, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpy2DAsync(ws->lz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nl, hipMemcpyDeviceToDevice, ctx->stream));
   }
   std::vector<AffinePoint> pz_commit, lz_commit;
-  CK(commit_cols(ctx, srs->g_lagrange, pk->pz_l.fr(), nch, (G1Affine *)pk->points.p, pz_commit));
+  CK(commit_cols(ctx, srs->g_lagrange, ws->pz_l.fr(), nch, (G1Affine *)ws->points.p, pz_commit));
   for (const auto &p : pz_commit) tr.write_point(p);
   if (cfg.n_lookup) {
-    CK(commit_cols(ctx, srs->g_lagrange, pk->lz_l.fr(), cfg.n_lookup, (G1Affine *)pk->points.p, lz_commit));
+    CK(commit_cols(ctx, srs->g_lagrange, ws->lz_l.fr(), cfg.n_lookup, (G1Affine *)ws->points.p, lz_commit));
     for (const auto &p : lz_commit) tr.write_point(p);
   }
   // ------------------------------------------------------------ vanishing: random polynomial (coefficient form)
-  Fr *rand_c = pk->misc.fr() + 8 * n, *rand_l = pk->misc.fr() + 9 * n, *H_c = pk->misc.fr() + 10 * n, *H_l = pk->misc.fr() + 11 * n;
+  Fr *rand_c = ws->misc.fr() + 8 * n, *rand_l = ws->misc.fr() + 9 * n, *H_c = ws->misc.fr() + 10 * n, *H_l = ws->misc.fr() + 11 * n;
   {
     std::vector<U256> rc(n);
     for (auto &v : rc) v = rng.next();
     CK(upload_canon(ctx, rand_c, rc.data(), n));
   }
   std::vector<AffinePoint> rand_commit;
-  CK(commit_cols(ctx, srs->g, rand_c, 1, (G1Affine *)pk->points.p, rand_commit));
+  CK(commit_cols(ctx, srs->g, rand_c, 1, (G1Affine *)ws->points.p, rand_commit));
   tr.write_point(rand_commit[0]);
   const Fr y = mont(tr.squeeze());
   const double t_commit = now_ms();
   // ------------------------------------------------------------ quotient
-  CK(extend_cols(ctx, pk, pk->adv_l.fr(), cfg.n_advice(), pk->adv_ext.fr()));
-  CK(extend_cols(ctx, pk, pk->pz_l.fr(), nch, pk->pz_ext.fr()));
-  CK(extend_cols(ctx, pk, pk->lz_l.fr(), cfg.n_lookup, pk->lz_ext.fr()));
-  CK(extend_cols(ctx, pk, pk->la_l.fr(), cfg.n_lookup, pk->la_ext.fr()));
-  CK(extend_cols(ctx, pk, pk->ls_l.fr(), cfg.n_lookup, pk->ls_ext.fr()));
-  CK(extend_cols(ctx, pk, pk->inst_l.fr(), 1, pk->inst_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->adv_l.fr(), cfg.n_advice(), ws->adv_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->pz_l.fr(), nch, ws->pz_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->lz_l.fr(), cfg.n_lookup, ws->lz_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->la_l.fr(), cfg.n_lookup, ws->la_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->ls_l.fr(), cfg.n_lookup, ws->ls_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->inst_l.fr(), 1, ws->inst_ext.fr()));
   {
     // expression groups, in the folding order of oracle/halo2_ref.py expressions_at
     std::vector<zkp::QGroup> groups;
@@ -598,9 +633,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     if (G > 96) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
     std::vector<Fr> ypow(G);
     for (size_t g = 0; g < G; ++g) ypow[g] = fr_pow(y, E - 1 - last_e[g]);
-    zkp::QGroup *groups_dev = (zkp::QGroup *)((char *)pk->small.p + 256 * 1024);
-    Fr *ypow_dev = (Fr *)((char *)pk->small.p + 384 * 1024);
-    Fr *zinv_dev = (Fr *)((char *)pk->small.p + 512 * 1024);
+    zkp::QGroup *groups_dev = (zkp::QGroup *)((char *)ws->small.p + 256 * 1024);
+    Fr *ypow_dev = (Fr *)((char *)ws->small.p + 384 * 1024);
+    Fr *zinv_dev = (Fr *)((char *)ws->small.p + 512 * 1024);
     CK(zkfhe_upload(ctx, groups_dev, groups.data(), G * sizeof(zkp::QGroup)));
     CK(zkfhe_upload(ctx, ypow_dev, ypow.data(), G * 32));
     const Fr wext = zk_fr_root_of_unity((int)k + 2);
@@ -612,19 +647,19 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     }
     CK(zkfhe_upload(ctx, zinv_dev, zinv, 4 * 32));
     zkp::QArgs qa;
-    qa.adv = pk->adv_ext.fr();
+    qa.adv = ws->adv_ext.fr();
     qa.fix = pk->fixed_ext.fr();
     qa.sig = pk->sigma_ext.fr();
-    qa.pz = pk->pz_ext.fr();
-    qa.lz = pk->lz_ext.fr();
-    qa.la = pk->la_ext.fr();
-    qa.ls = pk->ls_ext.fr();
-    qa.inst = pk->inst_ext.fr();
+    qa.pz = ws->pz_ext.fr();
+    qa.lz = ws->lz_ext.fr();
+    qa.la = ws->la_ext.fr();
+    qa.ls = ws->ls_ext.fr();
+    qa.inst = ws->inst_ext.fr();
     qa.lext = pk->l_ext.fr();
     qa.xs = pk->xs_ext.fr();
     qa.beta_delta = beta_delta_dev;
     qa.groups = groups_dev;
-    qa.partials = pk->partials.fr();
+    qa.partials = ws->partials.fr();
     qa.y = y;
     qa.beta = beta;
     qa.gamma = gamma;
@@ -645,17 +680,17 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     dim3 grid((unsigned)((ne + 255) / 256), (unsigned)G);
     zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
     ZK_LAUNCH_CHECK(ctx);
-    zkp::k_quotient_combine<<<(unsigned)((ne + 255) / 256), 256, 0, ctx->stream>>>(pk->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, pk->h_ext.fr());
+    zkp::k_quotient_combine<<<(unsigned)((ne + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, ws->h_ext.fr());
     ZK_LAUNCH_CHECK(ctx);
     const Fr g = mont_u64(COSET_G);
-    CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)pk->h_ext.p, (zkfhe_fr *)pk->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));
+    CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)ws->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));
   }
   std::vector<AffinePoint> h_commit;
-  CK(commit_cols(ctx, srs->g, pk->h_c.fr(), 3, (G1Affine *)pk->points.p, h_commit));
+  CK(commit_cols(ctx, srs->g, ws->h_c.fr(), 3, (G1Affine *)ws->points.p, h_commit));
   {
     // the quotient must have degree < 3n: a non-zero top quarter means a violated constraint
     std::vector<U256> top(8);
-    CK(zkfhe_download(ctx, top.data(), pk->h_c.fr() + 3 * n, 8 * 32));
+    CK(zkfhe_download(ctx, top.data(), ws->h_c.fr() + 3 * n, 8 * 32));
     for (const auto &v : top)
       if (!v.is_zero()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "quotient degree too high: a constraint is violated");
   }
@@ -668,9 +703,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   {
     // H(X) = h0 + x^n h1 + x^2n h2, and the random polynomial, in Lagrange form
     const Fr sc[3] = {Fr::one(), xn, xn * xn};
-    const Fr *ptrs[3] = {pk->h_c.fr(), pk->h_c.fr() + n, pk->h_c.fr() + 2 * n};
-    const Fr **ptrs_dev = (const Fr **)((char *)pk->small.p + 640 * 1024);
-    Fr *sc_dev = (Fr *)((char *)pk->small.p + 648 * 1024);
+    const Fr *ptrs[3] = {ws->h_c.fr(), ws->h_c.fr() + n, ws->h_c.fr() + 2 * n};
+    const Fr **ptrs_dev = (const Fr **)((char *)ws->small.p + 640 * 1024);
+    Fr *sc_dev = (Fr *)((char *)ws->small.p + 648 * 1024);
     CK(zkfhe_upload(ctx, ptrs_dev, ptrs, sizeof(ptrs)));
     CK(zkfhe_upload(ctx, sc_dev, sc, sizeof(sc)));
     zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
@@ -691,9 +726,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     pts_rot[4] = x * fr_pow(w, u);
     pts_rot[5] = x * dom->omega_inv;
   }
-  Fr *bw = pk->misc.fr();  // [6][n] barycentric weights
+  Fr *bw = ws->misc.fr();  // [6][n] barycentric weights
   {
-    Fr *pts_dev = (Fr *)((char *)pk->small.p + 656 * 1024);
+    Fr *pts_dev = (Fr *)((char *)ws->small.p + 656 * 1024);
     CK(zkfhe_upload(ctx, pts_dev, pts_rot, sizeof(pts_rot)));
     zkp::k_bary_den<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, pts_dev, 6, n, bw);
     ZK_LAUNCH_CHECK(ctx);
@@ -711,7 +746,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     items.push_back(it);
   };
   for (unsigned c = 0; c < cfg.n_advice(); ++c) {
-    const Fr *p = pk->adv_l.fr() + (size_t)c * n;
+    const Fr *p = ws->adv_l.fr() + (size_t)c * n;
     if (c < cfg.n_gate()) add_item(p, {0, 1, 2, 3});
     else if (c < cfg.adv_rlc0()) add_item(p, {0});
     else add_item(p, {0, 1, 2});
@@ -722,13 +757,13 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   add_item(rand_l, {0});
   for (unsigned c = 0; c < cfg.n_perm(); ++c) add_item(pk->sigma_l.fr() + (size_t)c * n, {0});
   for (unsigned j = 0; j < nch; ++j) {
-    if (j + 1 != nch) add_item(pk->pz_l.fr() + (size_t)j * n, {0, 1, 4});
-    else add_item(pk->pz_l.fr() + (size_t)j * n, {0, 1});
+    if (j + 1 != nch) add_item(ws->pz_l.fr() + (size_t)j * n, {0, 1, 4});
+    else add_item(ws->pz_l.fr() + (size_t)j * n, {0, 1});
   }
   for (unsigned i = 0; i < cfg.n_lookup; ++i) {
-    add_item(pk->lz_l.fr() + (size_t)i * n, {0, 1});
-    add_item(pk->la_l.fr() + (size_t)i * n, {0, 5});
-    add_item(pk->ls_l.fr() + (size_t)i * n, {0});
+    add_item(ws->lz_l.fr() + (size_t)i * n, {0, 1});
+    add_item(ws->la_l.fr() + (size_t)i * n, {0, 5});
+    add_item(ws->ls_l.fr() + (size_t)i * n, {0});
   }
   {
     std::vector<zkp::EvalJob> jobs(items.size());
@@ -737,9 +772,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       jobs[i].n_rot = items[i].n_rot;
       for (int r = 0; r < 4; ++r) jobs[i].rot[r] = r < items[i].n_rot ? items[i].rot[r] : 0;
     }
-    DevBuf jd, od;
-    CK(jd.alloc(ctx, jobs.size() * sizeof(zkp::EvalJob)));
-    CK(od.alloc(ctx, jobs.size() * 4 * 32));
+    DevBuf &jd = ws->jobs, &od = ws->evout;
     CK(zkfhe_upload(ctx, jd.p, jobs.data(), jobs.size() * sizeof(zkp::EvalJob)));
     zkp::k_eval_jobs<<<(unsigned)jobs.size(), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, od.fr());
     ZK_LAUNCH_CHECK(ctx);
@@ -748,8 +781,6 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(zkfhe_download(ctx, ev.data(), od.p, ev.size() * 32));
     for (size_t i = 0; i < items.size(); ++i)
       for (int r = 0; r < items[i].n_rot; ++r) items[i].ev[r] = ev[i * 4 + r];
-    jd.release();
-    od.release();
   }
   for (size_t i = 0; i < items.size(); ++i) {
     if (i == idx_H) continue;  // implied by the identity, not written
@@ -775,15 +806,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   for (const auto &s : sets)
     for (int r : s.rots)
       if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
-  Fr *F = pk->misc.fr() + 12 * n;  // [ns][n]
+  Fr *F = ws->misc.fr() + 12 * n;  // [ns][n]
   if (ns > 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many rotation sets");
   std::vector<zkp::ShSet> shsets(ns);
   {
     size_t max_m = 0;
     for (const auto &s : sets) max_m = std::max(max_m, s.members.size());
-    DevBuf pd, sd;
-    CK(pd.alloc(ctx, max_m * sizeof(void *)));
-    CK(sd.alloc(ctx, max_m * 32));
+    struct { void *p; } pd, sd;  // pointer and scalar tables live behind the eval-job table
+    pd.p = (char *)ws->jobs.p + items.size() * sizeof(zkp::EvalJob);
+    sd.p = (char *)pd.p + ((max_m * sizeof(void *) + 31) / 32) * 32;
     for (size_t j = 0; j < ns; ++j) {
       const auto &mem = sets[j].members;
       std::vector<const Fr *> ptrs(mem.size());
@@ -824,8 +855,6 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         for (size_t q = 0; q < num.size(); ++q) S.rc[q] = S.rc[q] + num[q] * scl;
       }
     }
-    pd.release();
-    sd.release();
   }
   const Fr v = mont(tr.squeeze());
   {
@@ -837,11 +866,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       cur = cur * v;
     }
   }
-  zkp::ShSet *sets_dev = (zkp::ShSet *)((char *)pk->small.p + 700 * 1024);
-  Fr *zs = pk->misc.fr() + 20 * n;   // [ns][n]
-  Fr *hq = pk->misc.fr() + 28 * n;   // [n]
-  Fr *Wq = pk->misc.fr() + 29 * n;   // [n]
-  Fr *dinv = pk->misc.fr() + 30 * n; // [n]
+  zkp::ShSet *sets_dev = (zkp::ShSet *)((char *)ws->small.p + 700 * 1024);
+  Fr *zs = ws->misc.fr() + 20 * n;   // [ns][n]
+  Fr *hq = ws->misc.fr() + 28 * n;   // [n]
+  Fr *Wq = ws->misc.fr() + 29 * n;   // [n]
+  Fr *dinv = ws->misc.fr() + 30 * n; // [n]
   CK(zkfhe_upload(ctx, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
   zkp::k_sh_zs<<<grid_for(ctx, ns * n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, dom->fwd, n, zs);
   ZK_LAUNCH_CHECK(ctx);
@@ -849,7 +878,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   zkp::k_sh_h<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, zs, dom->fwd, n, hq);
   ZK_LAUNCH_CHECK(ctx);
   std::vector<AffinePoint> hq_commit, w_commit;
-  CK(commit_cols(ctx, srs->g_lagrange, hq, 1, (G1Affine *)pk->points.p, hq_commit));
+  CK(commit_cols(ctx, srs->g_lagrange, hq, 1, (G1Affine *)ws->points.p, hq_commit));
   tr.write_point(hq_commit[0]);
   const Fr uu = mont(tr.squeeze());
   {
@@ -873,7 +902,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     zkp::k_sh_w<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, hq, ztu, dinv, n, Wq);
     ZK_LAUNCH_CHECK(ctx);
   }
-  CK(commit_cols(ctx, srs->g_lagrange, Wq, 1, (G1Affine *)pk->points.p, w_commit));
+  CK(commit_cols(ctx, srs->g_lagrange, Wq, 1, (G1Affine *)ws->points.p, w_commit));
   tr.write_point(w_commit[0]);
   proof = tr.out;
   const double t_end = now_ms();
@@ -904,10 +933,12 @@ int zkfhe_bfv_keygen(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_jso
 int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
   if (!pk) return ZKFHE_OK;
   zkfhe_sync(ctx);
-  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow, &pk->adv_l, &pk->la_l,
-                    &pk->ls_l, &pk->lz_l, &pk->pz_l, &pk->inst_l, &pk->tmp_c, &pk->adv_ext, &pk->pz_ext, &pk->lz_ext, &pk->la_ext, &pk->ls_ext,
-                    &pk->inst_ext, &pk->partials, &pk->h_ext, &pk->h_c, &pk->misc, &pk->points, &pk->num, &pk->den, &pk->small};
+  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow};
   for (DevBuf *b : bufs) b->release();
+  for (auto &kv : pk->workspaces) {
+    for (DevBuf *b : kv.second->all()) b->release();
+    delete kv.second;
+  }
   delete pk;
   return ZKFHE_OK;
 }
