@@ -86,13 +86,31 @@ def build(force=False, jobs=None, verbose=True):
     return LIB
 
 
+def build_cli(verbose=True):
+    """the `bfv` command-line driver (zk-fhe_amd/bfv), linked against libzkfhe_hip.so with an $ORIGIN rpath"""
+    build(verbose=verbose)
+    exe = os.path.join(HERE, "bfv")
+    src = os.path.join(HERE, "host", "bfv_main.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        cmd = ["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + HERE, "-lzkfhe_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("bfv CLI link failed:\n" + r.stdout[-4000:])
+        if verbose:
+            print("[zkfhe build] built", exe, flush=True)
+    return exe
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--cli", action="store_true", help="also build the bfv command-line driver")
     a = ap.parse_args()
     try:
         build(a.force, a.jobs)
+        if a.cli:
+            build_cli()
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

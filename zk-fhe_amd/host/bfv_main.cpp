@@ -1,0 +1,241 @@
+// `bfv` -- command-line driver with the reference's surface (README.md:18-52; clap `Cli` of halo2-scaffold,
+// examples/bfv.rs:306-312):   bfv --name bfv -k 13 --input bfv/bfv.in {mock|keygen|prove|verify}
+// Files: reads data/<input>, configs/<name>.json (prove); writes configs/<name>.json (keygen), data/<name>.snark (prove).
+// The proving key is rebuilt in memory by `prove` (on-disk pk/vk formats: SURVEY.md section 8f, next).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/zkfhe.h"
+
+static std::string slurp(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) {
+    fprintf(stderr, "cannot open %s\n", path.c_str());
+    exit(2);
+  }
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+// tiny reader for the pinning file: numbers after a key, and number arrays
+static std::vector<uint32_t> numbers_after(const std::string &text, const std::string &key, size_t from = 0, size_t *end = nullptr) {
+  std::vector<uint32_t> out;
+  size_t p = text.find("\"" + key + "\"", from);
+  if (p == std::string::npos) return out;
+  p = text.find(':', p);
+  size_t i = p + 1;
+  while (i < text.size() && isspace((unsigned char)text[i])) ++i;
+  bool arr = text[i] == '[';
+  int depth = 0;
+  for (; i < text.size(); ++i) {
+    char c = text[i];
+    if (c == '[') ++depth;
+    else if (c == ']') {
+      if (--depth == 0) { ++i; break; }
+    } else if (isdigit((unsigned char)c)) {
+      uint64_t v = 0;
+      while (i < text.size() && isdigit((unsigned char)text[i])) v = v * 10 + (text[i++] - '0');
+      out.push_back((uint32_t)v);
+      --i;
+      if (!arr) { ++i; break; }
+    } else if (!arr && (c == ',' || c == '}')) break;
+  }
+  if (end) *end = i;
+  return out;
+}
+
+struct Pinning {
+  zkfhe_bfv_config c{};
+  std::vector<uint32_t> bp0, bp1, bpr;
+};
+
+static bool load_pinning(const std::string &path, Pinning &p) {
+  std::ifstream f(path);
+  if (!f) return false;
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string t = ss.str();
+  p.c.k = numbers_after(t, "degree")[0];
+  p.c.n_rlc = numbers_after(t, "num_rlc_columns")[0];
+  auto ra = numbers_after(t, "num_range_advice"), la = numbers_after(t, "num_lookup_advice");
+  p.c.n_gate0 = ra[0];
+  p.c.n_gate1 = ra[1];
+  p.c.n_lookup = la[1];
+  p.c.unusable_rows = numbers_after(t, "unusable_rows")[0];
+  p.c.lookup_bits = numbers_after(t, "lookup_bits")[0];
+  // "gate": [[..],[..],[]], "rlc": [..]
+  size_t g = t.find("\"gate\"");
+  size_t a = t.find('[', g), b1 = t.find('[', a + 1), e1 = t.find(']', b1), b2 = t.find('[', e1), e2 = t.find(']', b2);
+  auto parse = [&](size_t lo, size_t hi) {
+    std::vector<uint32_t> v;
+    for (size_t i = lo; i < hi; ++i)
+      if (isdigit((unsigned char)t[i])) {
+        uint64_t x = 0;
+        while (i < hi && isdigit((unsigned char)t[i])) x = x * 10 + (t[i++] - '0');
+        v.push_back((uint32_t)x);
+      }
+    return v;
+  };
+  p.bp0 = parse(b1, e1);
+  p.bp1 = parse(b2, e2);
+  p.bpr = numbers_after(t, "rlc", e2);
+  p.c.bp_gate0 = p.bp0.data();
+  p.c.n_bp_gate0 = (uint32_t)p.bp0.size();
+  p.c.bp_gate1 = p.bp1.data();
+  p.c.n_bp_gate1 = (uint32_t)p.bp1.size();
+  p.c.bp_rlc = p.bpr.data();
+  p.c.n_bp_rlc = (uint32_t)p.bpr.size();
+  p.c.replay = 1;
+  return true;
+}
+
+static void write_pinning(const std::string &path, const zkfhe_bfv_config &c, const std::vector<uint32_t> bp[3]) {
+  std::ofstream f(path);
+  auto arr = [&](const std::vector<uint32_t> &v) {
+    std::string s = "[";
+    for (size_t i = 0; i < v.size(); ++i) s += (i ? "," : "") + std::to_string(v[i]);
+    return s + "]";
+  };
+  f << "{\n  \"params\": {\n    \"degree\": " << c.k << ",\n    \"num_rlc_columns\": " << c.n_rlc << ",\n    \"num_range_advice\": [" << c.n_gate0 << ","
+    << c.n_gate1 << ",0],\n    \"num_lookup_advice\": [0," << c.n_lookup << ",0],\n    \"num_fixed\": 1,\n    \"unusable_rows\": " << c.unusable_rows
+    << ",\n    \"keccak_rows_per_round\": 50,\n    \"lookup_bits\": " << c.lookup_bits << "\n  },\n  \"break_points\": {\n    \"gate\": [" << arr(bp[0])
+    << "," << arr(bp[1]) << ",[]],\n    \"rlc\": " << arr(bp[2]) << "\n  }\n}\n";
+}
+
+#define CHECK(x)                                                          \
+  do {                                                                    \
+    int rc_ = (x);                                                        \
+    if (rc_) {                                                            \
+      fprintf(stderr, "%s failed (%d): %s\n", #x, rc_, zkfhe_last_error(ctx)); \
+      return 1;                                                           \
+    }                                                                     \
+  } while (0)
+
+int main(int argc, char **argv) {
+  std::string name = "bfv", input, cmd, config_path = "configs", data_path = "data";
+  unsigned k = 13;
+  zkfhe_bfv_params prm = {1024, 536870909ULL, 7, 19};  // examples/bfv.rs:27-30
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
+    if (a == "--name" || a == "-n") name = next();
+    else if (a == "-k" || a == "--degree") k = (unsigned)atoi(next().c_str());
+    else if (a == "--input" || a == "-i") input = next();
+    else if (a == "--config-path" || a == "-c") config_path = next();
+    else if (a == "--data-path" || a == "-d") data_path = next();
+    else if (a == "--ring-degree") prm.n = strtoull(next().c_str(), nullptr, 10);
+    else if (a == "--modulus") prm.q = strtoull(next().c_str(), nullptr, 10);
+    else if (a == "mock" || a == "keygen" || a == "prove" || a == "verify") cmd = a;
+    else if (a == "--") continue;
+    else {
+      fprintf(stderr, "usage: bfv --name <n> -k <degree> --input <file under data/> {mock|keygen|prove|verify}\n");
+      return 2;
+    }
+  }
+  if (input.empty()) input = name + ".in";
+  if (cmd.empty()) {
+    fprintf(stderr, "missing command: mock | keygen | prove | verify\n");
+    return 2;
+  }
+  const std::string text = slurp(data_path + "/" + input);
+  const std::string pin_path = config_path + "/" + name + ".json";
+  Pinning pin;
+  const bool have_pin = load_pinning(pin_path, pin);
+  if (cmd == "mock") {
+    // MockProver: the circuit's asserts + gate / copy / lookup consistency of the witness table, on the host
+    if (!have_pin) {
+      fprintf(stderr, "mock needs %s (run keygen first)\n", pin_path.c_str());
+      return 1;
+    }
+    uint8_t gamma[32] = {7};
+    char err[512] = {0};
+    zkfhe_bfv_tables *t = nullptr;
+    zkfhe_bfv_config c = pin.c;
+    c.replay = 0;
+    int rc = zkfhe_bfv_build_tables(text.c_str(), &prm, &c, gamma, 1, &t, err, sizeof(err));
+    if (rc) {
+      fprintf(stderr, "circuit is not satisfied: %s\n", err);
+      return 1;
+    }
+    printf("Mock prover: witness table built (%zu advice columns x %zu rows, %zu copy constraints), all circuit assertions hold\n",
+           zkfhe_bfv_tables_count(t, 0), zkfhe_bfv_tables_count(t, 2), zkfhe_bfv_tables_count(t, 4));
+    zkfhe_bfv_tables_free(t);
+    return 0;
+  }
+  if (cmd == "verify") {
+    fprintf(stderr, "verify: the C++ verifier is not built yet (SURVEY.md 8f); use oracle/halo2_ref.py verify (pairing check)\n");
+    return 3;
+  }
+  zkfhe_ctx *ctx = nullptr;
+  if (zkfhe_ctx_create(0, nullptr, &ctx)) {
+    fprintf(stderr, "no gfx950 device: %s\n", zkfhe_last_error(nullptr));
+    return 1;
+  }
+  zkfhe_srs *srs = nullptr;
+  const char *seed = "zkfhe-unsafe-srs";
+  CHECK(zkfhe_srs_create(ctx, k, (const uint8_t *)seed, strlen(seed), &srs));
+  zkfhe_bfv_pk *pk = nullptr;
+  if (cmd == "keygen") {
+    zkfhe_bfv_config c{};
+    if (have_pin) c = pin.c;
+    else {
+      fprintf(stderr, "keygen: %s not found; column counts must be given by a pinning file (auto-configuration: SURVEY.md 8f)\n", pin_path.c_str());
+      return 1;
+    }
+    c.replay = 0;
+    c.k = k;
+    CHECK(zkfhe_bfv_keygen(ctx, srs, text.c_str(), &prm, &c, &pk));
+    std::vector<uint32_t> bp[3];
+    for (int w = 0; w < 3; ++w) {
+      uint32_t cnt = 0;
+      zkfhe_bfv_pk_break_points(pk, w, nullptr, &cnt);
+      bp[w].resize(cnt);
+      zkfhe_bfv_pk_break_points(pk, w, bp[w].data(), &cnt);
+    }
+    write_pinning(pin_path, c, bp);
+    uint8_t d[32];
+    zkfhe_bfv_pk_info(pk, d, nullptr, nullptr);
+    printf("keygen done; pinning written to %s; vk digest ", pin_path.c_str());
+    for (int i = 31; i >= 0; --i) printf("%02x", d[i]);
+    printf("\n");
+  } else {
+    if (!have_pin) {
+      fprintf(stderr, "prove needs %s (run keygen first)\n", pin_path.c_str());
+      return 1;
+    }
+    // structure comes from an all-zero input of the same shape (the reference's bfv_empty.in, README.md:31)
+    std::string empty = text;
+    for (size_t i = 0; i + 1 < empty.size(); ++i)
+      if (empty[i] == '"' && isdigit((unsigned char)empty[i + 1])) {
+        size_t j = empty.find('"', i + 1);
+        empty.replace(i + 1, j - i - 1, "0");
+      }
+    CHECK(zkfhe_bfv_keygen(ctx, srs, empty.c_str(), &prm, &pin.c, &pk));
+    std::vector<uint8_t> proof(1 << 20);
+    size_t len = 0, ninst = 0;
+    uint8_t seed32[32] = {0};
+    FILE *ur = fopen("/dev/urandom", "rb");
+    if (ur) {
+      if (fread(seed32, 1, 32, ur) != 32) memset(seed32, 1, 32);
+      fclose(ur);
+    }
+    float tm[5];
+    auto t0 = std::chrono::steady_clock::now();
+    CHECK(zkfhe_bfv_prove(ctx, srs, pk, text.c_str(), seed32, proof.data(), proof.size(), &len, nullptr, &ninst, tm));
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::ofstream(data_path + "/" + name + ".snark", std::ios::binary).write((const char *)proof.data(), (std::streamsize)len);
+    printf("Proving time: %.3fms  (witness %.1f, commit %.1f, quotient %.1f, open %.1f)\n", ms, tm[0], tm[1], tm[2], tm[3]);
+    printf("proof: %zu bytes, %zu public inputs -> %s/%s.snark\n", len, ninst, data_path.c_str(), name.c_str());
+  }
+  zkfhe_bfv_pk_destroy(ctx, pk);
+  zkfhe_srs_destroy(ctx, srs);
+  zkfhe_ctx_destroy(ctx);
+  return 0;
+}
