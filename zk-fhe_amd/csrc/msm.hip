@@ -14,9 +14,9 @@
 //     point negated), so the "negative small" witness values (r - x) cost as little as small ones,
 //     and zero digits are skipped.
 //   * entries (bucket, table index, sign) are counting-sorted per MSM (global-atomic histogram,
-//     exclusive scan, scatter); one thread then sums one bucket with XYZZ mixed additions.  Buckets
-//     longer than HEAVY_T entries (skewed witness columns: thousands of 0/1 cells) are summed by a
-//     whole workgroup each.
+//     exclusive scan, scatter).  Every bucket is cut into tasks of <= 32 entries; one thread sums one task
+//     with XYZZ mixed additions, so the dependent chain is bounded however skewed a column is (witness
+//     columns hold thousands of 0/1 cells); a bucket's partials are merged by a thread (<= 8) or a wave.
 //   * bucket reduction sum_b b*B_b: 256 threads per MSM, running sums over groups of buckets, then a
 //     weighted tree in LDS; the result is normalised to affine in the same kernel.
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
@@ -28,7 +28,6 @@ using namespace zk;
 
 namespace {
 
-constexpr int HEAVY_T = 192;       // bucket length above which a workgroup sums the bucket
 constexpr int RED_THREADS = 256;   // threads of the bucket-reduction kernel
 
 // (r-1)/2 as canonical limbs: scalars above it are negated
@@ -133,25 +132,80 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scal
   }
 }
 
-// one thread per (column, bucket): XYZZ accumulation of the bucket's entries
-__global__ void __launch_bounds__(256) k_msm_accumulate(const unsigned *__restrict__ off, const unsigned *__restrict__ entries,
-                                                        size_t col_entries, const G1Affine *__restrict__ table, unsigned K,
-                                                        size_t n_cols, G1X *__restrict__ buckets, unsigned *__restrict__ heavy_count,
-                                                        unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
-  const size_t total = (size_t)K * n_cols;
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t col = g / K;
-    const unsigned b = (unsigned)(g - col * K);  // bucket value b+1
-    const unsigned *o = off + col * (K + 1);
-    const unsigned lo = o[b], hi = o[b + 1];
-    if (hi - lo > (unsigned)HEAVY_T) {
-      const unsigned slot = atomicAdd(heavy_count, 1u);
-      if (slot < heavy_cap) {
-        heavy_list[2 * slot] = (unsigned)col;
-        heavy_list[2 * slot + 1] = b;
-      }
-      continue;
+// ---- bounded-length accumulation tasks -------------------------------------------------------------
+// A bucket with cnt entries is cut into ceil(cnt / TASK_E) tasks; one thread sums one task (<= TASK_E mixed
+// additions), so the longest dependent chain in the kernel no longer depends on how skewed a column is
+// (witness columns hold thousands of 0/1 cells).  k_msm_task_count: tasks per column; k_msm_task_fill:
+// the task list (bucket id, slice); k_msm_accumulate: one thread per task -> partial sum;
+// k_msm_merge: one thread per bucket adds its partials (few), buckets with many partials go to a wave each.
+constexpr int TASK_E = 32;
+constexpr int MERGE_LIGHT = 8;  // partials merged by a single thread; more -> one wave per bucket
+
+__global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned *__restrict__ col_tasks) {
+  __shared__ unsigned sh[256];
+  const unsigned *o = off + (size_t)blockIdx.x * (K + 1);
+  unsigned s = 0;
+  for (unsigned b = threadIdx.x; b < K; b += 256) s += (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) col_tasks[blockIdx.x] = sh[0];
+}
+// exclusive scan over columns (single thread: n_cols is a few hundred), total in col_base[n_cols]
+__global__ void k_msm_task_colscan(const unsigned *__restrict__ col_tasks, unsigned n_cols, unsigned *__restrict__ col_base) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned acc = 0;
+  for (unsigned c = 0; c < n_cols; ++c) {
+    col_base[c] = acc;
+    acc += col_tasks[c];
+  }
+  col_base[n_cols] = acc;
+}
+// per column: exclusive scan of tasks-per-bucket -> first task of every bucket, and the task list itself
+__global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restrict__ off, unsigned K, const unsigned *__restrict__ col_base,
+                                                       unsigned *__restrict__ bucket_task0 /* [n_cols][K] */, uint2 *__restrict__ tasks) {
+  __shared__ unsigned part[256];
+  const size_t col = blockIdx.x;
+  const unsigned *o = off + col * (K + 1);
+  const unsigned per = (K + 255) / 256;
+  const unsigned lo = threadIdx.x * per, hi = min(lo + per, K);
+  unsigned s = 0;
+  for (unsigned b = lo; b < hi; ++b) s += (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned acc = col_base[col];
+    for (int i = 0; i < 256; ++i) {
+      unsigned t = part[i];
+      part[i] = acc;
+      acc += t;
     }
+  }
+  __syncthreads();
+  unsigned t0 = part[threadIdx.x];
+  for (unsigned b = lo; b < hi; ++b) {
+    const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+    bucket_task0[col * K + b] = t0;
+    for (unsigned j = 0; j < nt; ++j) tasks[t0 + j] = make_uint2((unsigned)(col * K + b), j);
+    t0 += nt;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict__ tasks, const unsigned *__restrict__ n_tasks_ptr,
+                                                        const unsigned *__restrict__ off, const unsigned *__restrict__ entries,
+                                                        size_t col_entries, const G1Affine *__restrict__ table, unsigned K,
+                                                        G1X *__restrict__ partials) {
+  const unsigned n_tasks = *n_tasks_ptr;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n_tasks; t += (size_t)gridDim.x * blockDim.x) {
+    const uint2 tk = tasks[t];
+    const size_t col = tk.x / K;
+    const unsigned b = tk.x - (unsigned)col * K;
+    const unsigned *o = off + col * (K + 1);
+    const unsigned lo = o[b] + tk.y * TASK_E;
+    const unsigned hi = min(lo + (unsigned)TASK_E, o[b + 1]);
     const unsigned *e = entries + col * col_entries;
     G1X acc = G1X::identity();
     for (unsigned k = lo; k < hi; ++k) {
@@ -159,42 +213,68 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const unsigned *__restri
       const G1Affine p = table[en & 0x7fffffffu];
       g1x_add_affine(acc, p, (en >> 31) != 0);
     }
+    partials[t] = acc;
+  }
+}
+
+// bucket sum = sum of its partials.  Light buckets: one thread.  Heavy ones are listed for k_msm_merge_heavy.
+__global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
+                                                   const G1X *__restrict__ partials, unsigned K, size_t n_cols, G1X *__restrict__ buckets,
+                                                   unsigned *__restrict__ heavy_count, unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
+  const size_t total = (size_t)K * n_cols;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t col = g / K;
+    const unsigned b = (unsigned)(g - col * K);
+    const unsigned *o = off + col * (K + 1);
+    const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+    if (nt > (unsigned)MERGE_LIGHT) {
+      const unsigned slot = atomicAdd(heavy_count, 1u);
+      if (slot < heavy_cap) heavy_list[slot] = (unsigned)g;
+      continue;
+    }
+    G1X acc = G1X::identity();
+    const unsigned t0 = bucket_task0[g];
+    for (unsigned j = 0; j < nt; ++j) g1x_add(acc, partials[t0 + j]);
     buckets[g] = acc;
   }
 }
 
-// one workgroup per heavy bucket: 256 partial sums, LDS tree
-__global__ void __launch_bounds__(256) k_msm_accumulate_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ entries,
-                                                              size_t col_entries, const G1Affine *__restrict__ table, unsigned K,
-                                                              G1X *__restrict__ buckets, const unsigned *__restrict__ heavy_count,
-                                                              const unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
-  __shared__ G1X sh[256];
+__device__ __forceinline__ G1X g1x_shfl_down(const G1X &p, int delta) {
+  G1X r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.x.l[i] = __shfl_down(p.x.l[i], delta);
+    r.y.l[i] = __shfl_down(p.y.l[i], delta);
+    r.zz.l[i] = __shfl_down(p.zz.l[i], delta);
+    r.zzz.l[i] = __shfl_down(p.zzz.l[i], delta);
+  }
+  return r;
+}
+
+// one wave per heavy bucket: lanes stride over the partials, then a 6-step shuffle tree
+__global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
+                                                         const G1X *__restrict__ partials, unsigned K, G1X *__restrict__ buckets,
+                                                         const unsigned *__restrict__ heavy_count, const unsigned *__restrict__ heavy_list,
+                                                         unsigned heavy_cap) {
   unsigned cnt = *heavy_count;
   if (cnt > heavy_cap) cnt = heavy_cap;
-  for (unsigned h = blockIdx.x; h < cnt; h += gridDim.x) {
-    const size_t col = heavy_list[2 * h];
-    const unsigned b = heavy_list[2 * h + 1];
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned h = wave; h < cnt; h += n_waves) {
+    const size_t g = heavy_list[h];
+    const size_t col = g / K;
+    const unsigned b = (unsigned)(g - col * K);
     const unsigned *o = off + col * (K + 1);
-    const unsigned lo = o[b], hi = o[b + 1];
-    const unsigned *e = entries + col * col_entries;
+    const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+    const unsigned t0 = bucket_task0[g];
     G1X acc = G1X::identity();
-    for (unsigned k = lo + threadIdx.x; k < hi; k += 256) {
-      const unsigned en = e[k];
-      const G1Affine p = table[en & 0x7fffffffu];
-      g1x_add_affine(acc, p, (en >> 31) != 0);
+    for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[t0 + j]);
+    for (int d = 32; d > 0; d >>= 1) {
+      const G1X other = g1x_shfl_down(acc, d);
+      if ((int)lane < d) g1x_add(acc, other);
     }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) {
-        G1X a = sh[threadIdx.x];
-        g1x_add(a, sh[threadIdx.x + s]);
-        sh[threadIdx.x] = a;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) buckets[col * K + b] = sh[0];
-    __syncthreads();
+    if (lane == 0) buckets[g] = acc;
   }
 }
 
@@ -364,23 +444,30 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
-  const size_t heavy_cap = (n_cols * col_entries) / HEAVY_T + 1;
-  // scratch 1: hist | off | cursor | heavy_count | heavy_list     scratch 2: entries     scratch 0: buckets
-  const size_t words = 3 * n_cols * K1 + 4 + 2 * heavy_cap;
+  const size_t max_tasks = (n_cols * col_entries) / TASK_E + (size_t)K * n_cols;      // upper bound on accumulation tasks
+  const size_t heavy_cap = (n_cols * col_entries) / ((size_t)TASK_E * MERGE_LIGHT) + 1;  // buckets with > MERGE_LIGHT partials
+  // scratch 1: hist | off | cursor | bucket_task0 | col_tasks | col_base | heavy_count | heavy_list | tasks
+  // scratch 2: entries     scratch 0: buckets | partials
+  const size_t words = 3 * n_cols * K1 + (size_t)K * n_cols + 2 * n_cols + 12 + heavy_cap + 2 * max_tasks;
   void *p1, *p2, *p0;
   int rc = zk_scratch(ctx, 1, words * sizeof(unsigned), &p1);
   if (rc) return rc;
   rc = zk_scratch(ctx, 2, n_cols * col_entries * sizeof(unsigned), &p2);
   if (rc) return rc;
-  rc = zk_scratch(ctx, 0, n_cols * (size_t)K * sizeof(G1X), &p0);
+  rc = zk_scratch(ctx, 0, (n_cols * (size_t)K + max_tasks) * sizeof(G1X), &p0);
   if (rc) return rc;
   unsigned *hist = (unsigned *)p1;
   unsigned *off = hist + n_cols * K1;
   unsigned *cursor = off + n_cols * K1;
-  unsigned *heavy_count = cursor + n_cols * K1;
+  unsigned *bucket_task0 = cursor + n_cols * K1;
+  unsigned *col_tasks = bucket_task0 + (size_t)K * n_cols;
+  unsigned *col_base = col_tasks + n_cols;          // n_cols + 1 entries
+  unsigned *heavy_count = col_base + n_cols + 4;
   unsigned *heavy_list = heavy_count + 4;
+  uint2 *tasks = (uint2 *)(((uintptr_t)(heavy_list + heavy_cap) + 7) & ~(uintptr_t)7);
   unsigned *entries = (unsigned *)p2;
   G1X *buckets = (G1X *)p0;
+  G1X *partials = buckets + n_cols * (size_t)K;
   ZK_HIP(ctx, hipMemsetAsync(hist, 0, n_cols * K1 * sizeof(unsigned), ctx->stream));
   ZK_HIP(ctx, hipMemsetAsync(heavy_count, 0, 4 * sizeof(unsigned), ctx->stream));
   const size_t total = n * n_cols;
@@ -393,16 +480,27 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   ZK_LAUNCH_CHECK(ctx);
   k_msm_scatter<<<grid, 256, 0, ctx->stream>>>((const Fr *)scalars_dev, n, n_cols, c, W, cursor, K1, entries, col_entries);
   ZK_LAUNCH_CHECK(ctx);
-  const size_t nb = (size_t)K * n_cols;
-  unsigned gridb = zk_blocks(nb, 256);
+  k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, col_tasks);
+  ZK_LAUNCH_CHECK(ctx);
+  k_msm_task_colscan<<<1, 64, 0, ctx->stream>>>(col_tasks, (unsigned)n_cols, col_base);
+  ZK_LAUNCH_CHECK(ctx);
+  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, col_base, bucket_task0, tasks);
+  ZK_LAUNCH_CHECK(ctx);
+  unsigned gridt = zk_blocks(max_tasks, 256);
+  const unsigned capt = (unsigned)ctx->num_cu * 32;
+  if (gridt > capt) gridt = capt;
   zk_prof_begin(ctx);
-  k_msm_accumulate<<<gridb, 256, 0, ctx->stream>>>(off, entries, col_entries, basis->table, K, n_cols, buckets, heavy_count,
-                                                   heavy_list, (unsigned)heavy_cap);
+  k_msm_accumulate<<<gridt, 256, 0, ctx->stream>>>(tasks, col_base + n_cols, off, entries, col_entries, basis->table, K, partials);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 0, 96.0 * (double)n * (double)n_cols);
-  unsigned gridh = (unsigned)(heavy_cap < 1024 ? heavy_cap : 1024);
-  k_msm_accumulate_heavy<<<gridh, 256, 0, ctx->stream>>>(off, entries, col_entries, basis->table, K, buckets, heavy_count, heavy_list,
-                                                         (unsigned)heavy_cap);
+  const size_t nb = (size_t)K * n_cols;
+  unsigned gridb = zk_blocks(nb, 256);
+  if (gridb > capt) gridb = capt;
+  k_msm_merge<<<gridb, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, n_cols, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
+  ZK_LAUNCH_CHECK(ctx);
+  unsigned gridh = (unsigned)((heavy_cap + 3) / 4);
+  if (gridh > 2048) gridh = 2048;
+  k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
   static bool red_attr = false;
   const int red_lds = 2 * RED_THREADS * (int)sizeof(G1X);
