@@ -32,6 +32,12 @@ def main():
         ts.append(ctx.timer_stop_ms())
     ms = float(np.median(ts))
     res["modmul_per_s"] = n * iters / (ms * 1e-3)
+    # single-wave dependent-chain latency of one modmul (64 threads, long chain)
+    lat_iters = 20000
+    ctx._check(ctx.lib.zkfhe_fr_sqr_chain(ctx.h, d.at(0), o.at(0), 64, lat_iters))
+    ctx.timer_start()
+    ctx._check(ctx.lib.zkfhe_fr_sqr_chain(ctx.h, d.at(0), o.at(0), 64, lat_iters))
+    res["modmul_latency_us_single_wave"] = ctx.timer_stop_ms() * 1e3 / lat_iters
     # element-wise mul: 96 B per element
     for _ in range(2):
         ctx.fr_binop_dev("mul", d, d, o, n)
