@@ -32,6 +32,8 @@ struct FrP {
                                  0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod p
   static constexpr u32 R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
                                 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+  static constexpr u32 R3[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu,
+                                0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};  // R^3 mod p
   static constexpr u32 INV = 0xefffffffu;  // -p^-1 mod 2^32
 };
 
@@ -42,6 +44,8 @@ struct FqP {
                                  0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
   static constexpr u32 R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
                                 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+  static constexpr u32 R3[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u,
+                                0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};
   static constexpr u32 INV = 0xe4866389u;
 };
 
@@ -264,14 +268,87 @@ ZK_HD Fp<P> fp_pow(const Fp<P>& a, const u32 (&e)[8]) {
   return r;
 }
 
-// a^-1 = a^(p-2); 0 -> 0 (the halo2 `invert().unwrap_or(0)` convention used by batch_invert).
+// a^-1, 0 -> 0 (the halo2 `invert().unwrap_or(0)` convention used by batch_invert).
+// Binary extended Euclid on the Montgomery representative x = aR: it yields x^-1 = a^-1 R^-1, and one
+// Montgomery product with R^3 brings that back to a^-1 R.  ~750 shift/add/sub rounds on 8 limbs -- an order
+// of magnitude cheaper than the 381 Montgomery products of a Fermat ladder, which is what the latency of
+// every normalisation (bucket reduction -> affine, batch inversion) used to be made of.
 template <class P>
 ZK_HD Fp<P> fp_inv(const Fp<P>& a) {
-  u32 e[8];
+  if (a.is_zero()) return a;
+  u32 u[8], v[8], x1[8], x2[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) e[i] = P::MOD[i];
-  e[0] -= 2;  // low limb of both moduli is >= 2
-  return fp_pow<P>(a, e);
+  for (int i = 0; i < 8; ++i) {
+    u[i] = a.l[i];
+    v[i] = P::MOD[i];
+    x1[i] = i == 0 ? 1u : 0u;
+    x2[i] = 0u;
+  }
+  auto is_one = [](const u32(&t)[8]) {
+    u32 o = t[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) o |= t[i];
+    return o == 0;
+  };
+  auto shr1 = [](u32(&t)[8]) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    t[7] >>= 1;
+  };
+  auto halve_mod = [&](u32(&t)[8]) {  // t/2 mod p for t < p
+    if (t[0] & 1u) {
+      u32 c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = zk_addc(t[i], P::MOD[i], c, &c);  // < 2^255: no carry out
+    }
+    shr1(t);
+  };
+  auto geq = [](const u32(&s)[8], const u32(&t)[8]) {
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) (void)zk_subc(s[i], t[i], br, &br);
+    return br == 0;
+  };
+  auto sub_raw = [](u32(&s)[8], const u32(&t)[8]) {
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = zk_subc(s[i], t[i], br, &br);
+  };
+  auto sub_mod = [&](u32(&s)[8], const u32(&t)[8]) {
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = zk_subc(s[i], t[i], br, &br);
+    if (br) {
+      u32 c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = zk_addc(s[i], P::MOD[i], c, &c);
+    }
+  };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1u)) {
+      shr1(u);
+      halve_mod(x1);
+    }
+    while (!(v[0] & 1u)) {
+      shr1(v);
+      halve_mod(x2);
+    }
+    if (geq(u, v)) {
+      sub_raw(u, v);
+      sub_mod(x1, x2);
+    } else {
+      sub_raw(v, u);
+      sub_mod(x2, x1);
+    }
+  }
+  Fp<P> r, r3;
+  const bool pick_u = is_one(u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.l[i] = pick_u ? x1[i] : x2[i];
+    r3.l[i] = P::R3[i];
+  }
+  return fp_mul<P>(r, r3);
 }
 
 typedef Fp<FrP> Fr;

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_fr_sqr_chain(const Fr *__restrict__ a, 
 // Batch inversion, Montgomery trick per thread over a strided chunk of CHUNK elements:
 // thread t owns elements t, t+T, t+2T, ... (T = total threads) so every load/store is coalesced.
 // prefix products go to `tmp` (n elements).  Zero elements are skipped and stay zero.
-#define BI_CHUNK 32
+#define BI_CHUNK 8
 __global__ void __launch_bounds__(256) k_fr_batch_invert(Fr *__restrict__ a, Fr *__restrict__ tmp, size_t n, size_t T) {
   size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (t >= T) return;

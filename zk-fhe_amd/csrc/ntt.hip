@@ -221,6 +221,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
     TileArgs a{};
     a.in = data;
     a.out = data;
+    a.in_tile_stride = n;
     a.col_stride_in = a.col_stride_out = n;
     a.tw = inverse ? dom->inv : dom->fwd;
     a.pre = nullptr;
@@ -250,6 +251,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   TileArgs a{};
   a.in = data;
   a.out = (Fr *)p;
+  a.in_tile_stride = (size_t)1 << MAX_TILE_LOG;
   a.col_stride_in = a.col_stride_out = n;
   a.tw = inverse ? tdom->inv : tdom->fwd;
   a.post = ninv_dev;
@@ -293,6 +295,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     TileArgs a{};
     a.in = (const Fr *)in_dev;
     a.out = (Fr *)out_dev;
+    a.in_tile_stride = 0;  // every coset row of a column starts from the same n coefficients
     a.col_stride_in = n;
     a.col_stride_out = ne;
     a.tw = dom->fwd;
@@ -302,17 +305,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     a.log_tiles = lef;
     a.in_len = (int)n;
     a.out_natural_tiles = 1;
-    // every tile of a column reads the SAME n input coefficients: in tile stride must be 0.
-    // k_ntt_tile addresses tiles at in + b*N, so launch one grid row per k1 with shifted out/pre pointers.
-    for (int k1 = 0; k1 < E; ++k1) {
-      TileArgs ak = a;
-      ak.out = (Fr *)out_dev + (size_t)k1 * n;
-      ak.pre = pre + (size_t)k1 * n;
-      ak.pre_tile_stride = 0;
-      rc = launch_tile_dyn(ctx, log_n, ak, 1, (unsigned)n_cols);
-      if (rc) return rc;
-    }
-    return ZKFHE_OK;
+    return launch_tile_dyn(ctx, log_n, a, (unsigned)E, (unsigned)n_cols);
   }
   // inverse: rows iNTT (size n, scaled by n^-1) into scratch, then combine across k1
   rc = zk_scratch(ctx, 0, n_cols * ne * sizeof(Fr), &p);
@@ -325,6 +318,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
   TileArgs a{};
   a.in = (const Fr *)in_dev;
   a.out = rows;
+  a.in_tile_stride = n;
   a.col_stride_in = ne;
   a.col_stride_out = ne;
   a.tw = dom->inv;

@@ -52,7 +52,8 @@ __device__ __forceinline__ void dft8(Fr (&r)[8], const Fr &w4, const Fr &w8, con
 }
 
 struct TileArgs {
-  const Fr *in;        // column c, tile b at in + c*col_stride_in + b*N (contiguous)
+  const Fr *in;        // column c, tile b at in + c*col_stride_in + b*in_tile_stride (contiguous run of N)
+  size_t in_tile_stride;  // N for independent tiles, 0 when every tile of a column reads the same coefficients
   Fr *out;             // element q of (c,b) goes to out + c*col_stride_out + out_off(b) + q*out_stride
   size_t col_stride_in, col_stride_out;
   const Fr *tw;        // omega_N^j (or omega_N^-j), j < N
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__((1 << LOGN) / 8) k_ntt_tile(TileArgs a) {
   const int tid = threadIdx.x;
   const unsigned b = blockIdx.x;  // tile within column
   const size_t c = blockIdx.y;
-  const Fr *__restrict__ src = a.in + c * a.col_stride_in + (size_t)b * N;
+  const Fr *__restrict__ src = a.in + c * a.col_stride_in + (size_t)b * a.in_tile_stride;
   Fr reg[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {

@@ -58,12 +58,20 @@ struct DevBuf {
 };
 
 
+struct View {  // a slice of a larger device allocation
+  void *p = nullptr;
+  Fr *fr() const { return (Fr *)p; }
+};
+
 struct Workspace {
-  DevBuf adv_l, la_l, ls_l, lz_l, pz_l, inst_l, tmp_c, adv_ext, pz_ext, lz_ext, la_ext, ls_ext, inst_ext, partials, h_ext, h_c, misc, points;
-  DevBuf num, den, small, jobs, evout, polyio;
+  // every polynomial of one proof, Lagrange form, contiguous: [advice | la | ls | pz | lz | instance] (all_l) and the
+  // same order on the extended coset (all_ext) -- one iNTT launch and one coset-NTT launch cover all of them
+  DevBuf all_l, all_ext;
+  View adv_l, la_l, ls_l, pz_l, lz_l, inst_l, adv_ext, la_ext, ls_ext, pz_ext, lz_ext, inst_ext;
+  size_t n_all = 0;
+  DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
   std::vector<DevBuf *> all() {
-    return {&adv_l, &la_l, &ls_l, &lz_l, &pz_l, &inst_l, &tmp_c, &adv_ext, &pz_ext, &lz_ext, &la_ext, &ls_ext, &inst_ext, &partials,
-            &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio};
+    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio};
   }
 };
 
@@ -215,24 +223,30 @@ std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const st
 
 int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
   const size_t n = c.n(), ne = 4 * n, col = n * 32, ecol = ne * 32;
-  CK(ws->adv_l.alloc(ctx, c.n_advice() * col));
-  CK(ws->la_l.alloc(ctx, c.n_lookup * col + 32));
-  CK(ws->ls_l.alloc(ctx, c.n_lookup * col + 32));
-  CK(ws->lz_l.alloc(ctx, c.n_lookup * col + 32));
-  CK(ws->pz_l.alloc(ctx, c.n_chunks() * col));
-  CK(ws->inst_l.alloc(ctx, col));
-  CK(ws->tmp_c.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * col));
-  CK(ws->adv_ext.alloc(ctx, c.n_advice() * ecol));
-  CK(ws->pz_ext.alloc(ctx, c.n_chunks() * ecol));
-  CK(ws->lz_ext.alloc(ctx, c.n_lookup * ecol + 32));
-  CK(ws->la_ext.alloc(ctx, c.n_lookup * ecol + 32));
-  CK(ws->ls_ext.alloc(ctx, c.n_lookup * ecol + 32));
-  CK(ws->inst_ext.alloc(ctx, ecol));
+  const size_t n_all = (size_t)c.n_advice() + 3 * c.n_lookup + c.n_chunks() + 1;
+  ws->n_all = n_all;
+  CK(ws->all_l.alloc(ctx, n_all * col));
+  CK(ws->all_ext.alloc(ctx, n_all * ecol));
+  {
+    size_t o = 0;
+    auto take = [&](View &l, View &e, size_t cols) {
+      l.p = (char *)ws->all_l.p + o * col;
+      e.p = (char *)ws->all_ext.p + o * ecol;
+      o += cols;
+    };
+    take(ws->adv_l, ws->adv_ext, c.n_advice());
+    take(ws->la_l, ws->la_ext, c.n_lookup);
+    take(ws->ls_l, ws->ls_ext, c.n_lookup);
+    take(ws->pz_l, ws->pz_ext, c.n_chunks());
+    take(ws->lz_l, ws->lz_ext, c.n_lookup);
+    take(ws->inst_l, ws->inst_ext, 1);
+  }
+  CK(ws->tmp_c.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * col));
   CK(ws->partials.alloc(ctx, 96 * ecol));
   CK(ws->h_ext.alloc(ctx, ecol));
   CK(ws->h_c.alloc(ctx, ecol));
   CK(ws->misc.alloc(ctx, 32 * col));
-  CK(ws->points.alloc(ctx, std::max<size_t>(c.n_advice(), c.n_perm()) * 64 + 64));
+  CK(ws->points.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * 64 + 64));
   CK(ws->num.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
   CK(ws->den.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
   CK(ws->small.alloc(ctx, 1 << 20));
@@ -503,8 +517,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     }
     CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, (size_t)cfg.n_lookup * n));
     CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->ls_l.p, (zkfhe_fr *)ws->ls_l.p, (size_t)cfg.n_lookup * n));
-    CK(commit_cols(ctx, srs->g_lagrange, ws->la_l.fr(), cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));
-    CK(commit_cols(ctx, srs->g_lagrange, ws->ls_l.fr(), cfg.n_lookup, (G1Affine *)ws->points.p, ls_commit));
+    CK(commit_cols(ctx, srs->g_lagrange, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
+    ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
+    la_commit.resize(cfg.n_lookup);
     for (unsigned i = 0; i < cfg.n_lookup; ++i) {
       tr.write_point(la_commit[i]);
       tr.write_point(ls_commit[i]);
@@ -588,12 +603,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_HIP(ctx, hipMemcpy2DAsync(ws->lz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nl, hipMemcpyDeviceToDevice, ctx->stream));
   }
   std::vector<AffinePoint> pz_commit, lz_commit;
-  CK(commit_cols(ctx, srs->g_lagrange, ws->pz_l.fr(), nch, (G1Affine *)ws->points.p, pz_commit));
+  CK(commit_cols(ctx, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, (G1Affine *)ws->points.p, pz_commit));  // pz | lz contiguous
+  lz_commit.assign(pz_commit.begin() + nch, pz_commit.end());
+  pz_commit.resize(nch);
   for (const auto &p : pz_commit) tr.write_point(p);
-  if (cfg.n_lookup) {
-    CK(commit_cols(ctx, srs->g_lagrange, ws->lz_l.fr(), cfg.n_lookup, (G1Affine *)ws->points.p, lz_commit));
-    for (const auto &p : lz_commit) tr.write_point(p);
-  }
+  for (const auto &p : lz_commit) tr.write_point(p);
   // ------------------------------------------------------------ vanishing: random polynomial (coefficient form)
   Fr *rand_c = ws->misc.fr() + 8 * n, *rand_l = ws->misc.fr() + 9 * n, *H_c = ws->misc.fr() + 10 * n, *H_l = ws->misc.fr() + 11 * n;
   {
@@ -607,12 +621,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const Fr y = mont(tr.squeeze());
   const double t_commit = now_ms();
   // ------------------------------------------------------------ quotient
-  CK(extend_cols(ctx, pk, ws, ws->adv_l.fr(), cfg.n_advice(), ws->adv_ext.fr()));
-  CK(extend_cols(ctx, pk, ws, ws->pz_l.fr(), nch, ws->pz_ext.fr()));
-  CK(extend_cols(ctx, pk, ws, ws->lz_l.fr(), cfg.n_lookup, ws->lz_ext.fr()));
-  CK(extend_cols(ctx, pk, ws, ws->la_l.fr(), cfg.n_lookup, ws->la_ext.fr()));
-  CK(extend_cols(ctx, pk, ws, ws->ls_l.fr(), cfg.n_lookup, ws->ls_ext.fr()));
-  CK(extend_cols(ctx, pk, ws, ws->inst_l.fr(), 1, ws->inst_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr()));
   {
     // expression groups, in the folding order of oracle/halo2_ref.py expressions_at
     std::vector<zkp::QGroup> groups;
