@@ -245,8 +245,28 @@ inline Placement place_stream(size_t n_cells, const std::vector<uint32_t> &selec
 
 // The witness table of one proof: advice columns (canonical values), and -- in keygen mode -- the fixed
 // columns and the copy constraints in permutation-column coordinates.
+// [n_advice][n] advice values, either owned or placed in caller-provided (e.g. pinned, reused) memory
+struct AdviceTable {
+  U256 *data = nullptr;
+  size_t n_cols = 0, n = 0;
+  std::vector<U256> own;
+  void init(size_t cols, size_t rows, U256 *external) {
+    n_cols = cols;
+    n = rows;
+    if (external) {
+      data = external;  // reused across proofs: every cell of the fixed layout is rewritten, the rest stays zero
+    } else {
+      own.assign(cols * rows, fe::zero());
+      data = own.data();
+    }
+  }
+  U256 *operator[](size_t c) { return data + c * n; }
+  const U256 *operator[](size_t c) const { return data + c * n; }
+  size_t size() const { return n_cols; }
+};
+
 struct Tables {
-  std::vector<std::vector<U256>> advice;  // [n_advice][n]
+  AdviceTable advice;  // [n_advice][n]
   std::vector<std::vector<U256>> fixed;   // [n_fixed][n]   (keygen only)
   std::vector<U256> instance;
   std::vector<std::pair<uint64_t, uint64_t>> copies;  // cell id = perm_col * n + row   (keygen only)
@@ -262,8 +282,8 @@ class Assigner {
   uint32_t col0[3];
   std::vector<std::pair<U256, uint32_t>> const_rows;  // first-appearance order
 
-  Assigner(const CircuitConfig &c, bool keygen_mode) : cfg(c), keygen(keygen_mode) {
-    t.advice.assign(cfg.n_advice(), std::vector<U256>(cfg.n(), fe::zero()));
+  Assigner(const CircuitConfig &c, bool keygen_mode, U256 *advice_storage = nullptr) : cfg(c), keygen(keygen_mode) {
+    t.advice.init(cfg.n_advice(), cfg.n(), advice_storage);
     if (keygen) t.fixed.assign(cfg.n_fixed(), std::vector<U256>(cfg.n(), fe::zero()));
     col0[CTX_PHASE0] = 0;
     col0[CTX_GATE1] = cfg.n_gate0;

@@ -70,6 +70,7 @@ int zkfhe_bfv_build_tables(const char *input_json, const zkfhe_bfv_params *param
     if (kg) as.finish_structure(ctx0, ctx_gate, ctx_rlc, make_public);
     for (const Cell &c : make_public) as.t.instance.push_back(c.value);
     res->t = std::move(as.t);
+    if (!res->t.advice.own.empty()) res->t.advice.data = res->t.advice.own.data();
     res->cells0 = ctx0.advice.size();
     res->cells1 = ctx_gate.advice.size();
     res->cells_rlc = ctx_rlc.advice.size();
@@ -104,7 +105,7 @@ size_t zkfhe_bfv_tables_count(const zkfhe_bfv_tables *t, int what) {
 
 int zkfhe_bfv_tables_copy_advice(const zkfhe_bfv_tables *t, uint64_t *out) {
   const size_t n = t->cfg.n();
-  for (size_t c = 0; c < t->t.advice.size(); ++c) memcpy(out + c * n * 4, t->t.advice[c].data(), n * 32);
+  for (size_t c = 0; c < t->t.advice.size(); ++c) memcpy(out + c * n * 4, t->t.advice[c], n * 32);
   return ZKFHE_OK;
 }
 int zkfhe_bfv_tables_copy_fixed(const zkfhe_bfv_tables *t, uint64_t *out) {

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 
 #include "../../include/zkfhe.h"
@@ -69,6 +71,8 @@ struct Workspace {
   DevBuf all_l, all_ext;
   View adv_l, la_l, ls_l, pz_l, lz_l, inst_l, adv_ext, la_ext, ls_ext, pz_ext, lz_ext, inst_ext;
   size_t n_all = 0;
+  U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
+  U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
   std::vector<DevBuf *> all() {
     return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio};
@@ -254,6 +258,9 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
   CK(ws->jobs.alloc(ctx, max_items * sizeof(zkp::EvalJob) + max_items * (sizeof(void *) + 32)));
   CK(ws->evout.alloc(ctx, max_items * 4 * 32));
   CK(ws->polyio.alloc(ctx, 4 * c.n() * 32));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_adv, (size_t)c.n_advice() * col, hipHostMallocDefault));
+  memset(ws->host_adv, 0, (size_t)c.n_advice() * col);
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_blind, std::max<size_t>(2 * c.n_lookup, 2) * col, hipHostMallocDefault));
   return ZKFHE_OK;
 }
 
@@ -440,6 +447,37 @@ void permute_lookup(const std::vector<U256> &input, size_t u, unsigned table_siz
     for (size_t k = 0; k < left[v]; ++k) s_perm[holes[hi++]] = fe::from_u64(v);
 }
 
+// The blinding stream is counter based (Blake2b(seed || i)), so all draws of a proof -- their number is fixed by the
+// circuit shape -- are produced by a helper thread while the witness is being generated; next() hands them out in order.
+class PreRng {
+ public:
+  PreRng(const uint8_t seed[32], size_t total) : vals(total), done(0) {
+    memcpy(sd, seed, 32);
+    th = std::thread([this] {
+      Rng r(sd);
+      for (size_t i = 0; i < vals.size(); ++i) {
+        vals[i] = r.next();
+        done.store(i + 1, std::memory_order_release);
+      }
+    });
+  }
+  ~PreRng() {
+    if (th.joinable()) th.join();
+  }
+  U256 next() {
+    if (idx >= vals.size()) throw std::logic_error("blinding stream exhausted");
+    while (done.load(std::memory_order_acquire) <= idx) std::this_thread::yield();
+    return vals[idx++];
+  }
+
+ private:
+  std::vector<U256> vals;
+  std::atomic<size_t> done;
+  size_t idx = 0;
+  uint8_t sd[32];
+  std::thread th;
+};
+
 struct OpenItem {
   const Fr *lagr;        // device pointer, Lagrange form
   int n_rot;
@@ -453,7 +491,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const size_t n = cfg.n(), u = cfg.u(), ne = 4 * n;
   const unsigned k = cfg.k;
   const double t_start = now_ms();
-  Rng rng(seed);
+  PreRng rng(seed, (size_t)cfg.n_advice() * (n - u) + 2 * (size_t)cfg.n_lookup * (n - u) +
+                        ((size_t)cfg.n_chunks() + cfg.n_lookup) * (n - u - 1) + n);
   Transcript tr;
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
@@ -469,7 +508,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
   std::vector<Cell> make_public;
   BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
-  Assigner as(cfg, false);
+  Assigner as(cfg, false, ws->host_adv);
   as.place(ctx0, true);
   instances.clear();
   for (const Cell &c : make_public) instances.push_back(c.value);
@@ -477,10 +516,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   for (const U256 &v : instances) tr.common_scalar(v);
   auto blind_and_upload = [&](unsigned c_lo, unsigned c_hi) -> int {
     for (unsigned c = c_lo; c < c_hi; ++c) {
-      std::vector<U256> &col = as.t.advice[c];
+      U256 *col = as.t.advice[c];
       for (size_t r = u; r < n; ++r) col[r] = rng.next();
-      ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c * n, col.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
     }
+    // the table is pinned and column-contiguous: one DMA for the whole phase
+    ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c_lo * n, as.t.advice[c_lo], (size_t)(c_hi - c_lo) * n * 32, hipMemcpyHostToDevice, ctx->stream));
     return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
                             (size_t)(c_hi - c_lo) * n);
   };
@@ -496,7 +536,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   as.place_lookups(ctx_gate);
   std::vector<std::vector<U256>> lookup_inputs(cfg.n_lookup);
   for (unsigned i = 0; i < cfg.n_lookup; ++i)
-    lookup_inputs[i].assign(as.t.advice[cfg.adv_lookup0() + i].begin(), as.t.advice[cfg.adv_lookup0() + i].begin() + u);
+    lookup_inputs[i].assign(as.t.advice[cfg.adv_lookup0() + i], as.t.advice[cfg.adv_lookup0() + i] + u);
   const double t_wit = now_ms();
   CK(blind_and_upload(cfg.n_gate0, cfg.n_advice()));
   CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
@@ -505,18 +545,18 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // ------------------------------------------------------------ lookups: permuted input / table
   std::vector<AffinePoint> la_commit, ls_commit;
   if (cfg.n_lookup) {
-    std::vector<U256> colA(n), colS(n), ap, sp;
+    std::vector<U256> ap, sp;
+    U256 *stA = ws->host_blind, *stS = ws->host_blind + (size_t)cfg.n_lookup * n;  // la | ls, as on the device
     for (unsigned i = 0; i < cfg.n_lookup; ++i) {
       permute_lookup(lookup_inputs[i], u, 1u << cfg.lookup_bits, ap, sp);
-      std::copy(ap.begin(), ap.end(), colA.begin());
-      std::copy(sp.begin(), sp.end(), colS.begin());
+      U256 *colA = stA + (size_t)i * n, *colS = stS + (size_t)i * n;
+      std::copy(ap.begin(), ap.end(), colA);
+      std::copy(sp.begin(), sp.end(), colS);
       for (size_t r = u; r < n; ++r) colA[r] = rng.next();
       for (size_t r = u; r < n; ++r) colS[r] = rng.next();
-      CK(zkfhe_upload(ctx, ws->la_l.fr() + (size_t)i * n, colA.data(), n * 32));
-      CK(zkfhe_upload(ctx, ws->ls_l.fr() + (size_t)i * n, colS.data(), n * 32));
     }
-    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, (size_t)cfg.n_lookup * n));
-    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->ls_l.p, (zkfhe_fr *)ws->ls_l.p, (size_t)cfg.n_lookup * n));
+    ZK_HIP(ctx, hipMemcpyAsync(ws->la_l.p, ws->host_blind, 2 * (size_t)cfg.n_lookup * n * 32, hipMemcpyHostToDevice, ctx->stream));
+    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
     CK(commit_cols(ctx, srs->g_lagrange, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
     ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
     la_commit.resize(cfg.n_lookup);
@@ -946,6 +986,8 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
   for (DevBuf *b : bufs) b->release();
   for (auto &kv : pk->workspaces) {
     for (DevBuf *b : kv.second->all()) b->release();
+    if (kv.second->host_adv) (void)hipHostFree(kv.second->host_adv);
+    if (kv.second->host_blind) (void)hipHostFree(kv.second->host_blind);
     delete kv.second;
   }
   delete pk;
