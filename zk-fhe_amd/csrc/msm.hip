@@ -72,13 +72,28 @@ __device__ __forceinline__ void for_each_digit(const Fr &mont, int c, int window
   }
 }
 
-__global__ void __launch_bounds__(256) k_msm_hist(const Fr *__restrict__ scalars, size_t n, size_t n_cols, int c, int windows,
-                                                  unsigned *__restrict__ hist /* [n_cols][K+1] */, unsigned K1) {
-  const size_t total = n * n_cols;
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t col = g / n;
-    unsigned *h = hist + col * K1;
-    for_each_digit(scalars[g], c, windows, [&](int, u32 b, bool) { atomicAdd(&h[b], 1u); });
+// Histogram / scatter with LDS-privatised counters.  A workgroup owns a chunk of CHUNK scalars of ONE column and
+// counts their digits in LDS (K+1 counters); only the non-zero bins touch global memory, with one atomic per
+// (workgroup, bucket) instead of one per entry -- device-scope atomics are memory transactions on this chip
+// (profiles/r1_pmc_traffic.md: 144 MB of writes per launch before this change).
+constexpr unsigned SORT_CHUNK = 2048;   // scalars per workgroup
+constexpr unsigned SORT_THREADS = 512;
+
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_hist(const Fr *__restrict__ scalars, size_t n, unsigned chunks_per_col, int c, int windows,
+                                                          unsigned *__restrict__ hist /* [n_cols][K+1] */, unsigned K1) {
+  extern __shared__ unsigned lh[];
+  const size_t col = blockIdx.x / chunks_per_col;
+  const unsigned chunk = blockIdx.x % chunks_per_col;
+  for (unsigned b = threadIdx.x; b < K1; b += SORT_THREADS) lh[b] = 0;
+  __syncthreads();
+  const size_t i0 = (size_t)chunk * SORT_CHUNK, i1 = min(n, i0 + SORT_CHUNK);
+  for (size_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS)
+    for_each_digit(scalars[col * n + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[b], 1u); });
+  __syncthreads();
+  unsigned *h = hist + col * K1;
+  for (unsigned b = threadIdx.x; b < K1; b += SORT_THREADS) {
+    const unsigned v = lh[b];
+    if (v) atomicAdd(&h[b], v);
   }
 }
 
@@ -116,20 +131,33 @@ __global__ void __launch_bounds__(256) k_msm_scan(const unsigned *__restrict__ h
   if (hi == K) o[K] = acc;  // total (every thread past the end writes the same value)
 }
 
-__global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scalars, size_t n, size_t n_cols, int c, int windows,
-                                                     unsigned *__restrict__ cursor, unsigned K1, unsigned *__restrict__ entries,
-                                                     size_t col_entries) {
-  const size_t total = n * n_cols;
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t col = g / n;
-    const unsigned i = (unsigned)(g - col * n);
-    unsigned *cu = cursor + col * K1;
-    unsigned *e = entries + col * col_entries;
-    for_each_digit(scalars[g], c, windows, [&](int w, u32 b, bool neg) {
-      const unsigned pos = atomicAdd(&cu[b], 1u);
-      e[pos] = ((unsigned)w * (unsigned)n + i) | (neg ? 0x80000000u : 0u);
-    });
+// scatter: count in LDS again, reserve one contiguous range per (workgroup, bucket) with a single global atomic,
+// then rank the entries inside the range with LDS atomics: entries of a bucket coming from one workgroup land next
+// to each other (fewer partial-line stores), and global atomics drop from one per entry to one per non-empty bin.
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restrict__ scalars, size_t n, unsigned chunks_per_col, int c, int windows,
+                                                             unsigned *__restrict__ cursor, unsigned K1, unsigned *__restrict__ entries,
+                                                             size_t col_entries) {
+  extern __shared__ unsigned lh[];  // [K1] counts, then running positions
+  const size_t col = blockIdx.x / chunks_per_col;
+  const unsigned chunk = blockIdx.x % chunks_per_col;
+  for (unsigned b = threadIdx.x; b < K1; b += SORT_THREADS) lh[b] = 0;
+  __syncthreads();
+  const size_t i0 = (size_t)chunk * SORT_CHUNK, i1 = min(n, i0 + SORT_CHUNK);
+  for (size_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS)
+    for_each_digit(scalars[col * n + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[b], 1u); });
+  __syncthreads();
+  unsigned *cu = cursor + col * K1;
+  for (unsigned b = threadIdx.x; b < K1; b += SORT_THREADS) {
+    const unsigned v = lh[b];
+    lh[b] = v ? atomicAdd(&cu[b], v) : 0u;  // base position of this workgroup's run in bucket b
   }
+  __syncthreads();
+  unsigned *e = entries + col * col_entries;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS)
+    for_each_digit(scalars[col * n + i], c, windows, [&](int w, u32 b, bool neg) {
+      const unsigned pos = atomicAdd(&lh[b], 1u);
+      e[pos] = ((unsigned)w * (unsigned)n + (unsigned)i) | (neg ? 0x80000000u : 0u);
+    });
 }
 
 // ---- bounded-length accumulation tasks -------------------------------------------------------------
@@ -536,15 +564,20 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   G1X *partials = buckets + n_cols * (size_t)K;
   ZK_HIP(ctx, hipMemsetAsync(hist, 0, n_cols * K1 * sizeof(unsigned), ctx->stream));
   ZK_HIP(ctx, hipMemsetAsync(heavy_count, 0, 4 * sizeof(unsigned), ctx->stream));
-  const size_t total = n * n_cols;
-  unsigned grid = zk_blocks(total, 256);
-  const unsigned cap = (unsigned)ctx->num_cu * 16;
-  if (grid > cap) grid = cap;
-  k_msm_hist<<<grid, 256, 0, ctx->stream>>>((const Fr *)scalars_dev, n, n_cols, c, W, hist, K1);
+  const unsigned chunks_per_col = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+  const unsigned grid = (unsigned)(n_cols * chunks_per_col);
+  const size_t sort_lds = (size_t)K1 * sizeof(unsigned);
+  static bool sort_attr = false;
+  if (!sort_attr && sort_lds > 48 * 1024) {
+    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    sort_attr = true;
+  }
+  k_msm_hist<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, n, chunks_per_col, c, W, hist, K1);
   ZK_LAUNCH_CHECK(ctx);
   k_msm_scan<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(hist, off, cursor, K1);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_scatter<<<grid, 256, 0, ctx->stream>>>((const Fr *)scalars_dev, n, n_cols, c, W, cursor, K1, entries, col_entries);
+  k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
   ZK_LAUNCH_CHECK(ctx);
   k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, col_tasks);
   ZK_LAUNCH_CHECK(ctx);
