@@ -86,57 +86,34 @@ def main():
             dist.barrier()
 
     import threading
+    import zk_fhe_amd.batch as batch
     n_streams = max(1, min(args.streams, args.steps))
     ctxs = [ctx] + [zk.Context(local_rank) for _ in range(n_streams - 1)]
     stage = np.zeros(5)
     proof_len = [0]
     lock = threading.Lock()
 
-    def run_jobs(first, count):
-        """`count` proofs, jobs first..first+count-1, pulled by the stream workers; returns when all are done"""
-        nxt = [first]
-        errs = []
+    def one_proof(c, j):
+        proof, inst, tm = pk.prove(inputs[j % 4], seeds[j % len(seeds)], ctx=c)
+        with lock:
+            stage[:] += np.array(tm)
+            proof_len[0] = len(proof)
+        return proof
 
-        def worker(c):
-            while True:
-                with lock:
-                    j = nxt[0]
-                    if j >= first + count:
-                        return
-                    nxt[0] += 1
-                try:
-                    proof, inst, tm = pk.prove(inputs[j % 4], seeds[j % len(seeds)], ctx=c)
-                except Exception as e:  # noqa: BLE001
-                    errs.append(e)
-                    return
-                with lock:
-                    stage[:] += np.array(tm)
-                    proof_len[0] = len(proof)
-        ths = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        if errs:
-            raise errs[0]
-
-    # warm-up: every stream proves at least once (allocates its workspace), then W more proofs
-    run_jobs(0, n_streams)
-    run_jobs(n_streams, args.warmup)
+    # warm-up: every stream proves once (allocates its workspace), then W more proofs
+    batch.run_concurrent(list(range(n_streams)), ctxs, one_proof)
+    batch.run_concurrent(list(range(n_streams, n_streams + args.warmup)), ctxs, one_proof)
     stage[:] = 0
     si = n_streams + args.warmup
     barrier()
     t0 = time.perf_counter()
-    run_jobs(si, args.steps)
+    batch.run_concurrent(list(range(si, si + args.steps)), ctxs, one_proof)   # exactly K proofs, n_streams in flight
     for c in ctxs:
         c.sync()
     barrier()
     dt = time.perf_counter() - t0
     si += args.steps
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = batch.max_over_ranks(dt, device="cuda" if world > 1 else None)
     stage /= max(1, args.steps)
 
     # dominant kernel (k_msm_accumulate) timed live with HIP events on the library's stream, in a separate untimed pass

@@ -1,0 +1,76 @@
+"""Batches of independent proofs over the GPUs of one node (BASELINE config 3).
+
+Proofs are independent objects: proof i goes to rank i mod W (one process per GPU), inside a rank the proofs run
+concurrently on several contexts (HIP streams) against one proving key.  There is NO data-path collective; the only
+communication is collecting the <= 62 KB proofs (all_gather_object) and the max-over-ranks of the wall time.
+Works with the gloo backend on CPU (tests) and nccl (= RCCL) on GPUs.
+"""
+import threading
+
+
+def shard_indices(n_items, rank, world):
+    """proof i -> rank i mod world"""
+    return list(range(rank, n_items, world))
+
+
+def run_concurrent(jobs, workers, fn):
+    """Run fn(worker, job) for every job, `len(workers)` at a time (one thread per worker, jobs pulled from a shared
+    counter).  Returns results in job order; the first exception is re-raised."""
+    results = [None] * len(jobs)
+    lock = threading.Lock()
+    nxt = [0]
+    errs = []
+
+    def loop(w):
+        while True:
+            with lock:
+                j = nxt[0]
+                if j >= len(jobs) or errs:
+                    return
+                nxt[0] += 1
+            try:
+                results[j] = fn(w, jobs[j])
+            except Exception as e:  # noqa: BLE001
+                with lock:
+                    errs.append(e)
+                return
+    ths = [threading.Thread(target=loop, args=(w,)) for w in workers]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return results
+
+
+def prove_batch(pk, inputs, seeds, contexts):
+    """All proofs of this rank: inputs[i] (JSON text), seeds[i]; `contexts` = zk.Context objects of this rank's GPU."""
+    return run_concurrent(list(range(len(inputs))), contexts, lambda c, i: pk.prove(inputs[i], seeds[i], ctx=c)[0])
+
+
+def gather_proofs(local, n_items, rank, world):
+    """local: {global index: proof bytes} of this rank -> list of all n_items proofs (on every rank)."""
+    if world == 1:
+        return [local[i] for i in range(n_items)]
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, local)
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    missing = [i for i in range(n_items) if i not in merged]
+    if missing:
+        raise RuntimeError("proofs missing after gather: %s" % missing[:8])
+    return [merged[i] for i in range(n_items)]
+
+
+def max_over_ranks(seconds, device=None):
+    """Wall time of the slowest rank (what bench.py reports)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
