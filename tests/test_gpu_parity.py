@@ -120,7 +120,7 @@ def test_ntt_k13_batch_properties(ctx):
     assert np.array_equal(ctx.ntt(s[None], log_n, False)[0], orc.fe_binop("add", f[0], f[1]))
 
 
-@pytest.mark.parametrize("log_n,lef", [(4, 2), (7, 1), (10, 3), (13, 2)])
+@pytest.mark.parametrize("log_n,lef", [(4, 2), (7, 1), (10, 3), (13, 2), (14, 2), (15, 1)])
 def test_coset_ntt(ctx, log_n, lef):
     rng = np.random.default_rng(log_n * 10 + lef)
     n, E = 1 << log_n, 1 << lef

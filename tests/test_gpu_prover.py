@@ -120,3 +120,24 @@ def test_concurrent_proofs_on_two_streams(ctx):
     pk.destroy()
     srs.destroy()
     ctx2.close()
+
+
+def test_k14_proof_bytes_match_oracle(ctx):
+    """A circuit with more rows than one NTT tile (k = 14 > 13): exercises the long-row NTT / coset paths in the prover."""
+    import zk_fhe_amd as zk
+    prm = C.BfvParams(N=16)
+    inp = synth_input(16, prm.Q, prm.T, prm.B, 5)
+    circ = H.BfvCircuit(inp, prm)
+    hcfg = H.auto_config(14, 109, circ)
+    srs_o = H.make_srs(14)
+    pk_o, _ = H.keygen_circuit(hcfg, circ, srs_o)
+    proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, circ, b"k14")
+    assert H.verify(H.VerifyingKey(pk_o), srs_o, inst_o, proof_o)
+    srs = zk.Srs(ctx, 14)
+    pk = zk.BfvProvingKey(ctx, srs, json.dumps(inp), (16, prm.Q, prm.T, prm.B),
+                          zk.BfvConfig(14, hcfg.n_gate0, hcfg.n_gate1, hcfg.n_lookup, hcfg.n_rlc, 109))
+    assert pk.info()["vk_digest"] == pk_o.vk_digest
+    proof, inst, _ = pk.prove(json.dumps(inp), b"k14")
+    assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
+    pk.destroy()
+    srs.destroy()

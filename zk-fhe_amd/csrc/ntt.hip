@@ -90,6 +90,17 @@ __global__ void __launch_bounds__(256) k_pow_table_scaled(Fr start, Fr base, Fr 
 // coefficient i1*n + i2 = g^-(i1*n+i2) * 2^-lef * sum_k1 A[k1][i2] * w_ext^(-k1 (i1*n + i2))
 //                       = scale[i1*n+i2] * sum_k1 (A[k1][i2] * w_ext^(-k1 i2)) * w_E^(-k1 i1),  E = 2^lef.
 // LEF in {1,2,3}.
+// large-n forward coset extension, step 1: out[c][k1][i] = in[c][i] * pre[k1][i]
+__global__ void __launch_bounds__(256) k_coset_prescale(const Fr *__restrict__ in, const Fr *__restrict__ pre, Fr *__restrict__ out, size_t n_cols,
+                                                        int log_n, int lef) {
+  const size_t n = (size_t)1 << log_n, ne = n << lef;
+  const size_t total = n_cols * ne;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = g / ne, r = g - c * ne, i = r & (n - 1);
+    out[g] = in[c * n + i] * pre[r];
+  }
+}
+
 template <int LEF>
 __global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows, Fr *__restrict__ out, size_t n_cols, int log_n,
                                                      const Fr *__restrict__ tw_ext_inv /* w_ext^-j, j < n*E */,
@@ -266,7 +277,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
 
 int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n,
                           int log_ext_factor, const zkfhe_fr *g_host, int inverse) {
-  ZK_ARG(ctx, log_n >= 3 && log_n <= MAX_TILE_LOG);
+  ZK_ARG(ctx, log_n >= 3 && log_n + log_ext_factor <= 26);
   ZK_ARG(ctx, log_ext_factor >= 1 && log_ext_factor <= 3);
   ZK_ARG(ctx, g_host != nullptr);
   if (!n_cols) return ZKFHE_OK;
@@ -292,6 +303,15 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * edom->omega;
     }
+    if (log_n > MAX_TILE_LOG) {
+      // rows longer than one tile: pre-scale into the output rows, then a batched size-n NTT over all (column, k1) rows
+      unsigned gr = zk_blocks(n_cols * ne, 256);
+      const unsigned capg = (unsigned)ctx->num_cu * 16;
+      if (gr > capg) gr = capg;
+      k_coset_prescale<<<gr, 256, 0, ctx->stream>>>((const Fr *)in_dev, pre, (Fr *)out_dev, n_cols, log_n, lef);
+      ZK_LAUNCH_CHECK(ctx);
+      return zkfhe_ntt_batch(ctx, out_dev, n_cols * E, log_n, 0);
+    }
     TileArgs a{};
     a.in = (const Fr *)in_dev;
     a.out = (Fr *)out_dev;
@@ -308,6 +328,30 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     return launch_tile_dyn(ctx, log_n, a, (unsigned)E, (unsigned)n_cols);
   }
   // inverse: rows iNTT (size n, scaled by n^-1) into scratch, then combine across k1
+  if (log_n > MAX_TILE_LOG) {
+    // zkfhe_ntt_batch uses scratch slot 0 itself for long rows: stage the rows in the OUTPUT buffer, transform them
+    // there, then combine through slot 2
+    ZK_HIP(ctx, hipMemcpyAsync(out_dev, in_dev, n_cols * ne * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    rc = zkfhe_ntt_batch(ctx, out_dev, n_cols * E, log_n, 1);
+    if (rc) return rc;
+    rc = zk_scratch(ctx, 2, n_cols * ne * sizeof(Fr), &p);
+    if (rc) return rc;
+    Fr *rows2 = (Fr *)p;
+    ZK_HIP(ctx, hipMemcpyAsync(rows2, out_dev, n_cols * ne * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
+    if (rc) return rc;
+    Fr *scale2 = (Fr *)p;
+    const Fr einv2 = fp_inv<FrP>(zk_fr_from_u64((uint64_t)E));
+    const Fr ginv2 = fp_inv<FrP>(g);
+    k_pow_table_scaled<<<zk_blocks(ne, 256), 256, 0, ctx->stream>>>(einv2, ginv2, scale2, ne);
+    ZK_LAUNCH_CHECK(ctx);
+    unsigned grid2 = zk_blocks(n_cols * n, 256);
+    if (lef == 1) k_ext_combine<1><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv, scale2);
+    else if (lef == 2) k_ext_combine<2><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv, scale2);
+    else k_ext_combine<3><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv, scale2);
+    ZK_LAUNCH_CHECK(ctx);
+    return ZKFHE_OK;
+  }
   rc = zk_scratch(ctx, 0, n_cols * ne * sizeof(Fr), &p);
   if (rc) return rc;
   Fr *rows = (Fr *)p;
