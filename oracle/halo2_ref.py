@@ -197,6 +197,20 @@ def make_srs(k, seed=b"zkfhe-unsafe-srs"):
     return {"k": k, "s": s, "g": g, "g_lagrange": g_lagrange, "s_g2": PR.ec_mul(PR.G2_GEN, s)}
 
 
+def srs_verifier_half(k, seed=b"zkfhe-unsafe-srs"):
+    """Only what verify() needs from the SRS (s*G2): skips the 2 * 2^k G1 scalar multiplications."""
+    s = from_bytes_wide(hashlib.blake2b(bytes(seed), digest_size=64, person=b"zkfhe-srs").digest())
+    return {"k": k, "s": s, "s_g2": PR.ec_mul(PR.G2_GEN, s)}
+
+
+class RawVerifyingKey:
+    """A verifying key assembled from commitments computed elsewhere (e.g. by the GPU keygen)."""
+
+    def __init__(self, cfg, fixed_commit, sigma_commit, vk_digest):
+        self.cfg, self.omega = cfg, pyref.root_of_unity(cfg.k)
+        self.fixed_commit, self.sigma_commit, self.vk_digest = fixed_commit, sigma_commit, vk_digest
+
+
 # ----------------------------------------------------------------------------------------- assignment
 class Assignment:
     pass

@@ -141,3 +141,60 @@ def test_k14_proof_bytes_match_oracle(ctx):
     assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
     pk.destroy()
     srs.destroy()
+
+
+def test_config4_k16_n4096_60bit_modulus(ctx):
+    """BASELINE config 4: N = 4096, 60-bit Q (witness values up to 132 bits), k = 16.  The CPU oracle prover would take
+    minutes at this size, so the check is: the GPU proof is accepted by the oracle VERIFIER (pairing check) against the
+    commitments of the GPU keygen, and a tampered proof is not."""
+    import numpy as np
+    import zk_fhe_amd as zk
+    N, Q, T, B = 4096, (1 << 60) - 93, 7, 19
+    rng = np.random.default_rng(4)
+    pk0 = rng.integers(0, Q, N, dtype=np.int64)
+    pk1 = rng.integers(0, Q, N, dtype=np.int64)
+    u = rng.choice(np.array([0, 1, -1], dtype=np.int64), N)
+    m = rng.choice(np.array([0, 1, 2, 3, -1, -2, -3], dtype=np.int64), N)
+    e = np.clip(np.rint(rng.normal(0, 3.2, (2, N))), -B, B).astype(np.int64)
+
+    def negacyclic_pm1(a, s):  # a * s in Z_Q[x]/(x^N+1), s in {0,+1,-1}; big-endian in and out
+        a, s = a[::-1], s[::-1]
+        out = np.zeros(N, dtype=np.int64)
+        for i in np.nonzero(s)[0]:
+            sh = np.empty(N, dtype=np.int64)
+            sh[i:] = a[: N - i]
+            sh[:i] = (Q - a[N - i:]) % Q
+            out = (out + (sh if s[i] == 1 else (Q - sh) % Q)) % Q
+        return out[::-1]
+    delta = Q // T
+    md = np.array([(int(x) % Q) * delta % Q for x in m], dtype=np.int64)
+    c0 = (negacyclic_pm1(pk0, u) + md) % Q
+    c0 = (c0 + e[0] % Q) % Q
+    c1 = (negacyclic_pm1(pk1, u) + e[1] % Q) % Q
+    s = lambda v: [str(int(x) % Q) for x in v]  # noqa: E731
+    inp = dict(pk0=s(pk0), pk1=s(pk1), m=s(m), u=s(u), e0=s(e[0]), e1=s(e[1]), c0=s(c0), c1=s(c1), cyclo=s([1] + [0] * (N - 1) + [1]))
+    text = json.dumps(inp)
+    # column counts: place the circuit with generous limits and count the break points (halo2-base auto-configuration)
+    probe = zk.bfv_build_tables(text, (N, Q, T, B), zk.BfvConfig(16, 8, 400, 120, 16, 109), 1, keygen_mode=False)
+    n0, n1, nr = (len(probe["break_points"][k]) + 1 for k in ("gate0", "gate1", "rlc"))
+    nl = -(-probe["lookups"] // ((1 << 16) - 109))
+    print("config 4 columns: gate", n0, n1, "lookup", nl, "rlc", nr, "cells", probe["cells"])
+    zcfg = zk.BfvConfig(16, n0, n1, nl, nr, 109)
+    srs = zk.Srs(ctx, 16)
+    pk = zk.BfvProvingKey(ctx, srs, text, (N, Q, T, B), zcfg)
+    info = pk.info()
+    proof, inst, tm = pk.prove(text, b"config4")
+    print("config 4 prove timings ms [witness, commit, quotient, open, total]:", tm, "proof bytes", len(proof))
+    assert len(inst) == 4 * N + N + 1
+    hcfg = H.Config(16, n0, n1, nl, nr, 109)
+    vk = H.RawVerifyingKey(hcfg, info["fixed_commit"], info["sigma_commit"], info["vk_digest"])
+    srs_v = H.srs_verifier_half(16)
+    assert H.verify(vk, srs_v, inst, proof)
+    bad = bytearray(proof)
+    bad[-40] ^= 1
+    try:
+        assert not H.verify(vk, srs_v, inst, bytes(bad))
+    except AssertionError:
+        pass
+    pk.destroy()
+    srs.destroy()
