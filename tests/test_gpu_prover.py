@@ -143,13 +143,12 @@ def test_k14_proof_bytes_match_oracle(ctx):
     srs.destroy()
 
 
-def test_config4_k16_n4096_60bit_modulus(ctx):
-    """BASELINE config 4: N = 4096, 60-bit Q (witness values up to 132 bits), k = 16.  The CPU oracle prover would take
-    minutes at this size, so the check is: the GPU proof is accepted by the oracle VERIFIER (pairing check) against the
-    commitments of the GPU keygen, and a tampered proof is not."""
+def _prove_and_verify_large(ctx, N, k, tag):
+    """Large configurations: the CPU oracle prover would take minutes, so the check is: the GPU proof is accepted by the
+    oracle VERIFIER (pairing check) against the commitments of the GPU keygen, and a tampered proof is not."""
     import numpy as np
     import zk_fhe_amd as zk
-    N, Q, T, B = 4096, (1 << 60) - 93, 7, 19
+    Q, T, B = (1 << 60) - 93, 7, 19
     rng = np.random.default_rng(4)
     pk0 = rng.integers(0, Q, N, dtype=np.int64)
     pk1 = rng.integers(0, Q, N, dtype=np.int64)
@@ -175,20 +174,20 @@ def test_config4_k16_n4096_60bit_modulus(ctx):
     inp = dict(pk0=s(pk0), pk1=s(pk1), m=s(m), u=s(u), e0=s(e[0]), e1=s(e[1]), c0=s(c0), c1=s(c1), cyclo=s([1] + [0] * (N - 1) + [1]))
     text = json.dumps(inp)
     # column counts: place the circuit with generous limits and count the break points (halo2-base auto-configuration)
-    probe = zk.bfv_build_tables(text, (N, Q, T, B), zk.BfvConfig(16, 8, 400, 120, 16, 109), 1, keygen_mode=False)
+    probe = zk.bfv_build_tables(text, (N, Q, T, B), zk.BfvConfig(k, 8, 400, 120, 16, 109), 1, keygen_mode=False)
     n0, n1, nr = (len(probe["break_points"][k]) + 1 for k in ("gate0", "gate1", "rlc"))
-    nl = -(-probe["lookups"] // ((1 << 16) - 109))
-    print("config 4 columns: gate", n0, n1, "lookup", nl, "rlc", nr, "cells", probe["cells"])
-    zcfg = zk.BfvConfig(16, n0, n1, nl, nr, 109)
-    srs = zk.Srs(ctx, 16)
+    nl = -(-probe["lookups"] // ((1 << k) - 109))
+    print(tag, "columns: gate", n0, n1, "lookup", nl, "rlc", nr, "cells", probe["cells"])
+    zcfg = zk.BfvConfig(k, n0, n1, nl, nr, 109)
+    srs = zk.Srs(ctx, k)
     pk = zk.BfvProvingKey(ctx, srs, text, (N, Q, T, B), zcfg)
     info = pk.info()
-    proof, inst, tm = pk.prove(text, b"config4")
-    print("config 4 prove timings ms [witness, commit, quotient, open, total]:", tm, "proof bytes", len(proof))
+    proof, inst, tm = pk.prove(text, tag.encode())
+    print(tag, "prove timings ms [witness, commit, quotient, open, total]:", tm, "proof bytes", len(proof))
     assert len(inst) == 4 * N + N + 1
-    hcfg = H.Config(16, n0, n1, nl, nr, 109)
+    hcfg = H.Config(k, n0, n1, nl, nr, 109)
     vk = H.RawVerifyingKey(hcfg, info["fixed_commit"], info["sigma_commit"], info["vk_digest"])
-    srs_v = H.srs_verifier_half(16)
+    srs_v = H.srs_verifier_half(k)
     assert H.verify(vk, srs_v, inst, proof)
     bad = bytearray(proof)
     bad[-40] ^= 1
@@ -198,3 +197,16 @@ def test_config4_k16_n4096_60bit_modulus(ctx):
         pass
     pk.destroy()
     srs.destroy()
+    return (n0, n1, nl, nr), probe["cells"]
+
+
+def test_config4_k16_n4096_60bit_modulus(ctx):
+    """BASELINE config 4: N = 4096, 60-bit Q (witness values up to 132 bits), k = 16."""
+    cols, cells = _prove_and_verify_large(ctx, 4096, 16, "config4")
+    assert cols == (2, 124, 34, 3) and cells[1] == 8073420     # the shape SURVEY.md section 8d predicts
+
+
+def test_config5_k19_n16384(ctx):
+    """BASELINE config 5: N = 16384, k = 19 (n = 524288 rows): MSM-dominated, long-row NTTs everywhere."""
+    cols, cells = _prove_and_verify_large(ctx, 16384, 19, "config5")
+    assert cols[1] <= 64

@@ -491,7 +491,7 @@ class BfvProvingKey:
         cap = 1 << 20
         buf = ctypes.create_string_buffer(cap)
         plen = ctypes.c_size_t()
-        ninst = ctypes.c_size_t(1 << 16)
+        ninst = ctypes.c_size_t(1 << 20)
         ibuf = ctypes.create_string_buffer(32 * ninst.value)
         tm = (ctypes.c_float * 5)()
         ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, input_json_text.encode(), seed, buf, cap, ctypes.byref(plen),
