@@ -185,6 +185,17 @@ int zkfhe_bfv_pk_info(const zkfhe_bfv_pk *pk, uint8_t vk_digest[32], uint32_t *n
 int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t *sigma_out);
 int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count);
 
+/* Serialised verifying key: magic "ZKFHEVK1", 7 x u32 configuration, u32 n_fixed, u32 n_sigma, 32-byte vk digest, then
+ * the fixed and sigma commitments as canonical affine x||y (64 B each).  What `keygen` writes to data/<name>.vk. */
+int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, size_t *len);
+
+/* verify (README.md:48-52), host CPU only (no GPU, like the reference's verifier): replays the transcript, checks the
+ * quotient identity at x, and ends in one BN254 pairing-product check.  instances: n_instances canonical 32-byte LE
+ * scalars.  srs_seed: the seed the (unsafe, test) SRS was derived from.  *accepted = 1 iff the proof verifies; a
+ * malformed proof is reported as accepted = 0 with the reason in err. */
+int zkfhe_bfv_verify(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof,
+                     size_t proof_len, const uint8_t *srs_seed, size_t seed_len, int *accepted, char *err, size_t err_len);
+
 /* prove (README.md:42-44): witness generation + create_proof.  seed: 32 bytes for the blinding stream.
  * proof_out must hold proof_cap bytes; *proof_len receives the length.  instances_out (may be NULL): canonical
  * 32-byte LE scalars, *n_instances in/out.  timings_ms (may be NULL): [witness, commit, quotient, open, total]. */

@@ -87,6 +87,8 @@ def test_bfv_in_k13_proof_bytes_match_oracle(ctx):
     pk_o, _ = H.keygen_circuit(hcfg, H.BfvCircuit(json.loads(text_empty), prm), srs_o, bp)
     assert info["vk_digest"] == pk_o.vk_digest
     assert H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof), "oracle verifier (pairing check) rejects the GPU proof"
+    ok, why = zk.bfv_verify(pk.export_vk(), inst, proof)   # the product's own C++ verifier (host CPU)
+    assert ok, why
     proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, H.BfvCircuit(json.loads(text), prm), b"seed-1")
     assert inst == inst_o
     assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)

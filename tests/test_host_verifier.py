@@ -1,0 +1,45 @@
+"""The C++ verifier behind zkfhe_bfv_verify (host CPU, pairing check) against proofs made by the oracle prover.
+CPU only.  (GPU-made proofs are checked by both verifiers in tests/test_gpu_prover.py.)"""
+import pytest
+
+import zk_fhe_amd as zk
+from oracle import circuit_ref as C
+from oracle import halo2_ref as H
+from tests.test_proof_oracle import synth_input
+
+
+@pytest.fixture(scope="module")
+def toy():
+    prm = C.BfvParams(N=8)
+    inp = synth_input(8, prm.Q, prm.T, prm.B, 1)
+    circ = H.BfvCircuit(inp, prm)
+    cfg = H.auto_config(9, 9, circ)
+    srs = H.make_srs(9)
+    pk, _ = H.keygen_circuit(cfg, circ, srs)
+    proof, inst = H.prove(cfg, pk, srs, circ, b"seed-v")
+    vkb = zk.make_vk_bytes(cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits,
+                           pk.vk_digest, pk.fixed_commit, pk.sigma_commit)
+    return vkb, inst, proof
+
+
+def test_accepts_oracle_proof(toy):
+    vkb, inst, proof = toy
+    ok, why = zk.bfv_verify(vkb, inst, proof)
+    assert ok, why
+
+
+def test_rejects_tampering(toy):
+    vkb, inst, proof = toy
+    for pos in (40, len(proof) // 2, len(proof) - 40, len(proof) - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        ok, _ = zk.bfv_verify(vkb, inst, bytes(bad))
+        assert not ok
+    inst2 = list(inst)
+    inst2[0] = (inst2[0] + 1) % H.R
+    assert not zk.bfv_verify(vkb, inst2, proof)[0]
+    assert not zk.bfv_verify(vkb, inst, proof[:-32])[0]
+    assert not zk.bfv_verify(vkb, inst, proof, srs_seed=b"another-srs")[0]
+    vk2 = bytearray(vkb)
+    vk2[100] ^= 1
+    assert not zk.bfv_verify(bytes(vk2), inst, proof)[0]

@@ -30,7 +30,7 @@ EXPORTS = [
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points",
     "zkfhe_srs_create", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
-    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_verify",
     "zkfhe_version",
 ]
 
@@ -500,7 +500,41 @@ class BfvProvingKey:
         inst = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(ninst.value)]
         return buf.raw[: plen.value], inst, list(tm)
 
+    def export_vk(self):
+        lib = self.ctx.lib
+        lib.zkfhe_bfv_pk_export_vk.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        n = ctypes.c_size_t()
+        lib.zkfhe_bfv_pk_export_vk(self.h, None, 0, ctypes.byref(n))
+        buf = ctypes.create_string_buffer(n.value)
+        self.ctx._check(lib.zkfhe_bfv_pk_export_vk(self.h, buf, n.value, ctypes.byref(n)))
+        return buf.raw
+
     def destroy(self):
         if self.h:
             self.ctx.lib.zkfhe_bfv_pk_destroy(self.ctx.h, self.h)
             self.h = None
+
+
+def make_vk_bytes(k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits, vk_digest, fixed_commit, sigma_commit):
+    """Serialise a verifying key (same layout as zkfhe_bfv_pk_export_vk) from python values; points are (x, y) or None."""
+    import struct
+    out = b"ZKFHEVK1" + struct.pack("<9I", k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits, len(fixed_commit), len(sigma_commit))
+    out += int(vk_digest).to_bytes(32, "little")
+    for p in list(fixed_commit) + list(sigma_commit):
+        x, y = (0, 0) if p is None else p
+        out += int(x).to_bytes(32, "little") + int(y).to_bytes(32, "little")
+    return out
+
+
+def bfv_verify(vk_bytes, instances, proof, srs_seed=b"zkfhe-unsafe-srs"):
+    """Host-only verifier (C++: transcript replay, quotient identity, one pairing-product check). Returns (accepted, reason)."""
+    lib = load_library()
+    lib.zkfhe_bfv_verify.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                     ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]
+    inst = b"".join(int(v).to_bytes(32, "little") for v in instances)
+    ok = ctypes.c_int(0)
+    err = ctypes.create_string_buffer(256)
+    rc = lib.zkfhe_bfv_verify(vk_bytes, len(vk_bytes), inst, len(instances), proof, len(proof), bytes(srs_seed), len(srs_seed), ctypes.byref(ok), err, 256)
+    if rc != 0:
+        raise ZkfheError("zkfhe_bfv_verify: bad arguments (%d)" % rc)
+    return bool(ok.value), err.value.decode()

@@ -1,7 +1,8 @@
 // `bfv` -- command-line driver with the reference's surface (README.md:18-52; clap `Cli` of halo2-scaffold,
 // examples/bfv.rs:306-312):   bfv --name bfv -k 13 --input bfv/bfv.in {mock|keygen|prove|verify}
 // Files: reads data/<input>, configs/<name>.json (prove); writes configs/<name>.json (keygen), data/<name>.snark (prove).
-// The proving key is rebuilt in memory by `prove` (on-disk pk/vk formats: SURVEY.md section 8f, next).
+// keygen also writes data/<name>.vk; `verify` reads it with the snark on the host CPU.  The proving key is rebuilt in
+// memory by `prove` (an on-disk pk is section 8f work: it is 95 MB of columns that keygen recomputes in < 1 s).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -169,9 +170,34 @@ int main(int argc, char **argv) {
     zkfhe_bfv_tables_free(t);
     return 0;
   }
+  const char *seed = "zkfhe-unsafe-srs";
   if (cmd == "verify") {
-    fprintf(stderr, "verify: the C++ verifier is not built yet (SURVEY.md 8f); use oracle/halo2_ref.py verify (pairing check)\n");
-    return 3;
+    // README.md:48-52: reads data/<name>.vk and data/<name>.snark (host CPU only, no GPU needed)
+    const std::string vk = slurp(data_path + "/" + name + ".vk"), sn = slurp(data_path + "/" + name + ".snark");
+    if (sn.size() < 16 || memcmp(sn.data(), "ZKFHESN1", 8)) {
+      fprintf(stderr, "%s/%s.snark is not a zkfhe snark file\n", data_path.c_str(), name.c_str());
+      return 1;
+    }
+    uint64_t ninst = 0;
+    memcpy(&ninst, sn.data() + 8, 8);
+    if (sn.size() < 16 + 32 * ninst) {
+      fprintf(stderr, "snark file truncated\n");
+      return 1;
+    }
+    const uint8_t *inst = (const uint8_t *)sn.data() + 16, *proof = inst + 32 * ninst;
+    const size_t proof_len = sn.size() - 16 - 32 * ninst;
+    int ok = 0;
+    char err[256] = {0};
+    auto t0 = std::chrono::steady_clock::now();
+    zkfhe_bfv_verify((const uint8_t *)vk.data(), vk.size(), inst, (size_t)ninst, proof, proof_len, (const uint8_t *)seed, strlen(seed), &ok, err,
+                     sizeof(err));
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!ok) {
+      fprintf(stderr, "Snark verification FAILED%s%s\n", err[0] ? ": " : "", err);
+      return 1;
+    }
+    printf("Snark verified successfully in %.3fms\n", ms);
+    return 0;
   }
   zkfhe_ctx *ctx = nullptr;
   if (zkfhe_ctx_create(0, nullptr, &ctx)) {
@@ -179,7 +205,6 @@ int main(int argc, char **argv) {
     return 1;
   }
   zkfhe_srs *srs = nullptr;
-  const char *seed = "zkfhe-unsafe-srs";
   CHECK(zkfhe_srs_create(ctx, k, (const uint8_t *)seed, strlen(seed), &srs));
   zkfhe_bfv_pk *pk = nullptr;
   if (cmd == "keygen") {
@@ -202,7 +227,12 @@ int main(int argc, char **argv) {
     write_pinning(pin_path, c, bp);
     uint8_t d[32];
     zkfhe_bfv_pk_info(pk, d, nullptr, nullptr);
-    printf("keygen done; pinning written to %s; vk digest ", pin_path.c_str());
+    size_t vlen = 0;
+    zkfhe_bfv_pk_export_vk(pk, nullptr, 0, &vlen);
+    std::vector<uint8_t> vkb(vlen);
+    CHECK(zkfhe_bfv_pk_export_vk(pk, vkb.data(), vkb.size(), &vlen));
+    std::ofstream(data_path + "/" + name + ".vk", std::ios::binary).write((const char *)vkb.data(), (std::streamsize)vlen);
+    printf("keygen done; pinning written to %s, verifying key to %s/%s.vk; vk digest ", pin_path.c_str(), data_path.c_str(), name.c_str());
     for (int i = 31; i >= 0; --i) printf("%02x", d[i]);
     printf("\n");
   } else {
@@ -218,8 +248,8 @@ int main(int argc, char **argv) {
         empty.replace(i + 1, j - i - 1, "0");
       }
     CHECK(zkfhe_bfv_keygen(ctx, srs, empty.c_str(), &prm, &pin.c, &pk));
-    std::vector<uint8_t> proof(1 << 20);
-    size_t len = 0, ninst = 0;
+    std::vector<uint8_t> proof(1 << 20), instb((size_t)32 << 20);
+    size_t len = 0, ninst = instb.size() / 32;
     uint8_t seed32[32] = {0};
     FILE *ur = fopen("/dev/urandom", "rb");
     if (ur) {
@@ -228,9 +258,17 @@ int main(int argc, char **argv) {
     }
     float tm[5];
     auto t0 = std::chrono::steady_clock::now();
-    CHECK(zkfhe_bfv_prove(ctx, srs, pk, text.c_str(), seed32, proof.data(), proof.size(), &len, nullptr, &ninst, tm));
+    CHECK(zkfhe_bfv_prove(ctx, srs, pk, text.c_str(), seed32, proof.data(), proof.size(), &len, instb.data(), &ninst, tm));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::ofstream(data_path + "/" + name + ".snark", std::ios::binary).write((const char *)proof.data(), (std::streamsize)len);
+    {
+      // data/<name>.snark = "ZKFHESN1" | u64 n_instances | instances (32 B LE each) | proof bytes
+      std::ofstream f(data_path + "/" + name + ".snark", std::ios::binary);
+      const uint64_t n64 = ninst;
+      f.write("ZKFHESN1", 8);
+      f.write((const char *)&n64, 8);
+      f.write((const char *)instb.data(), (std::streamsize)(32 * ninst));
+      f.write((const char *)proof.data(), (std::streamsize)len);
+    }
     printf("Proving time: %.3fms  (witness %.1f, commit %.1f, quotient %.1f, open %.1f)\n", ms, tm[0], tm[1], tm[2], tm[3]);
     printf("proof: %zu bytes, %zu public inputs -> %s/%s.snark\n", len, ninst, data_path.c_str(), name.c_str());
   }

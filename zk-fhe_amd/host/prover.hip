@@ -1015,6 +1015,31 @@ int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t
   return ZKFHE_OK;
 }
 
+int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, size_t *len) {
+  if (!pk || !len) return ZKFHE_EINVAL;
+  const size_t nf = pk->fixed_commit.size(), ns = pk->sigma_commit.size();
+  const size_t need = 8 + 36 + 32 + 64 * (nf + ns);
+  *len = need;
+  if (!out || cap < need) return out ? ZKFHE_EINVAL : ZKFHE_OK;
+  memcpy(out, "ZKFHEVK1", 8);
+  const uint32_t hdr[9] = {pk->cfg.k, pk->cfg.n_gate0, pk->cfg.n_gate1, pk->cfg.n_lookup, pk->cfg.n_rlc, pk->cfg.unusable_rows,
+                           pk->cfg.lookup_bits, (uint32_t)nf, (uint32_t)ns};
+  memcpy(out + 8, hdr, 36);
+  memcpy(out + 44, pk->vk_digest.l, 32);
+  uint8_t *p = out + 76;
+  for (const auto &c : pk->fixed_commit) {
+    memcpy(p, c.x.l, 32);
+    memcpy(p + 32, c.y.l, 32);
+    p += 64;
+  }
+  for (const auto &c : pk->sigma_commit) {
+    memcpy(p, c.x.l, 32);
+    memcpy(p + 32, c.y.l, 32);
+    p += 64;
+  }
+  return ZKFHE_OK;
+}
+
 int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count) {
   if (!pk || !count) return ZKFHE_EINVAL;
   const auto &v = which == 0 ? pk->cfg.bp_gate0 : which == 1 ? pk->cfg.bp_gate1 : pk->cfg.bp_rlc;
