@@ -73,3 +73,36 @@ def test_run_concurrent_propagates_errors():
         return j
     with pytest.raises(ValueError):
         B.run_concurrent(list(range(8)), ["a", "b"], fn)
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = bytes([rank]) * 64 * 3          # three 64-byte "points" per rank
+    parts = B.all_gather_bytes(local, world)
+    if rank == 1:
+        out.put(parts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_bytes_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    parts = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert parts == [bytes([0]) * 192, bytes([1]) * 192]
+
+
+def test_point_ranges_partition():
+    for n, w in ((524288, 8), (8192, 3), (10, 4)):
+        rs = [B.point_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))

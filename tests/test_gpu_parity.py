@@ -211,3 +211,29 @@ def test_witness_kernels(ctx):
     q60 = (1 << 60) - 93
     assert orc.mont_to_ints(d) == [v // q60 for v in [(1 << 128) - 1, 0, Q, Q - 1, (1 << 127) + 12345]]
     assert orc.mont_to_ints(r) == [v % q60 for v in [(1 << 128) - 1, 0, Q, Q - 1, (1 << 127) + 12345]]
+
+
+def test_msm_point_range_sharding(ctx):
+    """an MSM split by point range into per-"rank" partial MSMs, partials added -> the full MSM.
+    (One GPU here: the ranks are emulated sequentially; the byte all-gather itself is covered by the gloo test.)"""
+    import zk_fhe_amd as zk
+    import zk_fhe_amd.batch as B
+    rng = np.random.default_rng(77)
+    n, n_cols, world = 4096, 3, 4
+    bases = _bases(n, seed=5)
+    S = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    want = orc.msm(S, bases)
+    parts = []
+    for r in range(world):
+        lo, hi = B.point_range(n, r, world)
+        b = zk.Basis(ctx, bases[lo:hi])
+        parts.append(ctx.msm(b, np.ascontiguousarray(S[:, lo:hi])))
+        b.destroy()
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = ctx.g1_add(acc, p)
+    assert np.array_equal(acc, want)
+    # world = 1 path of the class
+    full = zk.Basis(ctx, bases)
+    assert np.array_equal(B.ShardedMsm(ctx, full, 0, 1).msm(S), want)
+    full.destroy()

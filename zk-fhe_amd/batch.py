@@ -74,3 +74,45 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# One huge MSM split over the GPUs of a node (BASELINE config 5): rank r owns the point range
+# [r*n/W, (r+1)*n/W) of the basis (its own per-window table) and the matching scalars; a partial MSM is a group
+# element, so  sum_r partial_r  is the MSM.  EC addition is not an RCCL reduction op: the 64-byte affine partials
+# are all-gathered as raw bytes (n_cols * 64 B per rank -- latency-bound on xGMI) and every rank adds them locally.
+def point_range(n, rank, world):
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi
+
+
+def all_gather_bytes(local, world, device=None):
+    """local: bytes of equal length on every rank -> list of `world` byte strings (uint8 all_gather; gloo or nccl)."""
+    if world == 1:
+        return [bytes(local)]
+    import torch
+    import torch.distributed as dist
+    t = torch.frombuffer(bytearray(local), dtype=torch.uint8)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [bytes(o.cpu().numpy().tobytes()) for o in out]
+
+
+class ShardedMsm:
+    """basis_slice: zk.Basis built from this rank's point range; combine() adds the gathered partials on the GPU."""
+
+    def __init__(self, ctx, basis_slice, rank, world, device=None):
+        self.ctx, self.basis, self.rank, self.world, self.device = ctx, basis_slice, rank, world, device
+
+    def msm(self, scalars_slice):
+        """scalars_slice: (n_cols, n_local, 4) Montgomery Fr of this rank's range -> (n_cols, 8) affine result (every rank)."""
+        import numpy as np
+        part = self.ctx.msm(self.basis, scalars_slice)
+        parts = all_gather_bytes(part.tobytes(), self.world, self.device)
+        acc = np.frombuffer(parts[0], dtype=np.uint64).reshape(-1, 8).copy()
+        for p in parts[1:]:
+            acc = self.ctx.g1_add(acc, np.frombuffer(p, dtype=np.uint64).reshape(-1, 8))
+        return acc
