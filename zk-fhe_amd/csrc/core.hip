@@ -88,6 +88,7 @@ int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
 }
 
 int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return ZKFHE_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
@@ -107,6 +108,7 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
 const char *zkfhe_last_error(const zkfhe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int zkfhe_sync(zkfhe_ctx *ctx) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKFHE_OK;
 }
@@ -114,6 +116,7 @@ int zkfhe_sync(zkfhe_ctx *ctx) {
 void *zkfhe_stream(zkfhe_ctx *ctx) { return (void *)ctx->stream; }
 
 int zkfhe_device_info(zkfhe_ctx *ctx, char *arch_name, size_t arch_len, int *num_cu, size_t *hbm_bytes) {
+  ZK_ENTER(ctx);
   hipDeviceProp_t prop;
   ZK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
   if (arch_name && arch_len) { strncpy(arch_name, prop.gcnArchName, arch_len - 1); arch_name[arch_len - 1] = 0; }
@@ -123,6 +126,7 @@ int zkfhe_device_info(zkfhe_ctx *ctx, char *arch_name, size_t arch_len, int *num
 }
 
 int zkfhe_dev_alloc(zkfhe_ctx *ctx, size_t bytes, void **dptr) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, dptr != nullptr);
   ZK_HIP(ctx, hipSetDevice(ctx->device));
   hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
@@ -131,34 +135,41 @@ int zkfhe_dev_alloc(zkfhe_ctx *ctx, size_t bytes, void **dptr) {
   return ZKFHE_OK;
 }
 int zkfhe_dev_free(zkfhe_ctx *ctx, void *dptr) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipFree(dptr));
   return ZKFHE_OK;
 }
 int zkfhe_upload(zkfhe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKFHE_OK;
 }
 int zkfhe_download(zkfhe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKFHE_OK;
 }
 int zkfhe_copy_dev(zkfhe_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return ZKFHE_OK;
 }
 int zkfhe_memset_dev(zkfhe_ctx *ctx, void *dst_dev, int byte, size_t bytes) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
   return ZKFHE_OK;
 }
 
 int zkfhe_prof_enable(zkfhe_ctx *ctx, int on) {
+  ZK_ENTER(ctx);
   ctx->prof_on = on != 0;
   return ZKFHE_OK;
 }
 int zkfhe_prof_reset(zkfhe_ctx *ctx) {
+  ZK_ENTER(ctx);
   for (int i = 0; i < 2; ++i) {
     ctx->prof_ms[i] = ctx->prof_bytes[i] = 0;
     ctx->prof_launches[i] = 0;
@@ -166,6 +177,7 @@ int zkfhe_prof_reset(zkfhe_ctx *ctx) {
   return ZKFHE_OK;
 }
 int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launches, double *algorithmic_bytes) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, which >= 0 && which < 2);
   if (total_ms) *total_ms = ctx->prof_ms[which];
   if (launches) *launches = ctx->prof_launches[which];
@@ -174,10 +186,12 @@ int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launc
 }
 
 int zkfhe_timer_start(zkfhe_ctx *ctx) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return ZKFHE_OK;
 }
 int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms) {
+  ZK_ENTER(ctx);
   ZK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ZK_HIP(ctx, hipEventSynchronize(ctx->ev1));
   ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
@@ -251,24 +265,28 @@ static unsigned ew_grid(zkfhe_ctx *ctx, size_t n) {
 extern "C" {
 
 int zkfhe_fr_add(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *b, zkfhe_fr *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_binop<OP_ADD><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, (const Fr *)b, (Fr *)out, n);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
 int zkfhe_fr_sub(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *b, zkfhe_fr *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_binop<OP_SUB><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, (const Fr *)b, (Fr *)out, n);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
 int zkfhe_fr_mul(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *b, zkfhe_fr *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_binop<OP_MUL><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, (const Fr *)b, (Fr *)out, n);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
 int zkfhe_fr_scale(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *s_host, zkfhe_fr *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   ZK_ARG(ctx, s_host != nullptr);
   Fr s;
@@ -278,18 +296,21 @@ int zkfhe_fr_scale(zkfhe_ctx *ctx, const zkfhe_fr *a, const zkfhe_fr *s_host, zk
   return ZKFHE_OK;
 }
 int zkfhe_fr_to_mont(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_unop<1><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, Fr::zero(), (Fr *)out, n);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
 int zkfhe_fr_from_mont(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_unop<2><<<ew_grid(ctx, n), 256, 0, ctx->stream>>>((const Fr *)a, Fr::zero(), (Fr *)out, n);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
 int zkfhe_fr_batch_invert(zkfhe_ctx *ctx, zkfhe_fr *a, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   void *tmp;
   int rc = zk_scratch(ctx, 0, n * sizeof(Fr), &tmp);
@@ -300,6 +321,7 @@ int zkfhe_fr_batch_invert(zkfhe_ctx *ctx, zkfhe_fr *a, size_t n) {
   return ZKFHE_OK;
 }
 int zkfhe_fr_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t n, int iters) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_sqr_chain<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const Fr *)a, (Fr *)out, n, iters);
   ZK_LAUNCH_CHECK(ctx);

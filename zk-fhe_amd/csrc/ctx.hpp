@@ -53,6 +53,13 @@ int zk_fail_msg(zkfhe_ctx *ctx, int code, const std::string &msg);
 
 #define ZK_LAUNCH_CHECK(ctx) ZK_HIP(ctx, hipGetLastError())
 
+// HIP's current device is per host thread: every public entry point selects the context's device first, so contexts
+// of different GPUs (one process per GPU under torchrun, or several worker threads) never launch on the wrong one.
+#define ZK_ENTER(ctx)                                   \
+  do {                                                  \
+    if (ctx) (void)hipSetDevice((ctx)->device);         \
+  } while (0)
+
 #define ZK_ARG(ctx, cond)                                                        \
   do {                                                                           \
     if (!(cond)) return zk_fail_msg((ctx), ZKFHE_EINVAL, std::string("bad argument: ") + #cond); \

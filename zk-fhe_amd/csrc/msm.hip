@@ -495,6 +495,7 @@ int default_window_bits(size_t n) {
 extern "C" {
 
 int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t n, int window_bits, zkfhe_basis **out) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, out != nullptr && bases_host != nullptr && n > 0);
   ZK_ARG(ctx, window_bits == 0 || (window_bits >= 2 && window_bits <= 16));
   const int c = window_bits ? window_bits : default_window_bits(n);
@@ -521,6 +522,7 @@ int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t
 }
 
 int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis) {
+  ZK_ENTER(ctx);
   if (!basis) return ZKFHE_OK;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   hipFree(basis->table);
@@ -531,6 +533,7 @@ int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis) {
 size_t zkfhe_basis_len(const zkfhe_basis *basis) { return basis ? basis->n : 0; }
 
 int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols, zkfhe_g1_affine *out_dev) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, basis != nullptr);
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, scalars_dev != nullptr && out_dev != nullptr);
@@ -623,6 +626,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
 }
 
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_g1_add<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)a, (const G1Affine *)b, (G1Affine *)out, n);
   ZK_LAUNCH_CHECK(ctx);
@@ -630,6 +634,7 @@ int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine
 }
 
 int zkfhe_g1_mul(zkfhe_ctx *ctx, const zkfhe_g1_affine *p, const zkfhe_fr *k, zkfhe_g1_affine *out, size_t n) {
+  ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_g1_mul<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)p, (const Fr *)k, (G1Affine *)out, n);
   ZK_LAUNCH_CHECK(ctx);

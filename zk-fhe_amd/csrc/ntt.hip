@@ -182,6 +182,7 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
 extern "C" {
 
 int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, log_n >= 1 && log_n <= 26);
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, cols_dev != nullptr);
@@ -277,6 +278,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
 
 int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n,
                           int log_ext_factor, const zkfhe_fr *g_host, int inverse) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, log_n >= 3 && log_n + log_ext_factor <= 26);
   ZK_ARG(ctx, log_ext_factor >= 1 && log_ext_factor <= 3);
   ZK_ARG(ctx, g_host != nullptr);

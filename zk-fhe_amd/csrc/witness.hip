@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) k_div_mod(const Fr *__restrict__ a, uint6
 extern "C" {
 
 int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, size_t n, zkfhe_fr *out_dev) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, a_dev && b_dev && out_dev);
   ZK_ARG(ctx, n >= 1 && (n & (n - 1)) == 0 && n <= ((size_t)1 << 20));
   int log_m = 1;
@@ -92,6 +93,7 @@ int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint
 }
 
 int zkfhe_witness_div_mod(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, uint64_t q, zkfhe_fr *div_dev, zkfhe_fr *rem_dev, size_t n) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, q >= 1 && q < ((uint64_t)1 << 63));
   if (!n) return ZKFHE_OK;
   ZK_ARG(ctx, a_dev && div_dev && rem_dev);

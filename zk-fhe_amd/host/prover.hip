@@ -154,6 +154,7 @@ struct zkfhe_bfv_pk {
 extern "C" {
 
 int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, out != nullptr && k >= 3 && k <= 20);
   const size_t n = (size_t)1 << k;
   Blake2b h(64, "zkfhe-srs");
@@ -197,6 +198,7 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
 }
 
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {
+  ZK_ENTER(ctx);
   if (!srs) return ZKFHE_OK;
   zkfhe_basis_destroy(ctx, srs->g);
   zkfhe_basis_destroy(ctx, srs->g_lagrange);
@@ -971,6 +973,7 @@ extern "C" {
 
 int zkfhe_bfv_keygen(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const zkfhe_bfv_params *params,
                      const zkfhe_bfv_config *config, zkfhe_bfv_pk **out) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, srs && input_json && params && config && out);
   try {
     return keygen_impl(ctx, srs, input_json, params_from_c(params), config_from_c(config), config->replay != 0, out);
@@ -980,6 +983,7 @@ int zkfhe_bfv_keygen(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_jso
 }
 
 int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
+  ZK_ENTER(ctx);
   if (!pk) return ZKFHE_OK;
   zkfhe_sync(ctx);
   DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow};
@@ -1050,6 +1054,7 @@ int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, 
 
 int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk, const char *input_json, const uint8_t seed[32],
                     uint8_t *proof_out, size_t proof_cap, size_t *proof_len, uint8_t *instances_out, size_t *n_instances, float *timings_ms) {
+  ZK_ENTER(ctx);
   ZK_ARG(ctx, srs && pk && input_json && seed && proof_out && proof_len);
   try {
     std::vector<uint8_t> proof;
