@@ -156,7 +156,7 @@ def main():
             "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
             "config": {"workload": "one proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout",
                        "concurrent_proofs_per_gpu": n_streams,
-                       "proof_bytes": proof_len, "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
+                       "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),

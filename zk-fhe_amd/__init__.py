@@ -488,10 +488,10 @@ class BfvProvingKey:
         prove concurrently against this key from different threads (ctypes releases the GIL)."""
         ctx = ctx or self.ctx
         seed = bytes(seed).ljust(32, b"\x00")[:32]
-        cap = 1 << 20
+        cap = 1 << 18
         buf = ctypes.create_string_buffer(cap)
         plen = ctypes.c_size_t()
-        ninst = ctypes.c_size_t(1 << 20)
+        ninst = ctypes.c_size_t(5 * int(self.params[0]) + 8)   # 4 polynomials of N coefficients + cyclo (N + 1) are public
         ibuf = ctypes.create_string_buffer(32 * ninst.value)
         tm = (ctypes.c_float * 5)()
         ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, input_json_text.encode(), seed, buf, cap, ctypes.byref(plen),
