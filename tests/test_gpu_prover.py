@@ -96,6 +96,29 @@ def test_bfv_in_k13_proof_bytes_match_oracle(ctx):
     srs.destroy()
 
 
+def test_device_and_host_witness_generators_agree(ctx):
+    """The phase-1 gate stream is generated on the GPU by default; ZKFHE_WITNESS=host keeps the host generator.  Same
+    seed -> identical bytes, on the reference's input and on a second random one."""
+    import zk_fhe_amd as zk
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    prm = C.BfvParams()
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, open(os.path.join(G, "bfv_empty.in")).read(), (1024, prm.Q, prm.T, prm.B), zk.BfvConfig.from_pinning(cfgj))
+    texts = [open(os.path.join(G, "bfv.in")).read(), json.dumps(synth_input(1024, prm.Q, prm.T, prm.B, 77))]
+    try:
+        for i, text in enumerate(texts):
+            os.environ.pop("ZKFHE_WITNESS", None)
+            dev, inst_d, _ = pk.prove(text, b"w-%d" % i)
+            os.environ["ZKFHE_WITNESS"] = "host"
+            host, inst_h, _ = pk.prove(text, b"w-%d" % i)
+            assert inst_d == inst_h
+            assert first_diff(dev, host) is None, "first differing 32-byte item: %s" % first_diff(dev, host)
+    finally:
+        os.environ.pop("ZKFHE_WITNESS", None)
+    pk.destroy()
+    srs.destroy()
+
+
 def test_concurrent_proofs_on_two_streams(ctx):
     """Two contexts (streams + workspaces) of the same GPU prove against one key at the same time: same bytes as alone."""
     import threading

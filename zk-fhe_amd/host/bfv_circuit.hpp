@@ -178,6 +178,18 @@ inline void bfv_phase1(const BfvState &st, const BfvParams &prm, Context &ctx_ga
   ctx_gate.resolve_fractions();
 }
 
+// The RLC context alone (the 12 `compute_rlc_fixed_len` evaluations behind the four constrain_mul calls, in circuit
+// order) -- used when the gate context is generated on the GPU.  evals[3*i .. 3*i+2] = a(gamma), b(gamma), c(gamma).
+inline void bfv_phase1_rlc(const BfvState &st, Context &ctx_rlc, const U256 &gamma, U256 evals[12]) {
+  const RlcChip rlc(gamma);
+  const PolyChip *trip[4][3] = {{&st.pk0, &st.u, &st.pk0_u},
+                                {&st.quotient_0, &st.cyclo, &st.quotient_0_times_cyclo},
+                                {&st.pk1, &st.u, &st.pk1_u},
+                                {&st.quotient_1, &st.cyclo, &st.quotient_1_times_cyclo}};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 3; ++j) evals[3 * i + j] = rlc.compute_rlc_fixed_len(ctx_rlc, trip[i][j]->assigned_coefficients).value;
+}
+
 // --------------------------------------------------------------------------------------------- layout
 struct CircuitConfig {  // configs/<name>.json "params"
   unsigned k = 13;

@@ -48,6 +48,7 @@ class Context {
   std::vector<std::pair<CellRef, U256>> consts;    // cell == constant
   std::vector<CellRef> lookup;                     // cells to look up
   std::vector<uint32_t> fractions;                 // offsets holding a denominator to invert
+  std::vector<uint32_t> inv_slots;                 // every is_zero's 1/x cell, whatever the value (structure; keygen mode)
 
   Context(uint32_t id, bool is_rlc, bool record) : cid(id), rlc(is_rlc), record_structure(record) {}
 
@@ -115,6 +116,7 @@ class GateChip {
   Cell is_zero(Context &ctx, const Cell &a) const {
     const bool z = a.value.is_zero();
     const U256 zv = fe::from_u64(z ? 1 : 0);
+    if (ctx.record_structure) ctx.inv_slots.push_back((uint32_t)ctx.advice.size() + 2);
     ctx.assign_region({Witness(zv), Existing(a), z ? Witness(fe::one()) : WitnessFraction(a.value), Constant(1), Constant(0), Existing(a),
                        Witness(zv), Constant(0)},
                       {0, 4}, {{0, 6}});

@@ -17,6 +17,7 @@
 
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
+#include "gpu_witness.cuh"
 #include "prover_kernels.cuh"
 #include "transcript.hpp"
 
@@ -73,9 +74,12 @@ struct Workspace {
   size_t n_all = 0;
   U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
   U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
+  U256 *host_pool = nullptr;   // pinned staging for the coefficient arrays of the GPU witness generator
+  U256 *host_wblind = nullptr; // pinned staging for the blinding rows of device-generated columns
+  DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
   std::vector<DevBuf *> all() {
-    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio};
+    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio, &stream, &pool, &invtmp, &wblind};
   }
 };
 
@@ -145,6 +149,9 @@ struct zkfhe_bfv_pk {
   DevBuf fixed_l, sigma_l, fixed_ext, sigma_ext, l_ext, xs_ext, dpow;
   std::vector<AffinePoint> fixed_commit, sigma_commit;
   U256 vk_digest;
+  // structure of the phase-1 gate stream, recorded at keygen for the GPU witness generator
+  size_t gate1_cells = 0, n_lookup_cells = 0, n_inv_slots = 0;
+  DevBuf lookup_src, inv_slots, place_start, place_len;   // device: u32 lists
   // per-context prover workspaces: one proof at a time per zkfhe_ctx, any number of contexts (streams)
   // may prove concurrently against the same key (everything above is read-only after keygen)
   std::map<zkfhe_ctx *, Workspace *> workspaces;
@@ -266,6 +273,20 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
   return ZKFHE_OK;
 }
 
+// buffers of the GPU witness generator (sizes known only after keygen)
+int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws) {
+  if (ws->stream.p) return ZKFHE_OK;
+  const size_t N = pk->prm.N;
+  CK(ws->stream.alloc(ctx, (pk->gate1_cells + 8) * 32));
+  CK(ws->pool.alloc(ctx, 40 * (2 * N + 8) * 32));
+  CK(ws->invtmp.alloc(ctx, (pk->n_inv_slots + 8) * 32));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pool, 24 * (2 * N + 8) * 32, hipHostMallocDefault));
+  const size_t nblind = ((size_t)std::max(pk->cfg.n_gate1 + pk->cfg.n_lookup, 2 * pk->cfg.n_lookup) + 1) * (pk->cfg.n() - pk->cfg.u());
+  CK(ws->wblind.alloc(ctx, (nblind + 8) * 32));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_wblind, (nblind + 8) * 32, hipHostMallocDefault));
+  return ZKFHE_OK;
+}
+
 int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
   std::lock_guard<std::mutex> lock(pk->mu);
   auto it = pk->workspaces.find(ctx);
@@ -315,6 +336,38 @@ int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, co
   zkfhe_bfv_pk *pk = new zkfhe_bfv_pk();
   pk->cfg = cfg;
   pk->prm = prm;
+  {
+    // structure of the phase-1 gate stream for the GPU witness generator: where looked-up cells and deferred
+    // inverses sit in the stream, and which stream range each gate column holds (break points)
+    pk->gate1_cells = ctx_gate.advice.size();
+    pk->n_lookup_cells = ctx_gate.lookup.size();
+    pk->n_inv_slots = ctx_gate.inv_slots.size();
+    std::vector<uint32_t> lsrc(ctx_gate.lookup.size());
+    for (size_t i = 0; i < lsrc.size(); ++i) {
+      ZK_ASSERT(ctx_gate.lookup[i].ctx == CTX_GATE1, "lookup cell outside the phase-1 gate context");
+      lsrc[i] = ctx_gate.lookup[i].off;
+    }
+    std::vector<uint32_t> start(cfg.n_gate1, 0), len(cfg.n_gate1, 0);
+    size_t s = 0;
+    for (unsigned c = 0; c < cfg.n_gate1 && s < pk->gate1_cells; ++c) {
+      start[c] = (uint32_t)s;
+      if (c < cfg.bp_gate1.size()) {
+        len[c] = cfg.bp_gate1[c] + 1;   // rows 0..bp: the last one is the duplicate of the next column's first cell
+        s += cfg.bp_gate1[c];
+      } else {
+        len[c] = (uint32_t)(pk->gate1_cells - s);
+        s = pk->gate1_cells;
+      }
+    }
+    CK(pk->lookup_src.alloc(ctx, (lsrc.size() + 1) * 4));
+    CK(pk->inv_slots.alloc(ctx, (ctx_gate.inv_slots.size() + 1) * 4));
+    CK(pk->place_start.alloc(ctx, (start.size() + 1) * 4));
+    CK(pk->place_len.alloc(ctx, (len.size() + 1) * 4));
+    if (!lsrc.empty()) CK(zkfhe_upload(ctx, pk->lookup_src.p, lsrc.data(), lsrc.size() * 4));
+    if (!ctx_gate.inv_slots.empty()) CK(zkfhe_upload(ctx, pk->inv_slots.p, ctx_gate.inv_slots.data(), ctx_gate.inv_slots.size() * 4));
+    CK(zkfhe_upload(ctx, pk->place_start.p, start.data(), start.size() * 4));
+    CK(zkfhe_upload(ctx, pk->place_len.p, len.data(), len.size() * 4));
+  }
   // ---- sigma: union-find over cell ids, each class sorted by id is one cycle
   const size_t cells = (size_t)cfg.n_perm() * n;
   std::vector<uint32_t> parent(cells);
@@ -449,6 +502,198 @@ void permute_lookup(const std::vector<U256> &input, size_t u, unsigned table_siz
     for (size_t k = 0; k < left[v]; ++k) s_perm[holes[hi++]] = fe::from_u64(v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Phase-1 gate context on the GPU: the device twin of bfv_phase1 (examples/bfv.rs:167-304 through src/poly_chip.rs).
+// One launch per PolyChip call, one thread per coefficient; the stream offset of every call is a pure function of
+// the circuit shape and is cross-checked against the stream length recorded at keygen.
+struct DevPoly {
+  Fr *d = nullptr;
+  size_t len = 0;
+  uint64_t bits = 0;
+};
+
+class GpuPhase1 {
+ public:
+  GpuPhase1(zkfhe_ctx *c, const zkfhe_bfv_pk *k, Workspace *w) : ctx(c), pk(k), ws(w) {}
+
+  int run(const BfvState &st, const U256 evals[12]) {
+    const uint64_t Q = pk->prm.Q, T = pk->prm.T, B = pk->prm.B;
+    CK(alloc_witness_buffers(ctx, pk, ws));
+    stream = ws->stream.fr();
+    pool_used = 0;
+    off = 0;
+    // inputs: one pinned staging block, one DMA
+    h_used = 0;
+    DevPoly e0 = stage(st.e0), e1 = stage(st.e1), u = stage(st.u), m = stage(st.m);
+    DevPoly pk0_u = stage(st.pk0_u), q0 = stage(st.quotient_0), r0 = stage(st.remainder_0), q0c = stage(st.quotient_0_times_cyclo), xc0 = stage(st.expected_c0);
+    DevPoly pk1_u = stage(st.pk1_u), q1 = stage(st.quotient_1), r1 = stage(st.remainder_1), q1c = stage(st.quotient_1_times_cyclo), xc1 = stage(st.expected_c1);
+    ws->host_pool[h_used] = st.delta.value;
+    const Fr *delta = ws->pool.fr() + h_used;
+    const uint64_t delta_bits = st.delta.value.bits();
+    ++h_used;
+    pool_used = h_used;
+    // the four gate cells of each constrain_mul, Montgomery, staged after the inputs
+    Fr *mg_host = (Fr *)(ws->host_pool + h_used);
+    for (int i = 0; i < 4; ++i) {
+      mg_host[4 * i] = Fr::zero();
+      for (int j = 0; j < 3; ++j) mg_host[4 * i + 1 + j] = mont(evals[3 * i + j]);
+    }
+    const Fr *mg_dev = ws->pool.fr() + h_used;
+    h_used += 16;
+    pool_used = h_used;
+    ZK_HIP(ctx, hipMemcpyAsync(ws->pool.p, ws->host_pool, h_used * 32, hipMemcpyHostToDevice, ctx->stream));
+
+    CK(in_range(e0, B, Q));
+    CK(in_range(e1, B, Q));
+    CK(gadget(zkw::G_CHI_KEY, u, nullptr, nullptr, zkw::cpc_chi_key(), Q - 1, 0, Fr::zero()));
+    CK(in_range(m, T / 2, Q));
+    const int n_side = 2;
+    for (int side = 0; side < n_side; ++side) {
+      const DevPoly &pku = side ? pk1_u : pk0_u, &q = side ? q1 : q0, &r = side ? r1 : r0, &qc = side ? q1c : q0c;
+      CK(mul_gate(mg_dev + 8 * side));                                   // pk_i * u = pk_i_u
+      DevPoly pku_r;
+      CK(reduce_by_modulo(pku, Q, pku_r));
+      CK(in_field(q, Q));
+      CK(in_field(r, Q));
+      // reduce_by_cyclo (src/poly_chip.rs:183-223)
+      CK(mul_gate(mg_dev + 8 * side + 4));                               // quotient * cyclo = quotient_times_cyclo
+      DevPoly sum, sum_mod;
+      CK(add(qc, r, sum));
+      CK(reduce_by_modulo(sum, Q, sum_mod));
+      if (sum_mod.len < pku_r.len) return zk_fail_msg(ctx, ZKFHE_EINVAL, "degree <= self.degree (src/poly_chip.rs:375)");
+      DevPoly trimmed{sum_mod.d + (sum_mod.len - pku_r.len), pku_r.len, sum_mod.bits};
+      CK(equal(trimmed, pku_r));
+      const size_t N = pk->prm.N;
+      if (r.len < N) return zk_fail_msg(ctx, ZKFHE_EINVAL, "degree <= self.degree (src/poly_chip.rs:375)");
+      DevPoly acc{r.d + (r.len - N), N, r.bits};
+      if (side == 0) {
+        DevPoly m_delta, t;
+        CK(scalar_mul(m, delta, delta_bits, m_delta));
+        CK(add(acc, m_delta, t));
+        CK(add(t, e0, acc));
+      } else {
+        DevPoly t;
+        CK(add(acc, e1, t));
+        acc = t;
+      }
+      DevPoly c_red;
+      CK(reduce_by_modulo(acc, Q, c_red));
+      CK(equal(c_red, side ? xc1 : xc0));
+    }
+    if (off != pk->gate1_cells) return zk_fail_msg(ctx, ZKFHE_EINVAL, "GPU witness stream length differs from the keygen circuit shape");
+    // deferred 1/x cells of is_zero: one batch inversion over the structural slot list
+    if (pk->n_inv_slots) {
+      const unsigned g = (unsigned)((pk->n_inv_slots + 255) / 256);
+      zkw::k_gather<<<g, 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->inv_slots.p, pk->n_inv_slots, ws->invtmp.fr());
+      ZK_LAUNCH_CHECK(ctx);
+      CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)ws->invtmp.p, pk->n_inv_slots));
+      zkw::k_scatter<<<g, 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->inv_slots.p, pk->n_inv_slots, ws->invtmp.fr());
+      ZK_LAUNCH_CHECK(ctx);
+    }
+    // stream -> gate columns (break points) and lookup columns
+    const CircuitConfig &cfg = pk->cfg;
+    const size_t n = cfg.n();
+    zkw::k_place<<<grid_for(ctx, (size_t)cfg.n_gate1 * n), 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->place_start.p, (const unsigned *)pk->place_len.p,
+                                                                                 cfg.n_gate1, n, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n);
+    ZK_LAUNCH_CHECK(ctx);
+    if (cfg.n_lookup) {
+      if (pk->n_lookup_cells > (size_t)cfg.n_lookup * cfg.max_rows()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup cells do not fit the configured lookup columns");
+      zkw::k_place_lookups<<<grid_for(ctx, (size_t)cfg.n_lookup * n), 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->lookup_src.p, pk->n_lookup_cells,
+                                                                                           (unsigned)cfg.max_rows(), n, cfg.n_lookup,
+                                                                                           ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n);
+      ZK_LAUNCH_CHECK(ctx);
+    }
+    return ZKFHE_OK;
+  }
+
+ private:
+  zkfhe_ctx *ctx;
+  const zkfhe_bfv_pk *pk;
+  Workspace *ws;
+  Fr *stream = nullptr;
+  size_t off = 0, pool_used = 0, h_used = 0;
+
+  DevPoly stage(const PolyChip &p) {
+    DevPoly d;
+    d.len = p.assigned_coefficients.size();
+    d.bits = p.max_num_bits;
+    d.d = ws->pool.fr() + h_used;
+    for (size_t i = 0; i < d.len; ++i) ws->host_pool[h_used + i] = p.assigned_coefficients[i].value;
+    h_used += d.len;
+    return d;
+  }
+  Fr *take(size_t len) {
+    Fr *p = ws->pool.fr() + pool_used;
+    pool_used += len;
+    return p;
+  }
+  int gadget(int type, const DevPoly &a, const Fr *b, Fr *out, size_t cpc, uint64_t p0, uint64_t p1, const Fr &bound) {
+    if (pool_used * 32 > ws->pool.bytes || (off + a.len * cpc) > pk->gate1_cells)
+      return zk_fail_msg(ctx, ZKFHE_EINVAL, "GPU witness stream exceeds the keygen circuit shape");
+    zkw::GadgetArgs g;
+    g.type = type;
+    g.a = a.d;
+    g.b = b;
+    g.out = out;
+    g.stream = stream;
+    g.base = off;
+    g.cpc = cpc;
+    g.count = a.len;
+    g.p0 = p0;
+    g.p1 = p1;
+    g.bound = bound;
+    zkw::k_gadget<<<(unsigned)((a.len + 255) / 256), 256, 0, ctx->stream>>>(g);
+    ZK_LAUNCH_CHECK(ctx);
+    off += a.len * cpc;
+    return ZKFHE_OK;
+  }
+  int in_range(const DevPoly &a, uint64_t z, uint64_t y) {
+    if (!(z < y)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "z < y (src/poly_chip.rs:278)");
+    return gadget(zkw::G_IN_RANGE, a, nullptr, nullptr, zkw::cpc_in_range(z, y), z, y, Fr::zero());
+  }
+  int in_field(const DevPoly &a, uint64_t q) { return gadget(zkw::G_IN_FIELD, a, nullptr, nullptr, zkw::cpc_in_field(q), q, 0, Fr::zero()); }
+  int mul_gate(const Fr *cells_dev) {
+    if (off + 4 > pk->gate1_cells) return zk_fail_msg(ctx, ZKFHE_EINVAL, "GPU witness stream exceeds the keygen circuit shape");
+    ZK_HIP(ctx, hipMemcpyAsync(stream + off, cells_dev, 4 * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    off += 4;
+    return ZKFHE_OK;
+  }
+  int reduce_by_modulo(const DevPoly &a, uint64_t q, DevPoly &out) {
+    if (a.bits >= 192 || (q >> 63)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "reduce_by_modulo: operands too wide for the device divider (a < 2^192, q < 2^63)");
+    // halo2-base div_mod: div < 2^num_bits / q + 1
+    Fr bound;
+    zkw::u64 rem;
+    zkw::c_divmod(zkw::c_pow2((unsigned)a.bits), q, bound, rem);
+    bound = zkw::c_add(bound, zkw::c_u64(1));
+    out.d = take(a.len);
+    out.len = a.len;
+    out.bits = bits_u64(q);
+    return gadget(zkw::G_DIV_MOD, a, nullptr, out.d, zkw::cpc_div_mod(q, bound), q, 0, bound);
+  }
+  int add(const DevPoly &a, const DevPoly &b, DevPoly &out) {
+    if (b.len < a.len) return zk_fail_msg(ctx, ZKFHE_EINVAL, "add: operand lengths differ");
+    out.d = take(a.len);
+    out.len = a.len;
+    out.bits = std::max(a.bits, b.bits) + 1;
+    return gadget(zkw::G_ADD, a, b.d, out.d, 4, 0, 0, Fr::zero());
+  }
+  int scalar_mul(const DevPoly &a, const Fr *scalar, uint64_t scalar_bits, DevPoly &out) {
+    out.d = take(a.len);
+    out.len = a.len;
+    out.bits = a.bits + scalar_bits;
+    return gadget(zkw::G_SCALAR_MUL, a, scalar, out.d, 4, 0, 0, Fr::zero());
+  }
+  int equal(const DevPoly &a, const DevPoly &b) {
+    if (b.len < a.len) return zk_fail_msg(ctx, ZKFHE_EINVAL, "constrain_equality: operand lengths differ");
+    return gadget(zkw::G_EQUAL, a, b.d, nullptr, zkw::cpc_equal(), 0, 0, Fr::zero());
+  }
+};
+
+bool witness_on_host() {
+  const char *e = getenv("ZKFHE_WITNESS");
+  return e && strcmp(e, "host") == 0;
+}
+
 // The blinding stream is counter based (Blake2b(seed || i)), so all draws of a proof -- their number is fixed by the
 // circuit shape -- are produced by a helper thread while the witness is being generated; next() hands them out in order.
 class PreRng {
@@ -532,34 +777,78 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = pts[c]);
   const U256 gamma_rlc = tr.squeeze();
   // ------------------------------------------------------------ phase 1 witness
-  bfv_phase1(st, pk->prm, ctx_gate, ctx_rlc, gamma_rlc);
-  as.place(ctx_gate, true);
-  as.place(ctx_rlc, true);
-  as.place_lookups(ctx_gate);
-  std::vector<std::vector<U256>> lookup_inputs(cfg.n_lookup);
-  for (unsigned i = 0; i < cfg.n_lookup; ++i)
+  const bool host_witness = witness_on_host();
+  const size_t nbl = n - u;
+  int *lookup_err = nullptr;
+  if (host_witness) {
+    bfv_phase1(st, pk->prm, ctx_gate, ctx_rlc, gamma_rlc);
+    as.place(ctx_gate, true);
+    as.place(ctx_rlc, true);
+    as.place_lookups(ctx_gate);
+  } else {
+    // RLC context on the host (6 K cells), gate context (1.2 M cells) on the device
+    U256 evals[12];
+    bfv_phase1_rlc(st, ctx_rlc, gamma_rlc, evals);
+    as.place(ctx_rlc, true);
+    GpuPhase1 g1(ctx, pk, ws);
+    CK(g1.run(st, evals));
+  }
+  std::vector<std::vector<U256>> lookup_inputs(host_witness ? cfg.n_lookup : 0);
+  for (unsigned i = 0; i < lookup_inputs.size(); ++i)
     lookup_inputs[i].assign(as.t.advice[cfg.adv_lookup0() + i], as.t.advice[cfg.adv_lookup0() + i] + u);
   const double t_wit = now_ms();
-  CK(blind_and_upload(cfg.n_gate0, cfg.n_advice()));
+  if (host_witness) {
+    CK(blind_and_upload(cfg.n_gate0, cfg.n_advice()));
+  } else {
+    // blinding rows of the device-generated columns (same draw order as the host path: column by column)
+    const unsigned nc = cfg.adv_rlc0() - cfg.n_gate0;
+    for (size_t i = 0; i < (size_t)nc * nbl; ++i) ws->host_wblind[i] = rng.next();
+    CK(upload_canon(ctx, ws->wblind.fr(), ws->host_wblind, (size_t)nc * nbl));
+    ZK_HIP(ctx, hipMemcpy2DAsync(ws->adv_l.fr() + (size_t)cfg.n_gate0 * n + u, n * 32, ws->wblind.fr(), nbl * 32, nbl * 32, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
+  }
   CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
   tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
   // ------------------------------------------------------------ lookups: permuted input / table
   std::vector<AffinePoint> la_commit, ls_commit;
   if (cfg.n_lookup) {
-    std::vector<U256> ap, sp;
-    U256 *stA = ws->host_blind, *stS = ws->host_blind + (size_t)cfg.n_lookup * n;  // la | ls, as on the device
-    for (unsigned i = 0; i < cfg.n_lookup; ++i) {
-      permute_lookup(lookup_inputs[i], u, 1u << cfg.lookup_bits, ap, sp);
-      U256 *colA = stA + (size_t)i * n, *colS = stS + (size_t)i * n;
-      std::copy(ap.begin(), ap.end(), colA);
-      std::copy(sp.begin(), sp.end(), colS);
-      for (size_t r = u; r < n; ++r) colA[r] = rng.next();
-      for (size_t r = u; r < n; ++r) colS[r] = rng.next();
+    if (host_witness) {
+      std::vector<U256> ap, sp;
+      U256 *stA = ws->host_blind, *stS = ws->host_blind + (size_t)cfg.n_lookup * n;  // la | ls, as on the device
+      for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+        permute_lookup(lookup_inputs[i], u, 1u << cfg.lookup_bits, ap, sp);
+        U256 *colA = stA + (size_t)i * n, *colS = stS + (size_t)i * n;
+        std::copy(ap.begin(), ap.end(), colA);
+        std::copy(sp.begin(), sp.end(), colS);
+        for (size_t r = u; r < n; ++r) colA[r] = rng.next();
+        for (size_t r = u; r < n; ++r) colS[r] = rng.next();
+      }
+      ZK_HIP(ctx, hipMemcpyAsync(ws->la_l.p, ws->host_blind, 2 * (size_t)cfg.n_lookup * n * 32, hipMemcpyHostToDevice, ctx->stream));
+      CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
+    } else {
+      if (cfg.lookup_bits != 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "the device lookup permutation is built for lookup_bits = 8");
+      // the commit_cols above synchronised the stream, so the staging block is free again
+      lookup_err = (int *)(ws->wblind.fr() + 2 * (size_t)cfg.n_lookup * nbl);
+      ZK_HIP(ctx, hipMemsetAsync(lookup_err, 0, 4, ctx->stream));
+      zkw::k_lookup_permute<<<cfg.n_lookup, 256, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
+      ZK_LAUNCH_CHECK(ctx);
+      // blinding rows: la_i then ls_i, lookup by lookup; staged as [la columns | ls columns]
+      for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+        U256 *a = ws->host_wblind + (size_t)i * nbl, *s = ws->host_wblind + ((size_t)cfg.n_lookup + i) * nbl;
+        for (size_t r = 0; r < nbl; ++r) a[r] = rng.next();
+        for (size_t r = 0; r < nbl; ++r) s[r] = rng.next();
+      }
+      CK(upload_canon(ctx, ws->wblind.fr(), ws->host_wblind, 2 * (size_t)cfg.n_lookup * nbl));
+      // la_l | ls_l are contiguous: one strided copy covers both
+      ZK_HIP(ctx, hipMemcpy2DAsync(ws->la_l.fr() + u, n * 32, ws->wblind.fr(), nbl * 32, nbl * 32, 2 * cfg.n_lookup, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    ZK_HIP(ctx, hipMemcpyAsync(ws->la_l.p, ws->host_blind, 2 * (size_t)cfg.n_lookup * n * 32, hipMemcpyHostToDevice, ctx->stream));
-    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
     CK(commit_cols(ctx, srs->g_lagrange, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
+    if (lookup_err) {
+      int e = 0;
+      CK(zkfhe_download(ctx, &e, lookup_err, 4));
+      if (e) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
+    }
     ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
     la_commit.resize(cfg.n_lookup);
     for (unsigned i = 0; i < cfg.n_lookup; ++i) {
@@ -986,12 +1275,15 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
   ZK_ENTER(ctx);
   if (!pk) return ZKFHE_OK;
   zkfhe_sync(ctx);
-  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow};
+  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow,
+                    &pk->lookup_src, &pk->inv_slots, &pk->place_start, &pk->place_len};
   for (DevBuf *b : bufs) b->release();
   for (auto &kv : pk->workspaces) {
     for (DevBuf *b : kv.second->all()) b->release();
     if (kv.second->host_adv) (void)hipHostFree(kv.second->host_adv);
     if (kv.second->host_blind) (void)hipHostFree(kv.second->host_blind);
+    if (kv.second->host_pool) (void)hipHostFree(kv.second->host_pool);
+    if (kv.second->host_wblind) (void)hipHostFree(kv.second->host_wblind);
     delete kv.second;
   }
   delete pk;
