@@ -388,9 +388,12 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restric
 // ---- fast bucket reduction for 64 <= K <= 4096 -------------------------------------------------------
 // bucket index idx = 64 a + b carries weight idx + 1, so
 //     sum (idx+1) B = 64 * sum_a a R_a  +  sum_b (b+1) C_b ,   R_a = sum_b B[a][b],  C_b = sum_a B[a][b].
-// k_msm_marginals: one WAVE per row sum and per column sum (6-step butterfly of XYZZ additions);
-// k_msm_weighted: two waves per MSM do the 64-element weighted sums as shuffle trees, then one lane
-// normalises.  Dependent chain ~ 6 + (18 adds + 15 doublings) + 7 instead of ~100 additions.
+// k_msm_marginals: EIGHT lanes per row / column sum -- every lane adds up to 8 buckets serially (all lanes useful),
+// then a 3-step butterfly over the 8 lanes; 1.4 lane-additions per bucket and marginal instead of 6 for a whole-wave
+// butterfly.  lane = sub * 8 + g: the 8 outputs of a wave sit in the low lane bits so that column sums read
+// consecutive buckets across lanes.
+// k_msm_weighted: two waves per MSM; lane a forms a * R_a by double-and-add (<= 7 bits) and a 6-step butterfly sums
+// the lanes; then one lane normalises.
 __device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
   G1X r;
 #pragma unroll
@@ -407,19 +410,31 @@ __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ b
   const unsigned A = K >> 6;
   const unsigned per_col = A + 64;
   const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
-  const unsigned lane = threadIdx.x & 63;
-  if (wave >= n_cols * per_col) return;
-  const size_t col = wave / per_col;
-  const unsigned w = (unsigned)(wave - col * per_col);
+  const unsigned lane = threadIdx.x & 63, g = lane & 7, sub = lane >> 3;
+  const size_t o = wave * 8 + g;  // output index over all columns
+  const bool live = o < n_cols * per_col;
+  const size_t col = live ? o / per_col : 0;
+  const unsigned w = (unsigned)(o - col * per_col);
   const G1X *B = buckets + col * K;
-  G1X v;
-  if (w < A) v = B[(size_t)w * 64 + lane];                                  // row w
-  else v = lane < A ? B[(size_t)lane * 64 + (w - A)] : G1X::identity();     // column w - A
-  for (int m = 1; m < 64; m <<= 1) {
-    const G1X o = g1x_shfl_xor(v, m);
-    g1x_add(v, o);
+  size_t base, stride;
+  unsigned cnt;
+  if (w < A) {  // row w: buckets w*64 + sub + 8 i
+    base = (size_t)w * 64 + sub;
+    stride = 8;
+    cnt = 8;
+  } else {      // column w - A: buckets (sub + 8 i) * 64 + (w - A)
+    base = (size_t)sub * 64 + (w - A);
+    stride = 512;
+    cnt = A > sub ? (A - sub + 7) / 8 : 0;
   }
-  if (lane == 0) marg[col * per_col + w] = v;
+  if (!live) cnt = 0;
+  G1X v = G1X::identity();
+  for (unsigned i = 0; i < cnt; ++i) g1x_add(v, B[base + i * stride]);
+  for (int m = 8; m < 64; m <<= 1) {
+    const G1X other = g1x_shfl_xor(v, m);
+    g1x_add(v, other);
+  }
+  if (live && sub == 0) marg[o] = v;
 }
 
 __global__ void __launch_bounds__(128) k_msm_weighted(const G1X *__restrict__ marg, unsigned K, G1Affine *__restrict__ out) {
@@ -428,21 +443,18 @@ __global__ void __launch_bounds__(128) k_msm_weighted(const G1X *__restrict__ ma
   const size_t col = blockIdx.x;
   const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const G1X *M = marg + col * (A + 64);
-  G1X S = wv == 0 ? (lane < A ? M[lane] : G1X::identity()) : M[A + lane];
+  const G1X P = wv == 0 ? (lane < A ? M[lane] : G1X::identity()) : M[A + lane];
+  const unsigned k = wv == 0 ? lane : lane + 1;  // weights a (rows) and b + 1 (columns)
   G1X W = G1X::identity();
-  for (int l = 0; l < 6; ++l) {
-    const int m = 1 << l;
-    const G1X oS = g1x_shfl_xor(S, m), oW = g1x_shfl_xor(W, m);
-    G1X SR = (lane >> l) & 1 ? S : oS;  // the sum of the right-hand block
-    SR = g1x_mul_pow2(SR, l);
-    g1x_add(W, oW);
-    g1x_add(W, SR);
-    g1x_add(S, oS);
+  for (int bit = 6; bit >= 0; --bit) {
+    W = g1x_dbl(W);
+    if ((k >> bit) & 1) g1x_add(W, P);
   }
-  if (lane == 0) {
-    if (wv == 1) g1x_add(W, S);  // weights b + 1
-    sh[wv] = W;
+  for (int m = 1; m < 64; m <<= 1) {
+    const G1X other = g1x_shfl_xor(W, m);
+    g1x_add(W, other);
   }
+  if (lane == 0) sh[wv] = W;
   __syncthreads();
   if (threadIdx.x == 0) {
     G1X t = g1x_mul_pow2(sh[0], 6);
@@ -616,7 +628,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   if (K >= 64 && K <= 4096) {
     const unsigned per_col = (K >> 6) + 64;
     G1X *marg = partials;  // the accumulation partials are dead once the buckets are merged
-    const size_t waves = n_cols * per_col;
+    const size_t waves = (n_cols * per_col + 7) / 8;
     k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, marg);
     ZK_LAUNCH_CHECK(ctx);
     k_msm_weighted<<<(unsigned)n_cols, 128, 0, ctx->stream>>>(marg, K, (G1Affine *)out_dev);
