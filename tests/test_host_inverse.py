@@ -1,0 +1,22 @@
+"""fp_inv (safegcd division steps, zk-fhe_amd/csrc/bn254.cuh) against the binary-Euclid inversion and against
+a * a^-1 == 1, for Fr and Fq: 200 k random values plus powers of two, p - 1, p - 2 and short values.  The field code is
+host+device; this runs its host instantiation (no GPU)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_safegcd_inverse_matches_euclid(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "inverse_check")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "zk-fhe_amd", "csrc"),
+                    os.path.join(HERE, "native", "inverse_check.hip"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "Fr: 0 bad" in out and "Fq: 0 bad" in out, out
