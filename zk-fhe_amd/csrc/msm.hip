@@ -166,10 +166,17 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
 // (witness columns hold thousands of 0/1 cells).  k_msm_task_count: tasks per column; k_msm_task_fill:
 // the task list (bucket id, slice); k_msm_accumulate: one thread per task -> partial sum;
 // k_msm_merge: one thread per bucket adds its partials (few), buckets with many partials go to a wave each.
-constexpr int TASK_E = 32;
+// The task length is chosen per call (task_len below): 32 when the call has enough entries to fill the chip with
+// such tasks, shorter (down to 8) for calls of a few columns, whose run time is the dependent chain of one task.
+constexpr int TASK_E_MAX = 32;
 constexpr int MERGE_LIGHT = 8;  // partials merged by a single thread; more -> one wave per bucket
+static unsigned task_len(size_t total_entries) {
+  unsigned e = TASK_E_MAX;
+  while (e > 8 && total_entries / e < (size_t)196608) e >>= 1;
+  return e;
+}
 
-__global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned *__restrict__ col_tasks) {
+__global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, unsigned *__restrict__ col_tasks) {
   __shared__ unsigned sh[256];
   const unsigned *o = off + (size_t)blockIdx.x * (K + 1);
   unsigned s = 0;
@@ -193,7 +200,7 @@ __global__ void k_msm_task_colscan(const unsigned *__restrict__ col_tasks, unsig
   col_base[n_cols] = acc;
 }
 // per column: exclusive scan of tasks-per-bucket -> first task of every bucket, and the task list itself
-__global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restrict__ off, unsigned K, const unsigned *__restrict__ col_base,
+__global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, const unsigned *__restrict__ col_base,
                                                        unsigned *__restrict__ bucket_task0 /* [n_cols][K] */, uint2 *__restrict__ tasks) {
   __shared__ unsigned part[256];
   const size_t col = blockIdx.x;
@@ -224,7 +231,7 @@ __global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restric
 
 __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict__ tasks, const unsigned *__restrict__ n_tasks_ptr,
                                                         const unsigned *__restrict__ off, const unsigned *__restrict__ entries,
-                                                        size_t col_entries, const G1Affine *__restrict__ table, unsigned K,
+                                                        size_t col_entries, const G1Affine *__restrict__ table, unsigned K, unsigned TASK_E,
                                                         G1X *__restrict__ partials) {
   const unsigned n_tasks = *n_tasks_ptr;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n_tasks; t += (size_t)gridDim.x * blockDim.x) {
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
 
 // bucket sum = sum of its partials.  Light buckets: one thread.  Heavy ones are listed for k_msm_merge_heavy.
 __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
-                                                   const G1X *__restrict__ partials, unsigned K, size_t n_cols, G1X *__restrict__ buckets,
+                                                   const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, size_t n_cols, G1X *__restrict__ buckets,
                                                    unsigned *__restrict__ heavy_count, unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
   const size_t total = (size_t)K * n_cols;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
@@ -290,7 +297,7 @@ __device__ __forceinline__ G1X g1x_shfl_down(const G1X &p, int delta) {
 
 // one wave per heavy bucket: lanes stride over the partials, then a 6-step shuffle tree
 __global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
-                                                         const G1X *__restrict__ partials, unsigned K, G1X *__restrict__ buckets,
+                                                         const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, G1X *__restrict__ buckets,
                                                          const unsigned *__restrict__ heavy_count, const unsigned *__restrict__ heavy_list,
                                                          unsigned heavy_cap) {
   unsigned cnt = *heavy_count;
@@ -388,9 +395,9 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restric
 // ---- fast bucket reduction for 64 <= K <= 4096 -------------------------------------------------------
 // bucket index idx = 64 a + b carries weight idx + 1, so
 //     sum (idx+1) B = 64 * sum_a a R_a  +  sum_b (b+1) C_b ,   R_a = sum_b B[a][b],  C_b = sum_a B[a][b].
-// k_msm_marginals: EIGHT lanes per row / column sum -- every lane adds up to 8 buckets serially (all lanes useful),
-// then a 3-step butterfly over the 8 lanes; 1.4 lane-additions per bucket and marginal instead of 6 for a whole-wave
-// butterfly.  lane = sub * 8 + g: the 8 outputs of a wave sit in the low lane bits so that column sums read
+// k_msm_marginals: L lanes per row / column sum -- every lane adds up to 64/L buckets serially, then a butterfly over
+// the L lanes.  L = 8 for calls with many columns (1.4 lane-additions per bucket and marginal instead of the 6 of a
+// whole-wave butterfly), L = 64 for calls of a few columns (shortest dependent chain).  lane = sub * 8 + g: the 8 outputs of a wave sit in the low lane bits so that column sums read
 // consecutive buckets across lanes.
 // k_msm_weighted: two waves per MSM; lane a forms a * R_a by double-and-add (<= 7 bits) and a 6-step butterfly sums
 // the lanes; then one lane normalises.
@@ -406,31 +413,33 @@ __device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ buckets, unsigned K, size_t n_cols, G1X *__restrict__ marg /* [n_cols][A + 64] */) {
+__global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ buckets, unsigned K, size_t n_cols, unsigned L /* lanes per output: 8 or 64 */,
+                                                       G1X *__restrict__ marg /* [n_cols][A + 64] */) {
   const unsigned A = K >> 6;
   const unsigned per_col = A + 64;
+  const unsigned G = 64 / L;  // outputs per wave
   const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
-  const unsigned lane = threadIdx.x & 63, g = lane & 7, sub = lane >> 3;
-  const size_t o = wave * 8 + g;  // output index over all columns
+  const unsigned lane = threadIdx.x & 63, g = lane & (G - 1), sub = lane / G;
+  const size_t o = wave * G + g;  // output index over all columns
   const bool live = o < n_cols * per_col;
   const size_t col = live ? o / per_col : 0;
   const unsigned w = (unsigned)(o - col * per_col);
   const G1X *B = buckets + col * K;
   size_t base, stride;
   unsigned cnt;
-  if (w < A) {  // row w: buckets w*64 + sub + 8 i
+  if (w < A) {  // row w: buckets w*64 + sub + L i
     base = (size_t)w * 64 + sub;
-    stride = 8;
-    cnt = 8;
-  } else {      // column w - A: buckets (sub + 8 i) * 64 + (w - A)
+    stride = L;
+    cnt = 64 / L;
+  } else {      // column w - A: buckets (sub + L i) * 64 + (w - A)
     base = (size_t)sub * 64 + (w - A);
-    stride = 512;
-    cnt = A > sub ? (A - sub + 7) / 8 : 0;
+    stride = (size_t)L * 64;
+    cnt = A > sub ? (A - sub + L - 1) / L : 0;
   }
   if (!live) cnt = 0;
   G1X v = G1X::identity();
   for (unsigned i = 0; i < cnt; ++i) g1x_add(v, B[base + i * stride]);
-  for (int m = 8; m < 64; m <<= 1) {
+  for (int m = (int)G; m < 64; m <<= 1) {
     const G1X other = g1x_shfl_xor(v, m);
     g1x_add(v, other);
   }
@@ -562,6 +571,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
+  const unsigned TASK_E = task_len(n_cols * col_entries);
   const size_t max_tasks = (n_cols * col_entries) / TASK_E + (size_t)K * n_cols;      // upper bound on accumulation tasks
   const size_t heavy_cap = (n_cols * col_entries) / ((size_t)TASK_E * MERGE_LIGHT) + 1;  // buckets with > MERGE_LIGHT partials
   // scratch 1: hist | off | cursor | bucket_task0 | col_tasks | col_base | heavy_count | heavy_list | tasks
@@ -603,33 +613,34 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   ZK_LAUNCH_CHECK(ctx);
   k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, col_tasks);
+  k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_tasks);
   ZK_LAUNCH_CHECK(ctx);
   k_msm_task_colscan<<<1, 64, 0, ctx->stream>>>(col_tasks, (unsigned)n_cols, col_base);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, col_base, bucket_task0, tasks);
+  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_base, bucket_task0, tasks);
   ZK_LAUNCH_CHECK(ctx);
   unsigned gridt = zk_blocks(max_tasks, 256);
   const unsigned capt = (unsigned)ctx->num_cu * 32;
   if (gridt > capt) gridt = capt;
   zk_prof_begin(ctx);
-  k_msm_accumulate<<<gridt, 256, 0, ctx->stream>>>(tasks, col_base + n_cols, off, entries, col_entries, basis->table, K, partials);
+  k_msm_accumulate<<<gridt, 256, 0, ctx->stream>>>(tasks, col_base + n_cols, off, entries, col_entries, basis->table, K, TASK_E, partials);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 0, 96.0 * (double)n * (double)n_cols);
   const size_t nb = (size_t)K * n_cols;
   unsigned gridb = zk_blocks(nb, 256);
   if (gridb > capt) gridb = capt;
-  k_msm_merge<<<gridb, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, n_cols, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
+  k_msm_merge<<<gridb, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, TASK_E, n_cols, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
   unsigned gridh = (unsigned)((heavy_cap + 3) / 4);
   if (gridh > 2048) gridh = 2048;
-  k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
+  k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, TASK_E, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
   if (K >= 64 && K <= 4096) {
     const unsigned per_col = (K >> 6) + 64;
     G1X *marg = partials;  // the accumulation partials are dead once the buckets are merged
-    const size_t waves = (n_cols * per_col + 7) / 8;
-    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, marg);
+    const unsigned L = n_cols <= 16 ? 64 : 8;  // few columns: latency (7 additions deep); many: work (1.4 per bucket)
+    const size_t waves = (n_cols * per_col + 64 / L - 1) / (64 / L);
+    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, L, marg);
     ZK_LAUNCH_CHECK(ctx);
     k_msm_weighted<<<(unsigned)n_cols, 128, 0, ctx->stream>>>(marg, K, (G1Affine *)out_dev);
     ZK_LAUNCH_CHECK(ctx);
