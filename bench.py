@@ -2,8 +2,8 @@
 """bench.py -- BFV proofs/sec on MI355X (metric of BASELINE.json; contract in the task statement, DESIGN.md "Measurement").
 
 A "step" = ONE complete proof of zk-fhe's BFV correct-encryption circuit at the reference's configuration
-(k = 13, N = 1024, Q = 536870909, the column layout pinned by the reference's configs/bfv.json): host witness
-generation + the whole create_proof (197 advice commits, lookup / permutation arguments, quotient, evaluations,
+(k = 13, N = 1024, Q = 536870909, the column layout pinned by the reference's configs/bfv.json): witness generation
+(phase 0 on the host, the 1.23 M-cell phase-1 gate stream on the GPU) + the whole create_proof (197 advice commits, lookup / permutation arguments, quotient, evaluations,
 SHPLONK) through zkfhe_bfv_prove.  The proving key, SRS tables and the input texts are resident before the timed
 region (the reference's 10.2 s likewise excludes SRS / pk loading).  Inputs are seeded synthetic BFV
 encryptions of that shape.  N > 1: independent proofs, one replica per rank -- weak scaling, no data-path collective.
@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+MODMUL_PEAK_G = 125.0        # G Montgomery products / s, all 256 CUs busy: measured, tools/microbench.py fr_mul (profiles/r1_microbench.md)
+MODMUL_PER_MIXED_ADD = 11.0  # XYZZ += affine: 8 M + 2 S, plus the conditional negation / identity handling ~ 1
 Q, T, B, N = 536870909, 7, 19, 1024
 
 
@@ -161,7 +163,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
                          "launches_per_proof": msm["launches"] / 2,
-                         "ntt_tile": {"achieved": ntt_ach, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
+                         # the bound that actually binds this kernel (SURVEY.md 8(d) "secondary, honest bound"): 256-bit modular
+                         # multiplications.  11 per mixed XYZZ addition; peak = the v_mad_u64_u32 Montgomery product rate
+                         # measured on this chip with tools/microbench.py (profiles/r1_microbench.md)
+                         "int_alu": {"achieved": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9, "peak": MODMUL_PEAK_G,
+                                     "unit": "G modmul/s", "frac": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G,
+                                     "mixed_additions_per_proof": msm["ops"] / 2},
+                         "ntt_tile": {"achieved": ntt_ach, "int_alu_frac": (ntt["ops"] / (ntt["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G) if ntt["launches"] else None, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

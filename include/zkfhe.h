@@ -76,6 +76,8 @@ int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms);   /* waits for the stop even
 int zkfhe_prof_enable(zkfhe_ctx *ctx, int on);
 int zkfhe_prof_reset(zkfhe_ctx *ctx);
 int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launches, double *algorithmic_bytes);
+/* arithmetic units of the profiled launches: which = 0 -> mixed point additions (k_msm_accumulate), 1 -> butterflies (k_ntt_tile) */
+int zkfhe_prof_read_ops(zkfhe_ctx *ctx, int which, double *ops);
 
 /* ---- coefficient-wise Fr arithmetic (device buffers, out may alias a or b) ----------------- */
 int zkfhe_fr_add(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);

@@ -13,7 +13,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     import torch  # noqa: F401
     import zk_fhe_amd as zk
-    from oracle import binding as orc
     ctx = zk.Context(0)
     rng = np.random.default_rng(1)
     res = {}
@@ -73,7 +72,15 @@ def main():
         buf.free()
     # MSM sweep: uniform scalars, n = 8192
     nn = 8192
-    bases = orc.g1_powers(orc.ints_to_mont([5])[0], orc.ints_to_mont([77])[0], nn)
+    # bases: k_i * G for random k_i, made on the device (zkfhe_g1_mul); G = (1, 2), Montgomery limbs
+    Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+    def limbs(v):
+        return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    gen = np.array([limbs((1 << 256) % Q_MOD) + limbs((2 << 256) % Q_MOD)] * nn, dtype=np.uint64)
+    ks = np.array([limbs(((int(x) % R_MOD) << 256) % R_MOD) for x in rng.integers(1, 1 << 62, nn)], dtype=np.uint64)
+    bases = ctx.g1_mul(gen, ks)
     res["msm"] = {}
     for c in (10, 11, 12, 13, 14):
         B = zk.Basis(ctx, bases, c)

@@ -19,7 +19,7 @@ _lib = None
 EXPORTS = [
     "zkfhe_ctx_create", "zkfhe_ctx_destroy", "zkfhe_last_error", "zkfhe_sync", "zkfhe_stream", "zkfhe_device_info",
     "zkfhe_dev_alloc", "zkfhe_dev_free", "zkfhe_upload", "zkfhe_download", "zkfhe_copy_dev", "zkfhe_memset_dev",
-    "zkfhe_timer_start", "zkfhe_timer_stop_ms", "zkfhe_prof_enable", "zkfhe_prof_reset", "zkfhe_prof_read",
+    "zkfhe_timer_start", "zkfhe_timer_stop_ms", "zkfhe_prof_enable", "zkfhe_prof_reset", "zkfhe_prof_read", "zkfhe_prof_read_ops",
     "zkfhe_fr_add", "zkfhe_fr_sub", "zkfhe_fr_mul", "zkfhe_fr_scale", "zkfhe_fr_to_mont", "zkfhe_fr_from_mont",
     "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain",
     "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
@@ -189,7 +189,10 @@ class Context:
                                              ctypes.POINTER(ctypes.c_double)]
         ms, cnt, by = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_double()
         self._check(self.lib.zkfhe_prof_read(self.h, which, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(by)))
-        return {"total_ms": ms.value, "launches": cnt.value, "algorithmic_bytes": by.value}
+        self.lib.zkfhe_prof_read_ops.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        ops = ctypes.c_double()
+        self._check(self.lib.zkfhe_prof_read_ops(self.h, which, ctypes.byref(ops)))
+        return {"total_ms": ms.value, "launches": cnt.value, "algorithmic_bytes": by.value, "ops": ops.value}
 
     def timer_start(self):
         self._check(self.lib.zkfhe_timer_start(self.h))

@@ -171,7 +171,7 @@ int zkfhe_prof_enable(zkfhe_ctx *ctx, int on) {
 int zkfhe_prof_reset(zkfhe_ctx *ctx) {
   ZK_ENTER(ctx);
   for (int i = 0; i < 2; ++i) {
-    ctx->prof_ms[i] = ctx->prof_bytes[i] = 0;
+    ctx->prof_ms[i] = ctx->prof_bytes[i] = ctx->prof_ops[i] = 0;
     ctx->prof_launches[i] = 0;
   }
   return ZKFHE_OK;
@@ -182,6 +182,13 @@ int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launc
   if (total_ms) *total_ms = ctx->prof_ms[which];
   if (launches) *launches = ctx->prof_launches[which];
   if (algorithmic_bytes) *algorithmic_bytes = ctx->prof_bytes[which];
+  return ZKFHE_OK;
+}
+
+int zkfhe_prof_read_ops(zkfhe_ctx *ctx, int which, double *ops) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, which >= 0 && which < 2 && ops != nullptr);
+  *ops = ctx->prof_ops[which];
   return ZKFHE_OK;
 }
 

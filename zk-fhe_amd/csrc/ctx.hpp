@@ -29,7 +29,7 @@ struct zkfhe_ctx {
   // profiling (zkfhe_prof_*): [0] = k_msm_accumulate, [1] = k_ntt_tile
   bool prof_on = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
-  double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0};
+  double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0}, prof_ops[2] = {0, 0};
   uint64_t prof_launches[2] = {0, 0};
   void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[4] = {0, 0, 0, 0};

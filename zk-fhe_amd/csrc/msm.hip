@@ -20,6 +20,7 @@
 //   * bucket reduction sum_b b*B_b: 256 threads per MSM, running sums over groups of buckets, then a
 //     weighted tree in LDS; the result is normalised to affine in the same kernel.
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
+#include <vector>
 #include <cstring>
 
 #include "ctx.hpp"
@@ -171,9 +172,17 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
 constexpr int TASK_E_MAX = 32;
 constexpr int MERGE_LIGHT = 8;  // partials merged by a single thread; more -> one wave per bucket
 static unsigned task_len(size_t total_entries) {
-  unsigned e = TASK_E_MAX;
-  while (e > 8 && total_entries / e < (size_t)196608) e >>= 1;
-  return e;
+  static int forced = -1;
+  if (forced < 0) {
+    const char *s = getenv("ZKFHE_TASK_E");
+    forced = s ? atoi(s) : 0;
+  }
+  if (forced > 0) return (unsigned)forced;
+  // measured on the k = 13 prover (profiles/r1_task_len.md): tasks of 8 keep every lane of k_msm_accumulate busy (the
+  // 136-column grand-product call runs at 96 % of the modmul peak) and cost ~5 partials per bucket in k_msm_merge;
+  // 16 and 32 trade a cheaper merge for idle lanes and come out slower end to end.
+  (void)total_entries;
+  return 8;
 }
 
 __global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, unsigned *__restrict__ col_tasks) {
@@ -239,8 +248,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
     const size_t col = tk.x / K;
     const unsigned b = tk.x - (unsigned)col * K;
     const unsigned *o = off + col * (K + 1);
-    const unsigned lo = o[b] + tk.y * TASK_E;
-    const unsigned hi = min(lo + (unsigned)TASK_E, o[b + 1]);
+    // the bucket's entries are cut into nt EQUAL slices (not TASK_E, TASK_E, ..., remainder): the lanes of a wave then
+    // run chains of nearly the same length instead of idling behind the longest one
+    const unsigned cnt = o[b + 1] - o[b], nt = (cnt + TASK_E - 1) / TASK_E;
+    const unsigned lo = o[b] + (unsigned)(((unsigned long long)tk.y * cnt) / nt);
+    const unsigned hi = o[b] + (unsigned)(((unsigned long long)(tk.y + 1) * cnt) / nt);
     const unsigned *e = entries + col * col_entries;
     // software pipeline: the table gather of entry k+1 (and the index of entry k+2) are in flight while entry k is
     // added -- PMC showed 40 % of the wave cycles of the plain loop waiting on this dependent load chain
@@ -277,8 +289,16 @@ __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ 
       continue;
     }
     G1X acc = G1X::identity();
-    const unsigned t0 = bucket_task0[g];
-    for (unsigned j = 0; j < nt; ++j) g1x_add(acc, partials[t0 + j]);
+    if (nt) {
+      const unsigned t0 = bucket_task0[g];
+      acc = partials[t0];
+      G1X nxt = nt > 1 ? partials[t0 + 1] : acc;
+      for (unsigned j = 1; j < nt; ++j) {  // the load of partial j+1 is in flight while partial j is added
+        const G1X cur = nxt;
+        if (j + 1 < nt) nxt = partials[t0 + j + 1];
+        g1x_add(acc, cur);
+      }
+    }
     buckets[g] = acc;
   }
 }
@@ -295,7 +315,22 @@ __device__ __forceinline__ G1X g1x_shfl_down(const G1X &p, int delta) {
   return r;
 }
 
-// one wave per heavy bucket: lanes stride over the partials, then a 6-step shuffle tree
+__device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
+  G1X r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.x.l[i] = __shfl_xor(p.x.l[i], mask);
+    r.y.l[i] = __shfl_xor(p.y.l[i], mask);
+    r.zz.l[i] = __shfl_xor(p.zz.l[i], mask);
+    r.zzz.l[i] = __shfl_xor(p.zzz.l[i], mask);
+  }
+  return r;
+}
+
+// Buckets with more than MERGE_LIGHT partials.  Up to MERGE_MEDIUM partials (every column has ~2^(254 mod c) such
+// buckets: the narrow top window piles its digits onto them): EIGHT lanes per bucket, lanes stride over the partials,
+// 3-step butterfly.  Beyond (skewed witness columns): one wave per bucket, 6-step shuffle tree.
+constexpr unsigned MERGE_MEDIUM = 128;
 __global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
                                                          const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, G1X *__restrict__ buckets,
                                                          const unsigned *__restrict__ heavy_count, const unsigned *__restrict__ heavy_list,
@@ -305,12 +340,35 @@ __global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restr
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned base = wave * 8; base < cnt; base += n_waves * 8) {
+    const unsigned h = base + (lane >> 3), sub = lane & 7;
+    size_t g = 0;
+    unsigned nt = 0, t0 = 0;
+    if (h < cnt) {
+      g = heavy_list[h];
+      const size_t col = g / K;
+      const unsigned b = (unsigned)(g - col * K);
+      const unsigned *o = off + col * (K + 1);
+      nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+      t0 = bucket_task0[g];
+    }
+    const bool mine = nt && nt <= MERGE_MEDIUM;
+    G1X acc = G1X::identity();
+    if (mine)
+      for (unsigned j = sub; j < nt; j += 8) g1x_add(acc, partials[t0 + j]);
+    for (int m = 1; m < 8; m <<= 1) {
+      const G1X other = g1x_shfl_xor(acc, m);
+      g1x_add(acc, other);
+    }
+    if (mine && sub == 0) buckets[g] = acc;
+  }
   for (unsigned h = wave; h < cnt; h += n_waves) {
     const size_t g = heavy_list[h];
     const size_t col = g / K;
     const unsigned b = (unsigned)(g - col * K);
     const unsigned *o = off + col * (K + 1);
     const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+    if (nt <= MERGE_MEDIUM) continue;
     const unsigned t0 = bucket_task0[g];
     G1X acc = G1X::identity();
     for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[t0 + j]);
@@ -401,18 +459,6 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restric
 // consecutive buckets across lanes.
 // k_msm_weighted: two waves per MSM; lane a forms a * R_a by double-and-add (<= 7 bits) and a 6-step butterfly sums
 // the lanes; then one lane normalises.
-__device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
-  G1X r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    r.x.l[i] = __shfl_xor(p.x.l[i], mask);
-    r.y.l[i] = __shfl_xor(p.y.l[i], mask);
-    r.zz.l[i] = __shfl_xor(p.zz.l[i], mask);
-    r.zzz.l[i] = __shfl_xor(p.zzz.l[i], mask);
-  }
-  return r;
-}
-
 __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ buckets, unsigned K, size_t n_cols, unsigned L /* lanes per output: 8 or 64 */,
                                                        G1X *__restrict__ marg /* [n_cols][A + 64] */) {
   const unsigned A = K >> 6;
@@ -621,11 +667,22 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   ZK_LAUNCH_CHECK(ctx);
   unsigned gridt = zk_blocks(max_tasks, 256);
   const unsigned capt = (unsigned)ctx->num_cu * 32;
-  if (gridt > capt) gridt = capt;
+  static int acc_blocks = -1;
+  if (acc_blocks < 0) {
+    const char *s = getenv("ZKFHE_ACC_BLOCKS");
+    acc_blocks = s ? atoi(s) : 0;
+  }
+  const unsigned capa = acc_blocks > 0 ? (unsigned)ctx->num_cu * acc_blocks : capt;
+  if (gridt > capa) gridt = capa;
   zk_prof_begin(ctx);
   k_msm_accumulate<<<gridt, 256, 0, ctx->stream>>>(tasks, col_base + n_cols, off, entries, col_entries, basis->table, K, TASK_E, partials);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 0, 96.0 * (double)n * (double)n_cols);
+  if (ctx->prof_on) {  // mixed additions of this launch = sorted entries = off[col][K] summed over the columns
+    std::vector<unsigned> tot(n_cols);
+    ZK_HIP(ctx, hipMemcpy2D(tot.data(), sizeof(unsigned), off + K, (size_t)K1 * sizeof(unsigned), sizeof(unsigned), n_cols, hipMemcpyDeviceToHost));
+    for (unsigned t : tot) ctx->prof_ops[0] += (double)t;
+  }
   const size_t nb = (size_t)K * n_cols;
   unsigned gridb = zk_blocks(nb, 256);
   if (gridb > capt) gridb = capt;

@@ -192,6 +192,7 @@ inline int launch_tile(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsign
   k_ntt_tile<LOGN><<<grid, N / 8, lds_bytes, ctx->stream>>>(a);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 1, 64.0 * (double)N * (double)tiles * (double)cols);
+  if (ctx->prof_on) ctx->prof_ops[1] += 0.5 * (double)N * LOGN * (double)tiles * (double)cols;  // butterflies
   return ZKFHE_OK;
 }
 
