@@ -9,10 +9,99 @@
 
 namespace zkhost {
 
+// limb storage with a small inline buffer: the circuit's integers stay below 2^192 (six limbs), so the ~30 k BigInt
+// temporaries of one witness never touch the heap; larger values (pairing exponents) spill to a heap block
+class LimbVec {
+ public:
+  LimbVec() {}
+  LimbVec(size_t n, uint32_t v) { assign(n, v); }
+  LimbVec(const LimbVec &o) { copy_from(o); }
+  LimbVec(LimbVec &&o) noexcept { steal(o); }
+  ~LimbVec() { release(); }
+  LimbVec &operator=(const LimbVec &o) {
+    if (this != &o) {
+      n_ = 0;
+      copy_from(o);
+    }
+    return *this;
+  }
+  LimbVec &operator=(LimbVec &&o) noexcept {
+    if (this != &o) {
+      release();
+      steal(o);
+    }
+    return *this;
+  }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  uint32_t &operator[](size_t i) { return data()[i]; }
+  const uint32_t &operator[](size_t i) const { return data()[i]; }
+  uint32_t &back() { return data()[n_ - 1]; }
+  const uint32_t &back() const { return data()[n_ - 1]; }
+  uint32_t *begin() { return data(); }
+  uint32_t *end() { return data() + n_; }
+  const uint32_t *begin() const { return data(); }
+  const uint32_t *end() const { return data() + n_; }
+  void clear() { n_ = 0; }
+  void pop_back() { --n_; }
+  void push_back(uint32_t v) {
+    reserve(n_ + 1);
+    data()[n_++] = v;
+  }
+  void assign(size_t n, uint32_t v) {
+    n_ = 0;
+    reserve(n);
+    std::fill(data(), data() + n, v);
+    n_ = (uint32_t)n;
+  }
+
+ private:
+  static constexpr uint32_t INLINE = 6;
+  uint32_t n_ = 0, cap_ = INLINE;
+  uint32_t *heap_ = nullptr;
+  uint32_t buf_[INLINE];
+  uint32_t *data() { return heap_ ? heap_ : buf_; }
+  const uint32_t *data() const { return heap_ ? heap_ : buf_; }
+  void reserve(size_t want) {
+    if (want <= cap_) return;
+    size_t nc = std::max<size_t>(want, (size_t)cap_ * 2);
+    uint32_t *nh = new uint32_t[nc];
+    std::copy(data(), data() + n_, nh);
+    delete[] heap_;
+    heap_ = nh;
+    cap_ = (uint32_t)nc;
+  }
+  void release() {
+    delete[] heap_;
+    heap_ = nullptr;
+    cap_ = INLINE;
+    n_ = 0;
+  }
+  void copy_from(const LimbVec &o) {
+    reserve(o.n_);
+    std::copy(o.data(), o.data() + o.n_, data());
+    n_ = o.n_;
+  }
+  void steal(LimbVec &o) {
+    n_ = o.n_;
+    if (o.heap_) {
+      heap_ = o.heap_;
+      cap_ = o.cap_;
+      o.heap_ = nullptr;
+      o.cap_ = INLINE;
+    } else {
+      heap_ = nullptr;
+      cap_ = INLINE;
+      std::copy(o.buf_, o.buf_ + o.n_, buf_);
+    }
+    o.n_ = 0;
+  }
+};
+
 class BigInt {
  public:
   bool neg = false;
-  std::vector<uint32_t> mag;  // little-endian limbs, no leading zeros; empty == 0
+  LimbVec mag;  // little-endian limbs, no leading zeros; empty == 0
 
   BigInt() {}
   BigInt(uint64_t v) { set_u64(v); }
@@ -205,10 +294,10 @@ class BigInt {
     trim();
     return (uint32_t)rem;
   }
-  static std::vector<uint32_t> add_mag(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) {
+  static LimbVec add_mag(const LimbVec &a, const LimbVec &b) {
     const auto &x = a.size() >= b.size() ? a : b;
     const auto &y = a.size() >= b.size() ? b : a;
-    std::vector<uint32_t> r(x.size() + 1, 0);
+    LimbVec r(x.size() + 1, 0);
     uint64_t carry = 0;
     for (size_t i = 0; i < x.size(); ++i) {
       uint64_t t = (uint64_t)x[i] + (i < y.size() ? y[i] : 0) + carry;
@@ -219,8 +308,8 @@ class BigInt {
     while (!r.empty() && r.back() == 0) r.pop_back();
     return r;
   }
-  static std::vector<uint32_t> sub_mag(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b) {  // |a| > |b|
-    std::vector<uint32_t> r(a.size(), 0);
+  static LimbVec sub_mag(const LimbVec &a, const LimbVec &b) {  // |a| > |b|
+    LimbVec r(a.size(), 0);
     int64_t borrow = 0;
     for (size_t i = 0; i < a.size(); ++i) {
       int64_t t = (int64_t)a[i] - (i < b.size() ? b[i] : 0) - borrow;

@@ -75,6 +75,8 @@ struct Workspace {
   U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
   U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
   U256 *host_pool = nullptr;   // pinned staging for the coefficient arrays of the GPU witness generator
+  G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
+  hipEvent_t ev_pts = nullptr;
   U256 *host_wblind = nullptr; // pinned staging for the blinding rows of device-generated columns
   DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
@@ -284,6 +286,8 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   const size_t nblind = ((size_t)std::max(pk->cfg.n_gate1 + pk->cfg.n_lookup, 2 * pk->cfg.n_lookup) + 1) * (pk->cfg.n() - pk->cfg.u());
   CK(ws->wblind.alloc(ctx, (nblind + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_wblind, (nblind + 8) * 32, hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
+  ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming));
   return ZKFHE_OK;
 }
 
@@ -516,7 +520,10 @@ class GpuPhase1 {
  public:
   GpuPhase1(zkfhe_ctx *c, const zkfhe_bfv_pk *k, Workspace *w) : ctx(c), pk(k), ws(w) {}
 
-  int run(const BfvState &st, const U256 evals[12]) {
+  // Everything that does not depend on the phase-1 challenge: the gadget launches (the four constrain_mul gates only
+  // reserve their cells) and the deferred inversions.  Enqueued behind the phase-0 commitment, so the GPU works on it
+  // while the host hashes that commitment and evaluates the RLC context.
+  int launch(const BfvState &st) {
     const uint64_t Q = pk->prm.Q, T = pk->prm.T, B = pk->prm.B;
     CK(alloc_witness_buffers(ctx, pk, ws));
     stream = ws->stream.fr();
@@ -532,16 +539,12 @@ class GpuPhase1 {
     const uint64_t delta_bits = st.delta.value.bits();
     ++h_used;
     pool_used = h_used;
-    // the four gate cells of each constrain_mul, Montgomery, staged after the inputs
-    Fr *mg_host = (Fr *)(ws->host_pool + h_used);
-    for (int i = 0; i < 4; ++i) {
-      mg_host[4 * i] = Fr::zero();
-      for (int j = 0; j < 3; ++j) mg_host[4 * i + 1 + j] = mont(evals[3 * i + j]);
-    }
-    const Fr *mg_dev = ws->pool.fr() + h_used;
+    // the four gate cells of each constrain_mul (filled in by finish()), staged after the inputs
+    mg_slot = h_used;
+    n_mg = 0;
     h_used += 16;
     pool_used = h_used;
-    ZK_HIP(ctx, hipMemcpyAsync(ws->pool.p, ws->host_pool, h_used * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(ws->pool.p, ws->host_pool, mg_slot * 32, hipMemcpyHostToDevice, ctx->stream));
 
     CK(in_range(e0, B, Q));
     CK(in_range(e1, B, Q));
@@ -550,13 +553,13 @@ class GpuPhase1 {
     const int n_side = 2;
     for (int side = 0; side < n_side; ++side) {
       const DevPoly &pku = side ? pk1_u : pk0_u, &q = side ? q1 : q0, &r = side ? r1 : r0, &qc = side ? q1c : q0c;
-      CK(mul_gate(mg_dev + 8 * side));                                   // pk_i * u = pk_i_u
+      CK(mul_gate());                                                    // pk_i * u = pk_i_u
       DevPoly pku_r;
       CK(reduce_by_modulo(pku, Q, pku_r));
       CK(in_field(q, Q));
       CK(in_field(r, Q));
       // reduce_by_cyclo (src/poly_chip.rs:183-223)
-      CK(mul_gate(mg_dev + 8 * side + 4));                               // quotient * cyclo = quotient_times_cyclo
+      CK(mul_gate());                                                    // quotient * cyclo = quotient_times_cyclo
       DevPoly sum, sum_mod;
       CK(add(qc, r, sum));
       CK(reduce_by_modulo(sum, Q, sum_mod));
@@ -590,7 +593,20 @@ class GpuPhase1 {
       zkw::k_scatter<<<g, 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->inv_slots.p, pk->n_inv_slots, ws->invtmp.fr());
       ZK_LAUNCH_CHECK(ctx);
     }
-    // stream -> gate columns (break points) and lookup columns
+    return ZKFHE_OK;
+  }
+
+  // evals[3 i .. 3 i + 2] = a(gamma), b(gamma), c(gamma) of the i-th constrain_mul: fill the reserved gate cells, then
+  // stream -> gate columns (break points) and lookup columns
+  int finish(const U256 evals[12]) {
+    Fr *mg_host = (Fr *)(ws->host_pool + mg_slot);
+    for (int i = 0; i < 4; ++i) {
+      mg_host[4 * i] = Fr::zero();
+      for (int j = 0; j < 3; ++j) mg_host[4 * i + 1 + j] = mont(evals[3 * i + j]);
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(ws->pool.fr() + mg_slot, mg_host, 16 * 32, hipMemcpyHostToDevice, ctx->stream));
+    for (unsigned i = 0; i < n_mg; ++i)
+      ZK_HIP(ctx, hipMemcpyAsync(stream + mg_off[i], ws->pool.fr() + mg_slot + 4 * i, 4 * 32, hipMemcpyDeviceToDevice, ctx->stream));
     const CircuitConfig &cfg = pk->cfg;
     const size_t n = cfg.n();
     zkw::k_place<<<grid_for(ctx, (size_t)cfg.n_gate1 * n), 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->place_start.p, (const unsigned *)pk->place_len.p,
@@ -611,7 +627,8 @@ class GpuPhase1 {
   const zkfhe_bfv_pk *pk;
   Workspace *ws;
   Fr *stream = nullptr;
-  size_t off = 0, pool_used = 0, h_used = 0;
+  size_t off = 0, pool_used = 0, h_used = 0, mg_slot = 0, mg_off[4] = {0, 0, 0, 0};
+  unsigned n_mg = 0;
 
   DevPoly stage(const PolyChip &p) {
     DevPoly d;
@@ -652,9 +669,9 @@ class GpuPhase1 {
     return gadget(zkw::G_IN_RANGE, a, nullptr, nullptr, zkw::cpc_in_range(z, y), z, y, Fr::zero());
   }
   int in_field(const DevPoly &a, uint64_t q) { return gadget(zkw::G_IN_FIELD, a, nullptr, nullptr, zkw::cpc_in_field(q), q, 0, Fr::zero()); }
-  int mul_gate(const Fr *cells_dev) {
-    if (off + 4 > pk->gate1_cells) return zk_fail_msg(ctx, ZKFHE_EINVAL, "GPU witness stream exceeds the keygen circuit shape");
-    ZK_HIP(ctx, hipMemcpyAsync(stream + off, cells_dev, 4 * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  int mul_gate() {
+    if (off + 4 > pk->gate1_cells || n_mg >= 4) return zk_fail_msg(ctx, ZKFHE_EINVAL, "GPU witness stream exceeds the keygen circuit shape");
+    mg_off[n_mg++] = off;
     off += 4;
     return ZKFHE_OK;
   }
@@ -732,12 +749,26 @@ struct OpenItem {
   U256 ev[4];            // canonical evaluations
 };
 
+// ZKFHE_TRACE=1: host-side phase times of one proof on stderr
+struct Trace {
+  bool on;
+  double t0, last;
+  Trace() : on(getenv("ZKFHE_TRACE") != nullptr), t0(now_ms()), last(t0) {}
+  void mark(const char *what) {
+    if (!on) return;
+    const double t = now_ms();
+    fprintf(stderr, "[zkfhe trace] %8.3f ms (+%7.3f) %s\n", t - t0, t - last, what);
+    last = t;
+  }
+};
+
 int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const char *input_json, const uint8_t seed[32],
                std::vector<uint8_t> &proof, std::vector<U256> &instances, float *timings) {
   const CircuitConfig &cfg = pk->cfg;
   const size_t n = cfg.n(), u = cfg.u(), ne = 4 * n;
   const unsigned k = cfg.k;
   const double t_start = now_ms();
+  Trace trace;
   PreRng rng(seed, (size_t)cfg.n_advice() * (n - u) + 2 * (size_t)cfg.n_lookup * (n - u) +
                         ((size_t)cfg.n_chunks() + cfg.n_lookup) * (n - u - 1) + n);
   Transcript tr;
@@ -751,12 +782,16 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ~BackendGuard() { poly_mul_backend() = nullptr; }
   } guard(&gpu_mul);
   // ------------------------------------------------------------ phase 0 witness
+  trace.mark("setup (rng thread, workspace)");
   const CircuitInput in = CircuitInput::parse_json(input_json);
+  trace.mark("parse_json");
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
   std::vector<Cell> make_public;
   BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
+  trace.mark("bfv_phase0");
   Assigner as(cfg, false, ws->host_adv);
   as.place(ctx0, true);
+  trace.mark("place phase 0");
   instances.clear();
   for (const Cell &c : make_public) instances.push_back(c.value);
   tr.common_scalar(pk->vk_digest);
@@ -772,12 +807,28 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
                             (size_t)(c_hi - c_lo) * n);
   };
   std::vector<AffinePoint> adv_commit(cfg.n_advice()), pts;
+  trace.mark("transcript: instances");
   CK(blind_and_upload(0, cfg.n_gate0));
-  CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+  trace.mark("blind + upload phase 0");
+  const bool host_witness = witness_on_host();
+  GpuPhase1 g1(ctx, pk, ws);
+  if (host_witness) {
+    CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+  } else {
+    // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
+    CK(alloc_witness_buffers(ctx, pk, ws));
+    CK(zkfhe_msm_batch(ctx, srs->g_lagrange, (const zkfhe_fr *)ws->adv_l.fr(), cfg.n_gate0, (zkfhe_g1_affine *)ws->points.p));
+    ZK_HIP(ctx, hipMemcpyAsync(ws->host_pts, ws->points.p, cfg.n_gate0 * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
+    CK(g1.launch(st));
+    ZK_HIP(ctx, hipEventSynchronize(ws->ev_pts));
+    pts.resize(cfg.n_gate0);
+    for (unsigned c = 0; c < cfg.n_gate0; ++c) pts[c] = point_canon(ws->host_pts[c]);
+  }
+  trace.mark("commit phase 0 (GPU)");
   for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = pts[c]);
   const U256 gamma_rlc = tr.squeeze();
   // ------------------------------------------------------------ phase 1 witness
-  const bool host_witness = witness_on_host();
   const size_t nbl = n - u;
   int *lookup_err = nullptr;
   if (host_witness) {
@@ -789,9 +840,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     // RLC context on the host (6 K cells), gate context (1.2 M cells) on the device
     U256 evals[12];
     bfv_phase1_rlc(st, ctx_rlc, gamma_rlc, evals);
+    trace.mark("rlc context");
     as.place(ctx_rlc, true);
-    GpuPhase1 g1(ctx, pk, ws);
-    CK(g1.run(st, evals));
+    trace.mark("place rlc");
+    CK(g1.finish(evals));
+    trace.mark("gpu phase 1 (enqueue)");
   }
   std::vector<std::vector<U256>> lookup_inputs(host_witness ? cfg.n_lookup : 0);
   for (unsigned i = 0; i < lookup_inputs.size(); ++i)
@@ -807,7 +860,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_HIP(ctx, hipMemcpy2DAsync(ws->adv_l.fr() + (size_t)cfg.n_gate0 * n + u, n * 32, ws->wblind.fr(), nbl * 32, nbl * 32, nc, hipMemcpyDeviceToDevice, ctx->stream));
     CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
   }
+  trace.mark("blind + upload phase 1");
   CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+  trace.mark("commit phase 1 (GPU)");
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
   tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
   // ------------------------------------------------------------ lookups: permuted input / table
@@ -856,6 +911,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       tr.write_point(ls_commit[i]);
     }
   }
+  trace.mark("lookup permute + commit");
   const U256 beta_c = tr.squeeze(), gamma_c = tr.squeeze();
   const Fr beta = mont(beta_c), gamma = mont(gamma_c);
   // ------------------------------------------------------------ permutation grand products
@@ -951,6 +1007,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   tr.write_point(rand_commit[0]);
   const Fr y = mont(tr.squeeze());
   const double t_commit = now_ms();
+  trace.mark("grand products + commits");
   // ------------------------------------------------------------ quotient
   CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr()));
   {
@@ -1038,6 +1095,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const U256 x_c = tr.squeeze();
   const Fr x = mont(x_c);
   const double t_quot = now_ms();
+  trace.mark("quotient");
   // ------------------------------------------------------------ evaluations at x * w^rot (barycentric, Lagrange form)
   const Fr xn = fr_pow(x, n);
   {
@@ -1246,6 +1304,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   tr.write_point(w_commit[0]);
   proof = tr.out;
   const double t_end = now_ms();
+  trace.mark("evaluations + shplonk");
   if (timings) {
     timings[0] = (float)(t_wit - t_start);
     timings[1] = (float)(t_commit - t_wit);
@@ -1284,6 +1343,8 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
     if (kv.second->host_blind) (void)hipHostFree(kv.second->host_blind);
     if (kv.second->host_pool) (void)hipHostFree(kv.second->host_pool);
     if (kv.second->host_wblind) (void)hipHostFree(kv.second->host_wblind);
+    if (kv.second->host_pts) (void)hipHostFree(kv.second->host_pts);
+    if (kv.second->ev_pts) (void)hipEventDestroy(kv.second->ev_pts);
     delete kv.second;
   }
   delete pk;
