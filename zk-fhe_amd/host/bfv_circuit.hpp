@@ -2,6 +2,7 @@
 // :63-165 (phase 0 + out-of-circuit precomputation), :171-301 (the phase-1 callback), restated on the
 // host.  The operation order below fixes the cell stream, which the reference's configs/bfv.json pins.
 #pragma once
+#include <thread>
 #include <array>
 #include <cctype>
 #include <fstream>
@@ -181,13 +182,47 @@ inline void bfv_phase1(const BfvState &st, const BfvParams &prm, Context &ctx_ga
 // The RLC context alone (the 12 `compute_rlc_fixed_len` evaluations behind the four constrain_mul calls, in circuit
 // order) -- used when the gate context is generated on the GPU.  evals[3*i .. 3*i+2] = a(gamma), b(gamma), c(gamma).
 inline void bfv_phase1_rlc(const BfvState &st, Context &ctx_rlc, const U256 &gamma, U256 evals[12]) {
-  const RlcChip rlc(gamma);
   const PolyChip *trip[4][3] = {{&st.pk0, &st.u, &st.pk0_u},
                                 {&st.quotient_0, &st.cyclo, &st.quotient_0_times_cyclo},
                                 {&st.pk1, &st.u, &st.pk1_u},
                                 {&st.quotient_1, &st.cyclo, &st.quotient_1_times_cyclo}};
+  if (ctx_rlc.record_structure) {  // keygen / mock: through the chip, which records copies and selectors
+    const RlcChip rlc(gamma);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 3; ++j) evals[3 * i + j] = rlc.compute_rlc_fixed_len(ctx_rlc, trip[i][j]->assigned_coefficients).value;
+    return;
+  }
+  // prover: values only.  The 12 Horner chains are independent: their cell blocks ([x0, x1, acc1, x2, acc2, ...], 2L - 1
+  // cells each, RlcChip::compute_rlc_fixed_len) are laid out first and filled by four threads, one per constrain_mul.
+  // acc stays canonical: acc * gamma is one Montgomery product with gamma * R.
+  size_t base[4][3], total = ctx_rlc.advice.size();
   for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 3; ++j) evals[3 * i + j] = rlc.compute_rlc_fixed_len(ctx_rlc, trip[i][j]->assigned_coefficients).value;
+    for (int j = 0; j < 3; ++j) {
+      const size_t L = trip[i][j]->assigned_coefficients.size();
+      base[i][j] = total;
+      for (size_t s = 1; s < L; ++s) ctx_rlc.selector.push_back((uint32_t)(total + 2 * s - 2));
+      total += 2 * L - 1;
+    }
+  ctx_rlc.advice.resize(total);
+  const zk::Fr g = fe::to_mont(gamma);
+  auto chain = [&](int i) {
+    for (int j = 0; j < 3; ++j) {
+      const std::vector<Cell> &in = trip[i][j]->assigned_coefficients;
+      U256 *out = ctx_rlc.advice.data() + base[i][j];
+      zk::Fr acc = fe::to_fr_raw(in[0].value);
+      out[0] = in[0].value;
+      for (size_t s = 1; s < in.size(); ++s) {
+        acc = zk::fp_add<zk::FrP>(zk::fp_mul<zk::FrP>(acc, g), fe::to_fr_raw(in[s].value));
+        out[2 * s - 1] = in[s].value;
+        out[2 * s] = fe::from_fr_raw(acc);
+      }
+      evals[3 * i + j] = fe::from_fr_raw(acc);
+    }
+  };
+  std::thread th[3];
+  for (int i = 1; i < 4; ++i) th[i - 1] = std::thread(chain, i);
+  chain(0);
+  for (auto &t : th) t.join();
 }
 
 // --------------------------------------------------------------------------------------------- layout
