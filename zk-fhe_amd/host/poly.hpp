@@ -124,12 +124,14 @@ class Poly {
     ZK_ASSERT(divisor[0].fits_u64() && !divisor[0].is_zero(), "leading coefficient of cyclo");
     const uint64_t lead = divisor[0].to_u64();
     std::vector<BigInt> quotient;
+    std::vector<size_t> nz;  // the divisor's non-zero terms (two for x^N + 1): the update loop only visits those
+    for (size_t i = 0; i < divisor.size(); ++i)
+      if (!divisor[i].is_zero()) nz.push_back(i);
     size_t pos = 0;
     while (dividend.size() - pos > divisor.size() - 1) {
       BigInt ratio = dividend[pos].div_trunc_u64(lead);
       if (!ratio.is_zero())
-        for (size_t i = 0; i < divisor.size(); ++i)
-          if (!divisor[i].is_zero()) dividend[pos + i] -= ratio * divisor[i];
+        for (size_t i : nz) dividend[pos + i] -= ratio * divisor[i];
       quotient.push_back(std::move(ratio));
       ++pos;
     }
