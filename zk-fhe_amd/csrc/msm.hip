@@ -167,22 +167,23 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
 // (witness columns hold thousands of 0/1 cells).  k_msm_task_count: tasks per column; k_msm_task_fill:
 // the task list (bucket id, slice); k_msm_accumulate: one thread per task -> partial sum;
 // k_msm_merge: one thread per bucket adds its partials (few), buckets with many partials go to a wave each.
-// The task length is chosen per call (task_len below): 32 when the call has enough entries to fill the chip with
-// such tasks, shorter (down to 8) for calls of a few columns, whose run time is the dependent chain of one task.
+// The task length is chosen per basis geometry (task_len below): ~1/5 of the bucket load of a full-width column.
 constexpr int TASK_E_MAX = 32;
 constexpr int MERGE_LIGHT = 8;  // partials merged by a single thread; more -> one wave per bucket
-static unsigned task_len(size_t total_entries) {
+static unsigned task_len(size_t col_entries, unsigned K) {
   static int forced = -1;
   if (forced < 0) {
     const char *s = getenv("ZKFHE_TASK_E");
     forced = s ? atoi(s) : 0;
   }
   if (forced > 0) return (unsigned)forced;
-  // measured on the k = 13 prover (profiles/r1_task_len.md): tasks of 8 keep every lane of k_msm_accumulate busy (the
-  // 136-column grand-product call runs at 96 % of the modmul peak) and cost ~5 partials per bucket in k_msm_merge;
-  // 16 and 32 trade a cheaper merge for idle lanes and come out slower end to end.
-  (void)total_entries;
-  return 8;
+  // ~5 tasks per bucket of a full-width column: measured on the k = 13 prover (profiles/r1_task_len.md), tasks of 8 at
+  // 40 entries per bucket keep every lane of k_msm_accumulate busy (96 % of the modmul peak on the 136-column
+  // grand-product call) for ~5 partials per bucket in k_msm_merge; longer tasks idle lanes, shorter ones drown the merge.
+  const size_t load = col_entries / K;
+  unsigned e = 8;
+  while (e < (unsigned)TASK_E_MAX && (size_t)e * 5 < load) e <<= 1;
+  return e;
 }
 
 __global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, unsigned *__restrict__ col_tasks) {
@@ -617,7 +618,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
-  const unsigned TASK_E = task_len(n_cols * col_entries);
+  const unsigned TASK_E = task_len(col_entries, K);
   const size_t max_tasks = (n_cols * col_entries) / TASK_E + (size_t)K * n_cols;      // upper bound on accumulation tasks
   const size_t heavy_cap = (n_cols * col_entries) / ((size_t)TASK_E * MERGE_LIGHT) + 1;  // buckets with > MERGE_LIGHT partials
   // scratch 1: hist | off | cursor | bucket_task0 | col_tasks | col_base | heavy_count | heavy_list | tasks
