@@ -119,6 +119,48 @@ def test_device_and_host_witness_generators_agree(ctx):
     srs.destroy()
 
 
+def test_generated_inputs_and_rejected_witnesses(ctx):
+    """zk_fhe_amd.inputs (real BFV keygen + encrypt) -> prove -> the C++ verifier accepts; inputs that break a range
+    check or the ciphertext identity are refused by the GPU witness path with a status, not proved."""
+    import zk_fhe_amd as zk
+    from zk_fhe_amd import inputs
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    prm = C.BfvParams()
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, json.dumps(inputs.empty(1024)), (1024, prm.Q, prm.T, prm.B), zk.BfvConfig.from_pinning(cfgj), replay=True)
+    vk = pk.export_vk()
+    good = inputs.generate(1024, prm.Q, prm.T, prm.B, seed=5)
+    proof, inst, _ = pk.prove(json.dumps(good), b"gen-5")
+    ok, why = zk.bfv_verify(vk, inst, proof)
+    assert ok, why
+    # e0 outside [-B, B]: the range gadget's is_less_than output is 0, the copy to the constant 1 is violated
+    bad = dict(good)
+    e0 = list(bad["e0"])
+    e0[7] = str(prm.B + 1)
+    bad["e0"] = e0
+    with pytest.raises(zk.ZkfheError):
+        pk.prove(json.dumps(bad), b"gen-5")
+    # u outside {0, 1, Q-1}
+    bad = dict(good)
+    u = list(bad["u"])
+    u[3] = "2"
+    bad["u"] = u
+    with pytest.raises(zk.ZkfheError):
+        pk.prove(json.dumps(bad), b"gen-5")
+    # a coefficient >= Q is refused before any GPU work (src/poly.rs:28 asserts coeff <= modulus; Q itself then fails the field check)
+    bad = dict(good)
+    c1 = list(bad["c1"])
+    c1[0] = str(prm.Q + 5)
+    bad["c1"] = c1
+    with pytest.raises(zk.ZkfheError):
+        pk.prove(json.dumps(bad), b"gen-5")
+    # the context is still usable afterwards
+    proof2, inst2, _ = pk.prove(json.dumps(good), b"gen-5")
+    assert proof2 == proof and inst2 == inst
+    pk.destroy()
+    srs.destroy()
+
+
 def test_concurrent_proofs_on_two_streams(ctx):
     """Two contexts (streams + workspaces) of the same GPU prove against one key at the same time: same bytes as alone."""
     import threading
