@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
 // the task list (bucket id, slice); k_msm_accumulate: one thread per task -> partial sum;
 // k_msm_merge: one thread per bucket adds its partials (few), buckets with many partials go to a wave each.
 // The task length is chosen per basis geometry (task_len below): ~1/5 of the bucket load of a full-width column.
-constexpr int TASK_E_MAX = 32;
+constexpr int TASK_E_MAX = 64;
 constexpr int MERGE_LIGHT = 8;  // partials merged by a single thread; more -> one wave per bucket
 static unsigned task_len(size_t col_entries, unsigned K) {
   static int forced = -1;
@@ -177,66 +177,104 @@ static unsigned task_len(size_t col_entries, unsigned K) {
     forced = s ? atoi(s) : 0;
   }
   if (forced > 0) return (unsigned)forced;
-  // ~5 tasks per bucket of a full-width column: measured on the k = 13 prover (profiles/r1_task_len.md), tasks of 8 at
-  // 40 entries per bucket keep every lane of k_msm_accumulate busy (96 % of the modmul peak on the 136-column
-  // grand-product call) for ~5 partials per bucket in k_msm_merge; longer tasks idle lanes, shorter ones drown the merge.
+  // ~3 tasks per bucket of a full-width column (profiles/r1_task_len.md): with the length-sorted task list every wave
+  // runs equal chains whatever E is, so E only trades the number of partials the merge has to add against the number
+  // of tasks available to fill the chip; 16 at k = 13 (40 entries per bucket) measured best end to end.
   const size_t load = col_entries / K;
   unsigned e = 8;
-  while (e < (unsigned)TASK_E_MAX && (size_t)e * 5 < load) e <<= 1;
+  while (e < (unsigned)TASK_E_MAX && (size_t)e * 3 < load) e <<= 1;
   return e;
 }
 
-__global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, unsigned *__restrict__ col_tasks) {
-  __shared__ unsigned sh[256];
+// Slices of a bucket with cnt entries: nt = ceil(cnt / E) slices, the first r = cnt % nt of length a + 1, the others of
+// length a = cnt / nt.  The task list is ordered by slice length, longest first (counting sort over the E length
+// classes): the 64 lanes of a wave then run chains of the SAME length -- with the bucket-ordered list a wave mixed
+// lengths between E/2 and E and idled behind its longest lane (measured: 54 % of the modmul peak at E = 32 against
+// 85 % at E = 8, where slices are nearly equal but every bucket costs five partials in the merge).
+constexpr unsigned TASK_BINS = 65;  // slice lengths 0..64
+struct Slices {
+  unsigned nt, a, r;
+};
+__device__ __forceinline__ Slices slices_of(unsigned cnt, unsigned TASK_E) {
+  Slices s;
+  s.nt = (cnt + TASK_E - 1) / TASK_E;
+  s.a = s.nt ? cnt / s.nt : 0;
+  s.r = s.nt ? cnt - s.a * s.nt : 0;
+  return s;
+}
+// position of partial j of a bucket in the task / partial arrays
+__device__ __forceinline__ unsigned partial_pos(const Slices &s, unsigned posA, unsigned posB, unsigned j) { return j < s.r ? posA + j : posB + (j - s.r); }
+
+// per column: number of slices of every length
+__global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, unsigned *__restrict__ col_hist /* [n_cols][TASK_BINS] */) {
+  __shared__ unsigned h[TASK_BINS];
+  for (unsigned i = threadIdx.x; i < TASK_BINS; i += 256) h[i] = 0;
+  __syncthreads();
   const unsigned *o = off + (size_t)blockIdx.x * (K + 1);
-  unsigned s = 0;
-  for (unsigned b = threadIdx.x; b < K; b += 256) s += (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
-    if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
-    __syncthreads();
+  for (unsigned b = threadIdx.x; b < K; b += 256) {
+    const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
+    if (!s.nt) continue;
+    if (s.r) atomicAdd(&h[s.a + 1], s.r);
+    atomicAdd(&h[s.a], s.nt - s.r);
   }
-  if (threadIdx.x == 0) col_tasks[blockIdx.x] = sh[0];
-}
-// exclusive scan over columns (single thread: n_cols is a few hundred), total in col_base[n_cols]
-__global__ void k_msm_task_colscan(const unsigned *__restrict__ col_tasks, unsigned n_cols, unsigned *__restrict__ col_base) {
-  if (threadIdx.x || blockIdx.x) return;
-  unsigned acc = 0;
-  for (unsigned c = 0; c < n_cols; ++c) {
-    col_base[c] = acc;
-    acc += col_tasks[c];
-  }
-  col_base[n_cols] = acc;
-}
-// per column: exclusive scan of tasks-per-bucket -> first task of every bucket, and the task list itself
-__global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, const unsigned *__restrict__ col_base,
-                                                       unsigned *__restrict__ bucket_task0 /* [n_cols][K] */, uint2 *__restrict__ tasks) {
-  __shared__ unsigned part[256];
-  const size_t col = blockIdx.x;
-  const unsigned *o = off + col * (K + 1);
-  const unsigned per = (K + 255) / 256;
-  const unsigned lo = threadIdx.x * per, hi = min(lo + per, K);
-  unsigned s = 0;
-  for (unsigned b = lo; b < hi; ++b) s += (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
-  part[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned acc = col_base[col];
-    for (int i = 0; i < 256; ++i) {
-      unsigned t = part[i];
-      part[i] = acc;
-      acc += t;
+  for (unsigned i = threadIdx.x; i < TASK_BINS; i += 256) col_hist[(size_t)blockIdx.x * TASK_BINS + i] = h[i];
+}
+// first task of every (length, column): lengths descending, columns ascending inside a length.  One block of 128 threads.
+__global__ void __launch_bounds__(128) k_msm_task_colscan(const unsigned *__restrict__ col_hist, unsigned n_cols, unsigned *__restrict__ col_base /* [n_cols][TASK_BINS] */,
+                                                          unsigned *__restrict__ n_tasks) {
+  __shared__ unsigned bin_total[TASK_BINS], bin_base[TASK_BINS];
+  const unsigned L = threadIdx.x;
+  if (L < TASK_BINS) {
+    unsigned s = 0;
+    for (unsigned c = 0; c < n_cols; ++c) s += col_hist[(size_t)c * TASK_BINS + L];
+    bin_total[L] = s;
+  }
+  __syncthreads();
+  if (L == 0) {
+    unsigned acc = 0;
+    for (int l = (int)TASK_BINS - 1; l >= 0; --l) {
+      bin_base[l] = acc;
+      acc += bin_total[l];
+    }
+    *n_tasks = acc;
+  }
+  __syncthreads();
+  if (L < TASK_BINS) {
+    unsigned acc = bin_base[L];
+    for (unsigned c = 0; c < n_cols; ++c) {
+      col_base[(size_t)c * TASK_BINS + L] = acc;
+      acc += col_hist[(size_t)c * TASK_BINS + L];
     }
   }
+}
+// per column: hand out the positions (LDS cursors per length class) and write the task list
+__global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, const unsigned *__restrict__ col_base,
+                                                       unsigned *__restrict__ bucket_posA, unsigned *__restrict__ bucket_posB /* [n_cols][K] each */,
+                                                       uint2 *__restrict__ tasks) {
+  __shared__ unsigned cur[TASK_BINS];
+  const size_t col = blockIdx.x;
+  for (unsigned i = threadIdx.x; i < TASK_BINS; i += 256) cur[i] = col_base[col * TASK_BINS + i];
   __syncthreads();
-  unsigned t0 = part[threadIdx.x];
-  for (unsigned b = lo; b < hi; ++b) {
-    const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
-    bucket_task0[col * K + b] = t0;
-    for (unsigned j = 0; j < nt; ++j) tasks[t0 + j] = make_uint2((unsigned)(col * K + b), j);
-    t0 += nt;
+  const unsigned *o = off + col * (K + 1);
+  for (unsigned b = threadIdx.x; b < K; b += 256) {
+    const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
+    if (!s.nt) continue;
+    const unsigned g = (unsigned)(col * K + b);
+    const unsigned posA = s.r ? atomicAdd(&cur[s.a + 1], s.r) : 0u;
+    const unsigned posB = atomicAdd(&cur[s.a], s.nt - s.r);
+    bucket_posA[g] = posA;
+    bucket_posB[g] = posB;
+    for (unsigned j = 0; j < s.r; ++j) tasks[posA + j] = make_uint2(g, j);
+    for (unsigned j = s.r; j < s.nt; ++j) tasks[posB + (j - s.r)] = make_uint2(g, j);
   }
+}
+
+// 16-byte load of four consecutive entry words at a 4-byte aligned address (the entry array is padded by 32 bytes)
+__device__ __forceinline__ uint4 ld_entries(const unsigned *p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
 }
 
 __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict__ tasks, const unsigned *__restrict__ n_tasks_ptr,
@@ -249,33 +287,39 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
     const size_t col = tk.x / K;
     const unsigned b = tk.x - (unsigned)col * K;
     const unsigned *o = off + col * (K + 1);
-    // the bucket's entries are cut into nt EQUAL slices (not TASK_E, TASK_E, ..., remainder): the lanes of a wave then
-    // run chains of nearly the same length instead of idling behind the longest one
-    const unsigned cnt = o[b + 1] - o[b], nt = (cnt + TASK_E - 1) / TASK_E;
-    const unsigned lo = o[b] + (unsigned)(((unsigned long long)tk.y * cnt) / nt);
-    const unsigned hi = o[b] + (unsigned)(((unsigned long long)(tk.y + 1) * cnt) / nt);
+    const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
+    const unsigned lo = o[b] + (tk.y < s.r ? tk.y * (s.a + 1) : tk.y * s.a + s.r);
+    const unsigned hi = lo + s.a + (tk.y < s.r ? 1u : 0u);
     const unsigned *e = entries + col * col_entries;
-    // software pipeline: the table gather of entry k+1 (and the index of entry k+2) are in flight while entry k is
-    // added -- PMC showed 40 % of the wave cycles of the plain loop waiting on this dependent load chain
+    // software pipeline: the table gather of entry k+1 is in flight while entry k is added (PMC showed 40 % of the wave
+    // cycles of the plain loop waiting on this dependent load chain).  The entry indices themselves come in 16-byte
+    // loads into an 8-entry shift window: with one 4-byte load per entry and lanes 4*E bytes apart, every lane pulled
+    // its own cache line through L1 once per entry.
     G1X acc = G1X::identity();
-    unsigned en = e[lo];
-    unsigned en1 = lo + 1 < hi ? e[lo + 1] : 0u;
-    G1Affine p = table[en & 0x7fffffffu];
-    for (unsigned k = lo; k < hi; ++k) {
-      const unsigned en2 = k + 2 < hi ? e[k + 2] : 0u;
+    const unsigned *ep = e + lo;
+    uint4 w0 = ld_entries(ep), w1 = ld_entries(ep + 4);
+    unsigned valid = 8;
+    G1Affine p = table[w0.x & 0x7fffffffu];
+    const unsigned cnt_e = hi - lo;
+    for (unsigned i = 0; i < cnt_e; ++i) {
+      const unsigned en = w0.x, en1 = w0.y;
       G1Affine pn = p;
-      if (k + 1 < hi) pn = table[en1 & 0x7fffffffu];
+      if (i + 1 < cnt_e) pn = table[en1 & 0x7fffffffu];
       g1x_add_affine(acc, p, (en >> 31) != 0);
       p = pn;
-      en = en1;
-      en1 = en2;
+      w0.x = w0.y, w0.y = w0.z, w0.z = w0.w, w0.w = w1.x;
+      w1.x = w1.y, w1.y = w1.z, w1.z = w1.w;
+      if (--valid == 4) {
+        w1 = ld_entries(ep + i + 5);   // entries i+5 .. i+8 of the slice (window now starts at i+1)
+        valid = 8;
+      }
     }
     partials[t] = acc;
   }
 }
 
 // bucket sum = sum of its partials.  Light buckets: one thread.  Heavy ones are listed for k_msm_merge_heavy.
-__global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
+__global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_posA, const unsigned *__restrict__ bucket_posB,
                                                    const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, size_t n_cols, G1X *__restrict__ buckets,
                                                    unsigned *__restrict__ heavy_count, unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
   const size_t total = (size_t)K * n_cols;
@@ -283,7 +327,8 @@ __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ 
     const size_t col = g / K;
     const unsigned b = (unsigned)(g - col * K);
     const unsigned *o = off + col * (K + 1);
-    const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+    const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
+    const unsigned nt = s.nt;
     if (nt > (unsigned)MERGE_LIGHT) {
       const unsigned slot = atomicAdd(heavy_count, 1u);
       if (slot < heavy_cap) heavy_list[slot] = (unsigned)g;
@@ -291,12 +336,12 @@ __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ 
     }
     G1X acc = G1X::identity();
     if (nt) {
-      const unsigned t0 = bucket_task0[g];
-      acc = partials[t0];
-      G1X nxt = nt > 1 ? partials[t0 + 1] : acc;
+      const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
+      acc = partials[partial_pos(s, pa, pb, 0)];
+      G1X nxt = nt > 1 ? partials[partial_pos(s, pa, pb, 1)] : acc;
       for (unsigned j = 1; j < nt; ++j) {  // the load of partial j+1 is in flight while partial j is added
         const G1X cur = nxt;
-        if (j + 1 < nt) nxt = partials[t0 + j + 1];
+        if (j + 1 < nt) nxt = partials[partial_pos(s, pa, pb, j + 1)];
         g1x_add(acc, cur);
       }
     }
@@ -332,7 +377,7 @@ __device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
 // buckets: the narrow top window piles its digits onto them): EIGHT lanes per bucket, lanes stride over the partials,
 // 3-step butterfly.  Beyond (skewed witness columns): one wave per bucket, 6-step shuffle tree.
 constexpr unsigned MERGE_MEDIUM = 128;
-__global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_task0,
+__global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_posA, const unsigned *__restrict__ bucket_posB,
                                                          const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, G1X *__restrict__ buckets,
                                                          const unsigned *__restrict__ heavy_count, const unsigned *__restrict__ heavy_list,
                                                          unsigned heavy_cap) {
@@ -344,19 +389,22 @@ __global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restr
   for (unsigned base = wave * 8; base < cnt; base += n_waves * 8) {
     const unsigned h = base + (lane >> 3), sub = lane & 7;
     size_t g = 0;
-    unsigned nt = 0, t0 = 0;
+    unsigned nt = 0, pa = 0, pb = 0;
+    Slices s = {0, 0, 0};
     if (h < cnt) {
       g = heavy_list[h];
       const size_t col = g / K;
       const unsigned b = (unsigned)(g - col * K);
       const unsigned *o = off + col * (K + 1);
-      nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
-      t0 = bucket_task0[g];
+      s = slices_of(o[b + 1] - o[b], TASK_E);
+      nt = s.nt;
+      pa = bucket_posA[g];
+      pb = bucket_posB[g];
     }
     const bool mine = nt && nt <= MERGE_MEDIUM;
     G1X acc = G1X::identity();
     if (mine)
-      for (unsigned j = sub; j < nt; j += 8) g1x_add(acc, partials[t0 + j]);
+      for (unsigned j = sub; j < nt; j += 8) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
     for (int m = 1; m < 8; m <<= 1) {
       const G1X other = g1x_shfl_xor(acc, m);
       g1x_add(acc, other);
@@ -368,11 +416,12 @@ __global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restr
     const size_t col = g / K;
     const unsigned b = (unsigned)(g - col * K);
     const unsigned *o = off + col * (K + 1);
-    const unsigned nt = (o[b + 1] - o[b] + TASK_E - 1) / TASK_E;
+    const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
+    const unsigned nt = s.nt;
     if (nt <= MERGE_MEDIUM) continue;
-    const unsigned t0 = bucket_task0[g];
+    const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
     G1X acc = G1X::identity();
-    for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[t0 + j]);
+    for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
     for (int d = 32; d > 0; d >>= 1) {
       const G1X other = g1x_shfl_down(acc, d);
       if ((int)lane < d) g1x_add(acc, other);
@@ -621,23 +670,25 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const unsigned TASK_E = task_len(col_entries, K);
   const size_t max_tasks = (n_cols * col_entries) / TASK_E + (size_t)K * n_cols;      // upper bound on accumulation tasks
   const size_t heavy_cap = (n_cols * col_entries) / ((size_t)TASK_E * MERGE_LIGHT) + 1;  // buckets with > MERGE_LIGHT partials
-  // scratch 1: hist | off | cursor | bucket_task0 | col_tasks | col_base | heavy_count | heavy_list | tasks
+  // scratch 1: hist | off | cursor | bucket_posA | bucket_posB | col_hist | col_base | n_tasks | heavy_count | heavy_list | tasks
   // scratch 2: entries     scratch 0: buckets | partials
-  const size_t words = 3 * n_cols * K1 + (size_t)K * n_cols + 2 * n_cols + 12 + heavy_cap + 2 * max_tasks;
+  const size_t words = 3 * n_cols * K1 + 2 * (size_t)K * n_cols + 2 * n_cols * TASK_BINS + 16 + heavy_cap + 2 * max_tasks;
   void *p1, *p2, *p0;
   int rc = zk_scratch(ctx, 1, words * sizeof(unsigned), &p1);
   if (rc) return rc;
-  rc = zk_scratch(ctx, 2, n_cols * col_entries * sizeof(unsigned), &p2);
+  rc = zk_scratch(ctx, 2, n_cols * col_entries * sizeof(unsigned) + 64, &p2);
   if (rc) return rc;
   rc = zk_scratch(ctx, 0, (n_cols * (size_t)K + max_tasks) * sizeof(G1X), &p0);
   if (rc) return rc;
   unsigned *hist = (unsigned *)p1;
   unsigned *off = hist + n_cols * K1;
   unsigned *cursor = off + n_cols * K1;
-  unsigned *bucket_task0 = cursor + n_cols * K1;
-  unsigned *col_tasks = bucket_task0 + (size_t)K * n_cols;
-  unsigned *col_base = col_tasks + n_cols;          // n_cols + 1 entries
-  unsigned *heavy_count = col_base + n_cols + 4;
+  unsigned *bucket_posA = cursor + n_cols * K1;
+  unsigned *bucket_posB = bucket_posA + (size_t)K * n_cols;
+  unsigned *col_hist = bucket_posB + (size_t)K * n_cols;
+  unsigned *col_base = col_hist + n_cols * TASK_BINS;
+  unsigned *n_tasks_dev = col_base + n_cols * TASK_BINS;
+  unsigned *heavy_count = n_tasks_dev + 4;
   unsigned *heavy_list = heavy_count + 4;
   uint2 *tasks = (uint2 *)(((uintptr_t)(heavy_list + heavy_cap) + 7) & ~(uintptr_t)7);
   unsigned *entries = (unsigned *)p2;
@@ -660,11 +711,11 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   ZK_LAUNCH_CHECK(ctx);
   k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_tasks);
+  k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_hist);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_task_colscan<<<1, 64, 0, ctx->stream>>>(col_tasks, (unsigned)n_cols, col_base);
+  k_msm_task_colscan<<<1, 128, 0, ctx->stream>>>(col_hist, (unsigned)n_cols, col_base, n_tasks_dev);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_base, bucket_task0, tasks);
+  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_base, bucket_posA, bucket_posB, tasks);
   ZK_LAUNCH_CHECK(ctx);
   unsigned gridt = zk_blocks(max_tasks, 256);
   const unsigned capt = (unsigned)ctx->num_cu * 32;
@@ -676,7 +727,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const unsigned capa = acc_blocks > 0 ? (unsigned)ctx->num_cu * acc_blocks : capt;
   if (gridt > capa) gridt = capa;
   zk_prof_begin(ctx);
-  k_msm_accumulate<<<gridt, 256, 0, ctx->stream>>>(tasks, col_base + n_cols, off, entries, col_entries, basis->table, K, TASK_E, partials);
+  k_msm_accumulate<<<gridt, 256, 0, ctx->stream>>>(tasks, n_tasks_dev, off, entries, col_entries, basis->table, K, TASK_E, partials);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 0, 96.0 * (double)n * (double)n_cols);
   if (ctx->prof_on) {  // mixed additions of this launch = sorted entries = off[col][K] summed over the columns
@@ -687,11 +738,11 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const size_t nb = (size_t)K * n_cols;
   unsigned gridb = zk_blocks(nb, 256);
   if (gridb > capt) gridb = capt;
-  k_msm_merge<<<gridb, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, TASK_E, n_cols, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
+  k_msm_merge<<<gridb, 256, 0, ctx->stream>>>(off, bucket_posA, bucket_posB, partials, K, TASK_E, n_cols, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
   unsigned gridh = (unsigned)((heavy_cap + 3) / 4);
   if (gridh > 2048) gridh = 2048;
-  k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_task0, partials, K, TASK_E, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
+  k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_posA, bucket_posB, partials, K, TASK_E, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
   if (K >= 64 && K <= 4096) {
     const unsigned per_col = (K >> 6) + 64;
