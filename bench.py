@@ -55,7 +55,7 @@ def synth_bfv_input(seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=12, help="concurrent proofs per GPU (one HIP stream + workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
