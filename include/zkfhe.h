@@ -190,6 +190,11 @@ int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, 
 /* Serialised verifying key: magic "ZKFHEVK1", 7 x u32 configuration, u32 n_fixed, u32 n_sigma, 32-byte vk digest, then
  * the fixed and sigma commitments as canonical affine x||y (64 B each).  What `keygen` writes to data/<name>.vk. */
 int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, size_t *len);
+/* Proving key on disk (the reference's keygen writes data/<name>.pk, README.md:38): configuration, break points, commitments
+ * and the fixed / permutation columns; the extended-domain tables are rebuilt on load.  A key is bound to the SRS it was
+ * generated with. */
+int zkfhe_bfv_pk_save(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, const char *path);
+int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zkfhe_bfv_pk **out);
 
 /* verify (README.md:48-52), host CPU only (no GPU, like the reference's verifier): replays the transcript, checks the
  * quotient identity at x, and ends in one BN254 pairing-product check.  instances: n_instances canonical 32-byte LE

@@ -161,6 +161,44 @@ def test_generated_inputs_and_rejected_witnesses(ctx):
     srs.destroy()
 
 
+def test_proving_key_save_and_load(ctx, tmp_path):
+    """zkfhe_bfv_pk_save / zkfhe_bfv_pk_load: the reloaded key proves the same bytes; damaged files are refused."""
+    import zk_fhe_amd as zk
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    prm = C.BfvParams()
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, open(os.path.join(G, "bfv_empty.in")).read(), (1024, prm.Q, prm.T, prm.B), zk.BfvConfig.from_pinning(cfgj))
+    text = open(os.path.join(G, "bfv.in")).read()
+    proof, inst, _ = pk.prove(text, b"pk-io")
+    path = str(tmp_path / "bfv.pk")
+    pk.save(path)
+    info = pk.info()
+    pk.destroy()
+    pk2 = zk.BfvProvingKey.load(ctx, srs, path, 1024)
+    assert pk2.info() == info
+    proof2, inst2, _ = pk2.prove(text, b"pk-io")
+    assert proof2 == proof and inst2 == inst
+    pk2.destroy()
+    raw = bytearray(open(path, "rb").read())
+    for damage in ("magic", "commit", "short"):
+        bad = bytearray(raw)
+        if damage == "magic":
+            bad[0] ^= 1
+        elif damage == "commit":
+            bad[len(raw) - (163 + 199) * 8192 * 32 - 8 - 32 - 64] ^= 1     # inside the last sigma commitment
+        else:
+            bad = bad[: len(bad) // 2]
+        p2 = str(tmp_path / ("bad_%s.pk" % damage))
+        open(p2, "wb").write(bytes(bad))
+        with pytest.raises(zk.ZkfheError):
+            zk.BfvProvingKey.load(ctx, srs, p2, 1024)
+    srs2 = zk.Srs(ctx, 12)
+    with pytest.raises(zk.ZkfheError):
+        zk.BfvProvingKey.load(ctx, srs2, path, 1024)
+    srs2.destroy()
+    srs.destroy()
+
+
 def test_concurrent_proofs_on_two_streams(ctx):
     """Two contexts (streams + workspaces) of the same GPU prove against one key at the same time: same bytes as alone."""
     import threading

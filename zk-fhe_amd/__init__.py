@@ -30,7 +30,7 @@ EXPORTS = [
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points",
     "zkfhe_srs_create", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
-    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_verify",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_verify",
     "zkfhe_version",
 ]
 
@@ -443,6 +443,38 @@ class Srs:
 
 class BfvProvingKey:
     """zkfhe_bfv_keygen: fixed + sigma polynomials, commitments and extended-domain tables resident in HBM."""
+
+    @staticmethod
+    def _sigs(lib):
+        vp = ctypes.c_void_p
+        lib.zkfhe_bfv_pk_save.argtypes = [vp, vp, ctypes.c_char_p]
+        lib.zkfhe_bfv_pk_load.argtypes = [vp, vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+
+    @classmethod
+    def load(cls, ctx, srs, path, n_poly):
+        """zkfhe_bfv_pk_load: a key written by save() (or by `bfv ... keygen`).  n_poly = N of the BFV parameters (sizes the
+        instance buffer of prove())."""
+        self = cls.__new__(cls)
+        cls._sigs(ctx.lib)
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.zkfhe_bfv_pk_load(ctx.h, srs.h, os.fsencode(path), ctypes.byref(h)))
+        self.ctx, self.srs, self.params, self.config, self.h = ctx, srs, (int(n_poly), 0, 0, 0), None, h
+        self._prove_sigs(ctx.lib)
+        return self
+
+    def save(self, path):
+        self._sigs(self.ctx.lib)
+        self.ctx._check(self.ctx.lib.zkfhe_bfv_pk_save(self.ctx.h, self.h, os.fsencode(path)))
+
+    @staticmethod
+    def _prove_sigs(lib):
+        vp = ctypes.c_void_p
+        lib.zkfhe_bfv_pk_destroy.argtypes = [vp, vp]
+        lib.zkfhe_bfv_pk_info.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        lib.zkfhe_bfv_pk_commitments.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+        lib.zkfhe_bfv_pk_break_points.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_uint32)]
+        lib.zkfhe_bfv_prove.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                        ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_float)]
 
     def __init__(self, ctx, srs, input_json_text, params, config, replay=False):
         lib = ctx.lib

@@ -232,7 +232,8 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> vkb(vlen);
     CHECK(zkfhe_bfv_pk_export_vk(pk, vkb.data(), vkb.size(), &vlen));
     std::ofstream(data_path + "/" + name + ".vk", std::ios::binary).write((const char *)vkb.data(), (std::streamsize)vlen);
-    printf("keygen done; pinning written to %s, verifying key to %s/%s.vk; vk digest ", pin_path.c_str(), data_path.c_str(), name.c_str());
+    CHECK(zkfhe_bfv_pk_save(ctx, pk, (data_path + "/" + name + ".pk").c_str()));   // README.md:38: keygen writes data/<name>.pk
+    printf("keygen done; pinning written to %s, keys to %s/%s.{pk,vk}; vk digest ", pin_path.c_str(), data_path.c_str(), name.c_str());
     for (int i = 31; i >= 0; --i) printf("%02x", d[i]);
     printf("\n");
   } else {
@@ -240,14 +241,20 @@ int main(int argc, char **argv) {
       fprintf(stderr, "prove needs %s (run keygen first)\n", pin_path.c_str());
       return 1;
     }
-    // structure comes from an all-zero input of the same shape (the reference's bfv_empty.in, README.md:31)
-    std::string empty = text;
-    for (size_t i = 0; i + 1 < empty.size(); ++i)
-      if (empty[i] == '"' && isdigit((unsigned char)empty[i + 1])) {
-        size_t j = empty.find('"', i + 1);
-        empty.replace(i + 1, j - i - 1, "0");
-      }
-    CHECK(zkfhe_bfv_keygen(ctx, srs, empty.c_str(), &prm, &pin.c, &pk));
+    const std::string pk_path = data_path + "/" + name + ".pk";
+    if (FILE *pf = fopen(pk_path.c_str(), "rb")) {
+      fclose(pf);
+      CHECK(zkfhe_bfv_pk_load(ctx, srs, pk_path.c_str(), &pk));   // the key written by keygen
+    } else {
+      // no key on disk: rebuild it; structure comes from an all-zero input of the same shape (bfv_empty.in, README.md:31)
+      std::string empty = text;
+      for (size_t i = 0; i + 1 < empty.size(); ++i)
+        if (empty[i] == '"' && isdigit((unsigned char)empty[i + 1])) {
+          size_t j = empty.find('"', i + 1);
+          empty.replace(i + 1, j - i - 1, "0");
+        }
+      CHECK(zkfhe_bfv_keygen(ctx, srs, empty.c_str(), &prm, &pin.c, &pk));
+    }
     std::vector<uint8_t> proof(1 << 20), instb((size_t)32 << 20);
     size_t len = 0, ninst = instb.size() / 32;
     uint8_t seed32[32] = {0};

@@ -318,6 +318,58 @@ int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr,
   return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->tmp_c.p, (zkfhe_fr *)ext, count, (int)pk->cfg.k, 2, (const zkfhe_fr *)&g, 0);
 }
 
+// extended-coset evaluations of the fixed / sigma columns, l_0 / l_last / l_active and X on the coset: derived from the
+// Lagrange-form columns, rebuilt on load instead of stored (4x the size of the columns themselves)
+int build_resident_tables(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws) {
+  const CircuitConfig &cfg = pk->cfg;
+  const size_t n = cfg.n(), cells = (size_t)cfg.n_perm() * n;
+  const NttDomain *dom;
+  CK(zk_domain(ctx, (int)cfg.k, &dom));
+  CK(pk->fixed_ext.alloc(ctx, (size_t)cfg.n_fixed() * 4 * n * 32));
+  CK(pk->sigma_ext.alloc(ctx, cells * 4 * 32));
+  CK(pk->l_ext.alloc(ctx, 3 * 4 * n * 32));
+  CK(pk->xs_ext.alloc(ctx, 4 * n * 32));
+  CK(extend_cols(ctx, pk, ws, pk->fixed_l.fr(), cfg.n_fixed(), pk->fixed_ext.fr()));
+  CK(extend_cols(ctx, pk, ws, pk->sigma_l.fr(), cfg.n_perm(), pk->sigma_ext.fr()));
+  {
+    std::vector<U256> l(3 * n, fe::zero());
+    const size_t u = cfg.u();
+    l[0] = fe::one();
+    l[n + u] = fe::one();
+    for (size_t i = 0; i < u; ++i) l[2 * n + i] = fe::one();
+    CK(upload_canon(ctx, ws->misc.fr(), l.data(), 3 * n));
+    CK(extend_cols(ctx, pk, ws, ws->misc.fr(), 3, pk->l_ext.fr()));
+  }
+  {
+    const Fr wext = zk_fr_root_of_unity((int)cfg.k + 2);
+    Fr shift = mont_u64(COSET_G);
+    for (int k1 = 0; k1 < 4; ++k1) {
+      zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(shift, dom->omega, pk->xs_ext.fr() + (size_t)k1 * n, n);
+      ZK_LAUNCH_CHECK(ctx);
+      shift = shift * wext;
+    }
+  }
+  return ZKFHE_OK;
+}
+
+U256 vk_digest_of(const zkfhe_bfv_pk *pk) {
+  const CircuitConfig &cfg = pk->cfg;
+  Blake2b h(64, "zkfhe-vk");
+  const uint32_t hdr[7] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits};
+  h.update(hdr, sizeof(hdr));
+  for (const auto &p : pk->fixed_commit) {
+    h.update(p.x.l, 32);
+    h.update(p.y.l, 32);
+  }
+  for (const auto &p : pk->sigma_commit) {
+    h.update(p.x.l, 32);
+    h.update(p.y.l, 32);
+  }
+  uint8_t d[64];
+  h.digest(d);
+  return from_bytes_wide(d);
+}
+
 int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const BfvParams &prm, CircuitConfig cfg, bool replay,
                 zkfhe_bfv_pk **out) {
   const size_t n = cfg.n();
@@ -429,48 +481,10 @@ int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, co
   CK(get_workspace(ctx, pk, &ws));
   CK(commit_cols(ctx, srs->g_lagrange, pk->fixed_l.fr(), cfg.n_fixed(), (G1Affine *)ws->points.p, pk->fixed_commit));
   CK(commit_cols(ctx, srs->g_lagrange, pk->sigma_l.fr(), cfg.n_perm(), (G1Affine *)ws->points.p, pk->sigma_commit));
-  // ---- extended-domain evaluations kept resident
-  CK(pk->fixed_ext.alloc(ctx, (size_t)cfg.n_fixed() * 4 * n * 32));
-  CK(pk->sigma_ext.alloc(ctx, cells * 4 * 32));
-  CK(pk->l_ext.alloc(ctx, 3 * 4 * n * 32));
-  CK(pk->xs_ext.alloc(ctx, 4 * n * 32));
-  CK(extend_cols(ctx, pk, ws, pk->fixed_l.fr(), cfg.n_fixed(), pk->fixed_ext.fr()));
-  CK(extend_cols(ctx, pk, ws, pk->sigma_l.fr(), cfg.n_perm(), pk->sigma_ext.fr()));
-  {
-    std::vector<U256> l(3 * n, fe::zero());
-    const size_t u = cfg.u();
-    l[0] = fe::one();
-    l[n + u] = fe::one();
-    for (size_t i = 0; i < u; ++i) l[2 * n + i] = fe::one();
-    CK(upload_canon(ctx, ws->misc.fr(), l.data(), 3 * n));
-    CK(extend_cols(ctx, pk, ws, ws->misc.fr(), 3, pk->l_ext.fr()));
-  }
-  {
-    const Fr wext = zk_fr_root_of_unity((int)cfg.k + 2);
-    Fr shift = mont_u64(COSET_G);
-    for (int k1 = 0; k1 < 4; ++k1) {
-      zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(shift, dom->omega, pk->xs_ext.fr() + (size_t)k1 * n, n);
-      ZK_LAUNCH_CHECK(ctx);
-      shift = shift * wext;
-    }
-  }
+  CK(build_resident_tables(ctx, pk, ws));
   CK(zkfhe_sync(ctx));
   tgt.release();
-  // ---- vk digest
-  Blake2b h(64, "zkfhe-vk");
-  const uint32_t hdr[7] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits};
-  h.update(hdr, sizeof(hdr));
-  for (const auto &p : pk->fixed_commit) {
-    h.update(p.x.l, 32);
-    h.update(p.y.l, 32);
-  }
-  for (const auto &p : pk->sigma_commit) {
-    h.update(p.x.l, 32);
-    h.update(p.y.l, 32);
-  }
-  uint8_t d[64];
-  h.digest(d);
-  pk->vk_digest = from_bytes_wide(d);
+  pk->vk_digest = vk_digest_of(pk);
   *out = pk;
   return ZKFHE_OK;
 }
@@ -1348,6 +1362,173 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
     delete kv.second;
   }
   delete pk;
+  return ZKFHE_OK;
+}
+
+// ---- proving key on disk ("ZKFHEPK1"): configuration, break points, the structure lists of the GPU witness generator,
+// commitments and the fixed / sigma columns in Lagrange form (device limbs as they are).  The extended-coset tables are
+// rebuilt on load.  The key is bound to the SRS it was generated with (its commitments are stored, not recomputed).
+namespace {
+struct FileW {
+  FILE *f;
+  bool ok = true;
+  void raw(const void *p, size_t n) { ok = ok && fwrite(p, 1, n, f) == n; }
+  void u32(uint32_t v) { raw(&v, 4); }
+  void u64(uint64_t v) { raw(&v, 8); }
+  void vec32(const std::vector<uint32_t> &v) {
+    u64(v.size());
+    if (!v.empty()) raw(v.data(), v.size() * 4);
+  }
+};
+struct FileR {
+  FILE *f;
+  bool ok = true;
+  void raw(void *p, size_t n) { ok = ok && fread(p, 1, n, f) == n; }
+  uint32_t u32() {
+    uint32_t v = 0;
+    raw(&v, 4);
+    return v;
+  }
+  uint64_t u64() {
+    uint64_t v = 0;
+    raw(&v, 8);
+    return v;
+  }
+  std::vector<uint32_t> vec32(size_t limit) {
+    const uint64_t n = u64();
+    std::vector<uint32_t> v;
+    if (!ok || n > limit) {
+      ok = false;
+      return v;
+    }
+    v.resize(n);
+    if (n) raw(v.data(), n * 4);
+    return v;
+  }
+};
+int download_u32(zkfhe_ctx *ctx, const DevBuf &b, size_t count, std::vector<uint32_t> &out) {
+  out.resize(count);
+  if (count) CK(zkfhe_download(ctx, out.data(), b.p, count * 4));
+  return ZKFHE_OK;
+}
+int upload_u32(zkfhe_ctx *ctx, DevBuf &b, const std::vector<uint32_t> &v) {
+  CK(b.alloc(ctx, (v.size() + 1) * 4));
+  if (!v.empty()) CK(zkfhe_upload(ctx, b.p, v.data(), v.size() * 4));
+  return ZKFHE_OK;
+}
+}  // namespace
+
+int zkfhe_bfv_pk_save(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, const char *path) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, pk != nullptr && path != nullptr);
+  const CircuitConfig &cfg = pk->cfg;
+  const size_t n = cfg.n();
+  std::vector<uint32_t> lookup_src, inv_slots, place_start, place_len;
+  CK(download_u32(ctx, pk->lookup_src, pk->n_lookup_cells, lookup_src));
+  CK(download_u32(ctx, pk->inv_slots, pk->n_inv_slots, inv_slots));
+  CK(download_u32(ctx, pk->place_start, cfg.n_gate1, place_start));
+  CK(download_u32(ctx, pk->place_len, cfg.n_gate1, place_len));
+  std::vector<uint8_t> cols((size_t)(cfg.n_fixed() + cfg.n_perm()) * n * 32);
+  CK(zkfhe_download(ctx, cols.data(), pk->fixed_l.p, (size_t)cfg.n_fixed() * n * 32));
+  CK(zkfhe_download(ctx, cols.data() + (size_t)cfg.n_fixed() * n * 32, pk->sigma_l.p, (size_t)cfg.n_perm() * n * 32));
+  FILE *f = fopen(path, "wb");
+  if (!f) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("cannot write ") + path);
+  FileW w{f};
+  w.raw("ZKFHEPK1", 8);
+  const uint32_t hdr[7] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits};
+  w.raw(hdr, sizeof(hdr));
+  w.vec32(cfg.bp_gate0), w.vec32(cfg.bp_gate1), w.vec32(cfg.bp_rlc);
+  w.u64(pk->prm.N), w.u64(pk->prm.Q), w.u64(pk->prm.T), w.u64(pk->prm.B);
+  w.u64(pk->gate1_cells);
+  w.vec32(lookup_src), w.vec32(inv_slots), w.vec32(place_start), w.vec32(place_len);
+  w.u64(pk->fixed_commit.size()), w.u64(pk->sigma_commit.size());
+  for (const auto &pt : pk->fixed_commit) w.raw(&pt, sizeof(AffinePoint));
+  for (const auto &pt : pk->sigma_commit) w.raw(&pt, sizeof(AffinePoint));
+  w.raw(pk->vk_digest.l, 32);
+  w.u64(cols.size());
+  w.raw(cols.data(), cols.size());
+  const bool ok = w.ok && fclose(f) == 0;
+  if (!ok) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("short write to ") + path);
+  return ZKFHE_OK;
+}
+
+int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zkfhe_bfv_pk **out) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, srs != nullptr && path != nullptr && out != nullptr);
+  FILE *f = fopen(path, "rb");
+  if (!f) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("cannot read ") + path);
+  FileR r{f};
+  char magic[8];
+  r.raw(magic, 8);
+  if (!r.ok || memcmp(magic, "ZKFHEPK1", 8) != 0) {
+    fclose(f);
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + " is not a ZKFHEPK1 proving key");
+  }
+  zkfhe_bfv_pk *pk = new zkfhe_bfv_pk();
+  auto fail = [&](const std::string &why) {
+    fclose(f);
+    zkfhe_bfv_pk_destroy(ctx, pk);
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + ": " + why);
+  };
+  try {
+    uint32_t hdr[7];
+    r.raw(hdr, sizeof(hdr));
+    CircuitConfig &cfg = pk->cfg;
+    cfg.k = hdr[0], cfg.n_gate0 = hdr[1], cfg.n_gate1 = hdr[2], cfg.n_lookup = hdr[3], cfg.n_rlc = hdr[4], cfg.unusable_rows = hdr[5], cfg.lookup_bits = hdr[6];
+    if (!r.ok || cfg.k < 3 || cfg.k > 20 || cfg.n_gate0 + cfg.n_gate1 > 4096 || cfg.n_lookup > 4096 || cfg.n_rlc > 4096) return fail("bad header");
+    if (cfg.k != srs->k) return fail("proving key and SRS have different k");
+    cfg.bp_gate0 = r.vec32(1 << 16), cfg.bp_gate1 = r.vec32(1 << 16), cfg.bp_rlc = r.vec32(1 << 16);
+    pk->prm.N = r.u64(), pk->prm.Q = r.u64(), pk->prm.T = r.u64(), pk->prm.B = r.u64();
+    pk->gate1_cells = r.u64();
+    const size_t n = cfg.n(), max_cells = (size_t)cfg.n_gate1 * n;
+    const std::vector<uint32_t> lookup_src = r.vec32(max_cells), inv_slots = r.vec32(max_cells), place_start = r.vec32(cfg.n_gate1), place_len = r.vec32(cfg.n_gate1);
+    if (!r.ok || pk->gate1_cells > max_cells || place_start.size() != cfg.n_gate1 || place_len.size() != cfg.n_gate1) return fail("bad structure lists");
+    for (uint32_t o : lookup_src)
+      if (o >= pk->gate1_cells) return fail("lookup offset outside the gate stream");
+    for (uint32_t o : inv_slots)
+      if (o >= pk->gate1_cells) return fail("inverse slot outside the gate stream");
+    for (unsigned c = 0; c < cfg.n_gate1; ++c)
+      if ((size_t)place_start[c] + place_len[c] > pk->gate1_cells || place_len[c] > n) return fail("column range outside the gate stream");
+    pk->n_lookup_cells = lookup_src.size();
+    pk->n_inv_slots = inv_slots.size();
+    const uint64_t nf = r.u64(), ns = r.u64();
+    if (!r.ok || nf != cfg.n_fixed() || ns != cfg.n_perm()) return fail("commitment counts do not match the configuration");
+    pk->fixed_commit.resize(nf), pk->sigma_commit.resize(ns);
+    for (auto &pt : pk->fixed_commit) r.raw(&pt, sizeof(AffinePoint));
+    for (auto &pt : pk->sigma_commit) r.raw(&pt, sizeof(AffinePoint));
+    r.raw(pk->vk_digest.l, 32);
+    const uint64_t col_bytes = r.u64();
+    if (!r.ok || col_bytes != (uint64_t)(cfg.n_fixed() + cfg.n_perm()) * n * 32) return fail("column block has the wrong size");
+    if (!(vk_digest_of(pk) == pk->vk_digest)) return fail("verifying-key digest does not match the stored commitments");
+    std::vector<uint8_t> cols(col_bytes);
+    r.raw(cols.data(), cols.size());
+    if (!r.ok) return fail("truncated file");
+    fclose(f);
+    f = nullptr;
+    int rc;
+    if ((rc = upload_u32(ctx, pk->lookup_src, lookup_src)) || (rc = upload_u32(ctx, pk->inv_slots, inv_slots)) ||
+        (rc = upload_u32(ctx, pk->place_start, place_start)) || (rc = upload_u32(ctx, pk->place_len, place_len)) ||
+        (rc = pk->fixed_l.alloc(ctx, (size_t)cfg.n_fixed() * n * 32)) || (rc = pk->sigma_l.alloc(ctx, (size_t)cfg.n_perm() * n * 32)) ||
+        (rc = pk->dpow.alloc(ctx, (size_t)cfg.n_perm() * 32)) ||
+        (rc = zkfhe_upload(ctx, pk->fixed_l.p, cols.data(), (size_t)cfg.n_fixed() * n * 32)) ||
+        (rc = zkfhe_upload(ctx, pk->sigma_l.p, cols.data() + (size_t)cfg.n_fixed() * n * 32, (size_t)cfg.n_perm() * n * 32))) {
+      zkfhe_bfv_pk_destroy(ctx, pk);
+      return rc;
+    }
+    U256 dcan;
+    memcpy(dcan.l, DELTA_CANON, 32);
+    zkp::k_powers<<<1, 256, 0, ctx->stream>>>(Fr::one(), mont(dcan), pk->dpow.fr(), cfg.n_perm());
+    Workspace *ws;
+    if ((rc = get_workspace(ctx, pk, &ws)) || (rc = build_resident_tables(ctx, pk, ws)) || (rc = zkfhe_sync(ctx))) {
+      zkfhe_bfv_pk_destroy(ctx, pk);
+      return rc;
+    }
+  } catch (const std::exception &e) {
+    if (f) fclose(f);
+    zkfhe_bfv_pk_destroy(ctx, pk);
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, e.what());
+  }
+  *out = pk;
   return ZKFHE_OK;
 }
 
