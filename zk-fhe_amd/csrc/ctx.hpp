@@ -82,6 +82,8 @@ inline void zk_prof_end(zkfhe_ctx *ctx, int which, double bytes) {
 
 // returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse
 int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
+// stream-ordered device-to-device copy (own kernel for large blocks)
+int zk_copy_d2d(zkfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out);
 
 // host-side Fr helpers (same code as the device, compiled for the host)

@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restric
   }
 }
 
-// ---- fast bucket reduction for 64 <= K <= 4096 -------------------------------------------------------
+// ---- fast bucket reduction for 64 <= K <= 32768 -------------------------------------------------------
 // bucket index idx = 64 a + b carries weight idx + 1, so
 //     sum (idx+1) B = 64 * sum_a a R_a  +  sum_b (b+1) C_b ,   R_a = sum_b B[a][b],  C_b = sum_a B[a][b].
 // k_msm_marginals: L lanes per row / column sum -- every lane adds up to 64/L buckets serially, then a butterfly over
@@ -510,16 +510,17 @@ __global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restric
 // k_msm_weighted: two waves per MSM; lane a forms a * R_a by double-and-add (<= 7 bits) and a 6-step butterfly sums
 // the lanes; then one lane normalises.
 __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ buckets, unsigned K, size_t n_cols, unsigned L /* lanes per output: 8 or 64 */,
+                                                       unsigned w0, unsigned w_cnt /* outputs w0 .. w0 + w_cnt - 1 of every column */,
                                                        G1X *__restrict__ marg /* [n_cols][A + 64] */) {
   const unsigned A = K >> 6;
   const unsigned per_col = A + 64;
   const unsigned G = 64 / L;  // outputs per wave
   const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
   const unsigned lane = threadIdx.x & 63, g = lane & (G - 1), sub = lane / G;
-  const size_t o = wave * G + g;  // output index over all columns
-  const bool live = o < n_cols * per_col;
-  const size_t col = live ? o / per_col : 0;
-  const unsigned w = (unsigned)(o - col * per_col);
+  const size_t o = wave * G + g;  // output index over all columns, within the [w0, w0 + w_cnt) slice
+  const bool live = o < n_cols * w_cnt;
+  const size_t col = live ? o / w_cnt : 0;
+  const unsigned w = w0 + (unsigned)(o - col * w_cnt);
   const G1X *B = buckets + col * K;
   size_t base, stride;
   unsigned cnt;
@@ -539,19 +540,23 @@ __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ b
     const G1X other = g1x_shfl_xor(v, m);
     g1x_add(v, other);
   }
-  if (live && sub == 0) marg[o] = v;
+  if (live && sub == 0) marg[col * per_col + w] = v;
 }
 
-__global__ void __launch_bounds__(128) k_msm_weighted(const G1X *__restrict__ marg, unsigned K, G1Affine *__restrict__ out) {
-  __shared__ G1X sh[2];
+// one block per MSM: waves 0 .. ceil(A/64)-1 weight the row sums (a * R_a), the last wave the column sums ((b+1) * C_b)
+__global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ marg, unsigned K, G1Affine *__restrict__ out) {
+  __shared__ G1X sh[9];
   const unsigned A = K >> 6;
+  const unsigned row_waves = (A + 63) / 64;
   const size_t col = blockIdx.x;
   const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const G1X *M = marg + col * (A + 64);
-  const G1X P = wv == 0 ? (lane < A ? M[lane] : G1X::identity()) : M[A + lane];
-  const unsigned k = wv == 0 ? lane : lane + 1;  // weights a (rows) and b + 1 (columns)
+  const bool rows = wv < row_waves;
+  const unsigned a = wv * 64 + lane;
+  const G1X P = rows ? (a < A ? M[a] : G1X::identity()) : M[A + lane];
+  const unsigned k = rows ? a : lane + 1;  // weights a (rows) and b + 1 (columns)
   G1X W = G1X::identity();
-  for (int bit = 6; bit >= 0; --bit) {
+  for (int bit = 9; bit >= 0; --bit) {
     W = g1x_dbl(W);
     if ((k >> bit) & 1) g1x_add(W, P);
   }
@@ -562,8 +567,10 @@ __global__ void __launch_bounds__(128) k_msm_weighted(const G1X *__restrict__ ma
   if (lane == 0) sh[wv] = W;
   __syncthreads();
   if (threadIdx.x == 0) {
-    G1X t = g1x_mul_pow2(sh[0], 6);
-    g1x_add(t, sh[1]);
+    G1X t = sh[0];
+    for (unsigned w = 1; w < row_waves; ++w) g1x_add(t, sh[w]);
+    t = g1x_mul_pow2(t, 6);
+    g1x_add(t, sh[row_waves]);
     out[col] = g1x_to_affine(t);
   }
 }
@@ -744,15 +751,23 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   if (gridh > 2048) gridh = 2048;
   k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_posA, bucket_posB, partials, K, TASK_E, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
-  if (K >= 64 && K <= 4096) {
-    const unsigned per_col = (K >> 6) + 64;
+  if (K >= 64 && K <= 32768) {
+    const unsigned A = K >> 6, per_col = A + 64;
     G1X *marg = partials;  // the accumulation partials are dead once the buckets are merged
-    const unsigned L = n_cols <= 16 ? 64 : 8;  // few columns: latency (7 additions deep); many: work (1.4 per bucket)
-    const size_t waves = (n_cols * per_col + 64 / L - 1) / (64 / L);
-    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, L, marg);
+    // row sums (64 buckets each) and column sums (A buckets each).  Few columns: whole-wave butterflies (shortest chain);
+    // many: 8 lanes per sum (1.4 lane-additions per bucket) -- except column sums over more than 64 rows, whose serial
+    // part would be A / 8 additions deep
+    const unsigned Lr = n_cols <= 16 ? 64 : 8;
+    const unsigned Lc = (n_cols <= 16 || A > 64) ? 64 : 8;
+    size_t waves = (n_cols * A + 64 / Lr - 1) / (64 / Lr);
+    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lr, 0, A, marg);
     ZK_LAUNCH_CHECK(ctx);
-    k_msm_weighted<<<(unsigned)n_cols, 128, 0, ctx->stream>>>(marg, K, (G1Affine *)out_dev);
+    waves = (n_cols * 64 + 64 / Lc - 1) / (64 / Lc);
+    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lc, A, 64, marg);
     ZK_LAUNCH_CHECK(ctx);
+    k_msm_weighted<<<(unsigned)n_cols, 64 * ((A + 63) / 64 + 1), 0, ctx->stream>>>(marg, K, (G1Affine *)out_dev);
+    ZK_LAUNCH_CHECK(ctx);
+    (void)per_col;
     return ZKFHE_OK;
   }
   static bool red_attr = false;

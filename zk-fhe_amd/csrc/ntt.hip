@@ -216,7 +216,8 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
       rc = zk_scratch(ctx, 0, n_cols * n * sizeof(Fr), &p);
       if (rc) return rc;
       Fr *tmp = (Fr *)p;
-      ZK_HIP(ctx, hipMemcpyAsync(tmp, data, n_cols * n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+      rc = zk_copy_d2d(ctx, tmp, data, n_cols * n * sizeof(Fr));
+      if (rc) return rc;
       if (log_n == 2) {
         // swap elements 1 and 2 of every column: strided 2D copies
         ZK_HIP(ctx, hipMemcpy2DAsync(data + 1, 4 * sizeof(Fr), tmp + 2, 4 * sizeof(Fr), sizeof(Fr), n_cols, hipMemcpyDeviceToDevice, ctx->stream));
@@ -272,7 +273,8 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   a.out_natural_tiles = 0;
   rc = launch_tile_dyn(ctx, MAX_TILE_LOG, a, 1u << log_tiles, (unsigned)n_cols);
   if (rc) return rc;
-  ZK_HIP(ctx, hipMemcpyAsync(data, p, n_cols * n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  rc = zk_copy_d2d(ctx, data, p, n_cols * n * sizeof(Fr));
+  if (rc) return rc;
   return ZKFHE_OK;
 }
 
@@ -333,13 +335,15 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
   if (log_n > MAX_TILE_LOG) {
     // zkfhe_ntt_batch uses scratch slot 0 itself for long rows: stage the rows in the OUTPUT buffer, transform them
     // there, then combine through slot 2
-    ZK_HIP(ctx, hipMemcpyAsync(out_dev, in_dev, n_cols * ne * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    rc = zk_copy_d2d(ctx, out_dev, in_dev, n_cols * ne * sizeof(Fr));
+    if (rc) return rc;
     rc = zkfhe_ntt_batch(ctx, out_dev, n_cols * E, log_n, 1);
     if (rc) return rc;
     rc = zk_scratch(ctx, 2, n_cols * ne * sizeof(Fr), &p);
     if (rc) return rc;
     Fr *rows2 = (Fr *)p;
-    ZK_HIP(ctx, hipMemcpyAsync(rows2, out_dev, n_cols * ne * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+    rc = zk_copy_d2d(ctx, rows2, out_dev, n_cols * ne * sizeof(Fr));
+    if (rc) return rc;
     rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
     if (rc) return rc;
     Fr *scale2 = (Fr *)p;

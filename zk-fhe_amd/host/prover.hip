@@ -313,7 +313,7 @@ int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr,
   if (!count) return ZKFHE_OK;
   const size_t n = pk->cfg.n();
   const Fr g = mont_u64(COSET_G);
-  ZK_HIP(ctx, hipMemcpyAsync(ws->tmp_c.p, lagr, count * n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  CK(zk_copy_d2d(ctx, ws->tmp_c.p, lagr, count * n * 32));
   CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)ws->tmp_c.p, count, (int)pk->cfg.k, 1));
   return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->tmp_c.p, (zkfhe_fr *)ext, count, (int)pk->cfg.k, 2, (const zkfhe_fr *)&g, 0);
 }
@@ -1122,8 +1122,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(zkfhe_upload(ctx, sc_dev, sc, sizeof(sc)));
     zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
     ZK_LAUNCH_CHECK(ctx);
-    ZK_HIP(ctx, hipMemcpyAsync(H_l, H_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(rand_l, rand_c, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(zk_copy_d2d(ctx, H_l, H_c, n * 32));
+    CK(zk_copy_d2d(ctx, rand_l, rand_c, n * 32));
     CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)H_l, 1, (int)k, 0));
     CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)rand_l, 1, (int)k, 0));
   }
