@@ -99,7 +99,7 @@ def test_ntt_golden(ctx, vec):
         assert orc.mont_to_ints(ctx.ntt(a[None], t["log_n"], False)[0]) == hx(t["out"])
 
 
-@pytest.mark.parametrize("log_n", [14, 16])
+@pytest.mark.parametrize("log_n", [14, 15, 16, 17])
 def test_ntt_large(ctx, log_n):
     rng = np.random.default_rng(log_n)
     a = rand_fr(rng, 2 << log_n).reshape(2, 1 << log_n, 4)

@@ -60,6 +60,47 @@ __global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t
   }
 }
 
+// S consecutive radix-2 DIF stages (halves 2^log_half, 2^(log_half-1), ...) in one pass over memory: a thread holds the
+// 2^S elements base + m * 2^(log_half - S + 1) of one block of 2^(log_half + 1) and runs the S butterfly levels in
+// registers.  Long rows (k = 16 .. 19) used to make one full read+write of every column per stage.
+template <int S>
+__global__ void __launch_bounds__(256) k_dif_fused(Fr *__restrict__ data, size_t n_cols, int log_n, int log_half, const Fr *__restrict__ tw_n) {
+  constexpr int R = 1 << S;
+  const int log_q = log_half - S + 1;            // distance between the elements of a thread
+  const size_t q = (size_t)1 << log_q;
+  const size_t per_col = (size_t)1 << (log_n - S);
+  const size_t total = n_cols * per_col;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = g >> (log_n - S);
+    const size_t i = g & (per_col - 1);
+    const size_t j0 = i & (q - 1);
+    const size_t blk = i >> log_q;
+    Fr *p = data + (c << log_n) + (blk << (log_half + 1)) + j0;
+    Fr x[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = p[(size_t)m << log_q];
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int h = R >> (t + 1);                // partner distance in units of q
+      const int sh = log_n - 1 - (log_half - t); // twiddle exponent shift of this level
+#pragma unroll
+      for (int m = 0; m < R; ++m) {
+        if (m & h) continue;
+        const size_t j = j0 + ((size_t)(m & (h - 1)) << log_q);
+        const Fr a = x[m], b = x[m + h];
+        x[m] = a + b;
+        const Fr d = a - b;
+        const size_t e = j << sh;
+        x[m + h] = e ? d * tw_n[e] : d;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) p[(size_t)m << log_q] = x[m];
+  }
+}
+
 __global__ void __launch_bounds__(256) k_pow_table(Fr base, Fr *__restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr r = Fr::one();
@@ -247,13 +288,18 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   // large: DIF stages down to 2^13 blocks, then tile NTT per block with bit-reversed strided scatter
   const int log_tiles = log_n - MAX_TILE_LOG;
   const Fr *tw = inverse ? dom->inv : dom->fwd;
-  for (int s = log_n - 1; s >= MAX_TILE_LOG; --s) {
-    size_t work = n_cols * (n / 2);
+  for (int s = log_n - 1; s >= MAX_TILE_LOG;) {
+    const int left = s - MAX_TILE_LOG + 1;
+    const int S = left >= 3 ? 3 : left;       // fuse up to three stages per pass over memory
+    size_t work = n_cols * (n >> S);
     unsigned grid = zk_blocks(work, 256);
     unsigned cap = (unsigned)ctx->num_cu * 16;
     if (grid > cap) grid = cap;
-    k_dif_stage<<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+    if (S == 3) k_dif_fused<3><<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+    else if (S == 2) k_dif_fused<2><<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+    else k_dif_stage<<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
     ZK_LAUNCH_CHECK(ctx);
+    s -= S;
   }
   const NttDomain *tdom;
   rc = zk_domain(ctx, MAX_TILE_LOG, &tdom);
