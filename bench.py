@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=12, help="concurrent proofs per GPU (one HIP stream + workspace each)")
+    ap.add_argument("--streams", type=int, default=8, help="concurrent proofs per GPU (one HIP stream + workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -181,6 +181,10 @@ static unsigned task_len(size_t col_entries, unsigned K) {
   // runs equal chains whatever E is, so E only trades the number of partials the merge has to add against the number
   // of tasks available to fill the chip; 16 at k = 13 (40 entries per bucket) measured best end to end.
   const size_t load = col_entries / K;
+  // narrow windows on a long basis (the prover's c = 10 tables for columns of small values): the nominal load says 64,
+  // but those columns fill a few buckets with thousands of entries and leave the rest nearly empty -- 16 keeps the chains
+  // of the full buckets short (measured: 117 proofs/s against 115 at 32 and 114 at 64)
+  if (K <= 1024 && load > 128) return 16;
   unsigned e = 8;
   while (e < (unsigned)TASK_E_MAX && (size_t)e * 3 < load) e <<= 1;
   return e;

@@ -42,6 +42,9 @@ static const uint64_t COSET_G = 7;
 struct zkfhe_srs {
   uint32_t k = 0;
   zkfhe_basis *g = nullptr, *g_lagrange = nullptr;
+  // the same Lagrange points with narrower windows, for columns of small values (advice, permuted lookups): their cost is
+  // the per-bucket work (merge, marginals), not the additions, so 8x fewer buckets beats 30 % more windows
+  zkfhe_basis *g_lagrange_small = nullptr;
 };
 
 struct DevBuf {
@@ -199,6 +202,14 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
     CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, n));
     CK(zkfhe_download(ctx, host.data(), pts.p, n * 64));
     CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), n, 0, which == 0 ? &srs->g : &srs->g_lagrange));
+    if (which == 1) {
+      static int small_c = -1;
+      if (small_c < 0) {
+        const char *e = getenv("ZKFHE_SMALL_C");
+        small_c = e ? atoi(e) : 10;
+      }
+      if (small_c > 0 && k >= 12 && k <= 14) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), n, small_c, &srs->g_lagrange_small));
+    }
   }
   sc.release();
   pts.release();
@@ -211,6 +222,7 @@ int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {
   if (!srs) return ZKFHE_OK;
   zkfhe_basis_destroy(ctx, srs->g);
   zkfhe_basis_destroy(ctx, srs->g_lagrange);
+  zkfhe_basis_destroy(ctx, srs->g_lagrange_small);
   delete srs;
   return ZKFHE_OK;
 }
@@ -796,6 +808,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ~BackendGuard() { poly_mul_backend() = nullptr; }
   } guard(&gpu_mul);
   // ------------------------------------------------------------ phase 0 witness
+  const zkfhe_basis *small_basis = srs->g_lagrange_small ? srs->g_lagrange_small : srs->g_lagrange;
   trace.mark("setup (rng thread, workspace)");
   const CircuitInput in = CircuitInput::parse_json(input_json);
   trace.mark("parse_json");
@@ -827,11 +840,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const bool host_witness = witness_on_host();
   GpuPhase1 g1(ctx, pk, ws);
   if (host_witness) {
-    CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+    CK(commit_cols(ctx, small_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   } else {
     // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
     CK(alloc_witness_buffers(ctx, pk, ws));
-    CK(zkfhe_msm_batch(ctx, srs->g_lagrange, (const zkfhe_fr *)ws->adv_l.fr(), cfg.n_gate0, (zkfhe_g1_affine *)ws->points.p));
+    CK(zkfhe_msm_batch(ctx, small_basis, (const zkfhe_fr *)ws->adv_l.fr(), cfg.n_gate0, (zkfhe_g1_affine *)ws->points.p));
     ZK_HIP(ctx, hipMemcpyAsync(ws->host_pts, ws->points.p, cfg.n_gate0 * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
     CK(g1.launch(st));
@@ -875,7 +888,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
   }
   trace.mark("blind + upload phase 1");
-  CK(commit_cols(ctx, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+  CK(commit_cols(ctx, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   trace.mark("commit phase 1 (GPU)");
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
   tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
@@ -912,7 +925,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       // la_l | ls_l are contiguous: one strided copy covers both
       ZK_HIP(ctx, hipMemcpy2DAsync(ws->la_l.fr() + u, n * 32, ws->wblind.fr(), nbl * 32, nbl * 32, 2 * cfg.n_lookup, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    CK(commit_cols(ctx, srs->g_lagrange, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
+    CK(commit_cols(ctx, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
     if (lookup_err) {
       int e = 0;
       CK(zkfhe_download(ctx, &e, lookup_err, 4));
