@@ -85,6 +85,8 @@ int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
 // stream-ordered device-to-device copy (own kernel for large blocks)
 int zk_copy_d2d(zkfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out);
+// forward coset extension of the first `rows` cosets (ntt.hip)
+int zk_coset_ntt_rows(zkfhe_ctx *ctx, const zk::Fr *in_dev, zk::Fr *out_dev, size_t n_cols, int log_n, int lef, const zk::Fr &g, int rows);
 
 // host-side Fr helpers (same code as the device, compiled for the host)
 zk::Fr zk_fr_from_u64(uint64_t v);

@@ -324,6 +324,44 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   return ZKFHE_OK;
 }
 
+// Forward coset extension of the first `rows` cosets only (rows <= 2^lef; same coset-major layout, the remaining rows of
+// every column are left untouched).  The prover's quotient has degree < 3n, so three of the four cosets determine it.
+extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev, size_t n_cols, int log_n, int lef, const Fr &g, int rows) {
+  const int E = 1 << lef;
+  if (rows >= E || log_n > MAX_TILE_LOG) return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)in_dev, (zkfhe_fr *)out_dev, n_cols, log_n, lef, (const zkfhe_fr *)&g, 0);
+  if (!n_cols) return ZKFHE_OK;
+  const size_t n = (size_t)1 << log_n, ne = n * E;
+  const NttDomain *dom, *edom;
+  int rc = zk_domain(ctx, log_n, &dom);
+  if (rc) return rc;
+  rc = zk_domain(ctx, log_n + lef, &edom);
+  if (rc) return rc;
+  void *p;
+  rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
+  if (rc) return rc;
+  Fr *pre = (Fr *)p;
+  Fr shift = g;
+  for (int k1 = 0; k1 < rows; ++k1) {
+    k_pow_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(shift, pre + (size_t)k1 * n, n);
+    ZK_LAUNCH_CHECK(ctx);
+    shift = shift * edom->omega;
+  }
+  TileArgs a{};
+  a.in = in_dev;
+  a.out = out_dev;
+  a.in_tile_stride = 0;
+  a.col_stride_in = n;
+  a.col_stride_out = ne;
+  a.tw = dom->fwd;
+  a.pre = pre;
+  a.pre_tile_stride = n;
+  a.post = nullptr;
+  a.log_tiles = lef;
+  a.in_len = (int)n;
+  a.out_natural_tiles = 1;
+  return launch_tile_dyn(ctx, log_n, a, (unsigned)rows, (unsigned)n_cols);
+}
+
 int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n,
                           int log_ext_factor, const zkfhe_fr *g_host, int inverse) {
   ZK_ENTER(ctx);

@@ -321,13 +321,13 @@ int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
 }
 
 // coefficient form of `count` Lagrange columns (copy into tmp, iNTT), then coset-extend into ext
-int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext) {
+int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext, int rows = 4) {
   if (!count) return ZKFHE_OK;
   const size_t n = pk->cfg.n();
   const Fr g = mont_u64(COSET_G);
   CK(zk_copy_d2d(ctx, ws->tmp_c.p, lagr, count * n * 32));
   CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)ws->tmp_c.p, count, (int)pk->cfg.k, 1));
-  return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->tmp_c.p, (zkfhe_fr *)ext, count, (int)pk->cfg.k, 2, (const zkfhe_fr *)&g, 0);
+  return zk_coset_ntt_rows(ctx, (const Fr *)ws->tmp_c.p, ext, count, (int)pk->cfg.k, 2, g, rows);
 }
 
 // extended-coset evaluations of the fixed / sigma columns, l_0 / l_last / l_active and X on the coset: derived from the
@@ -1036,7 +1036,12 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const double t_commit = now_ms();
   trace.mark("grand products + commits");
   // ------------------------------------------------------------ quotient
-  CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr()));
+  // The quotient has degree < 3n, so three cosets determine it (one quarter less extension and evaluation work).  The
+  // fourth coset is only needed for the degree check below (a violated gate shows up as a non-zero top quarter):
+  // ZKFHE_CHECK_QUOTIENT=1 turns it back on.  Rows longer than one NTT tile keep the four-coset path.
+  static const bool check_quotient = getenv("ZKFHE_CHECK_QUOTIENT") != nullptr;
+  const int q_rows = (k <= 13 && !check_quotient) ? 3 : 4;
+  CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr(), q_rows));
   {
     // expression groups, in the folding order of oracle/halo2_ref.py expressions_at
     std::vector<zkp::QGroup> groups;
@@ -1101,17 +1106,50 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     qa.n_perm = cfg.n_perm();
     qa.chunk = cfg.chunk();
     qa.n_chunks = cfg.n_chunks();
-    dim3 grid((unsigned)((ne + 255) / 256), (unsigned)G);
+    qa.rows = (unsigned)q_rows;
+    const size_t npts = n * (size_t)q_rows;
+    dim3 grid((unsigned)((npts + 255) / 256), (unsigned)G);
     zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
     ZK_LAUNCH_CHECK(ctx);
-    zkp::k_quotient_combine<<<(unsigned)((ne + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, ws->h_ext.fr());
+    zkp::k_quotient_combine<<<(unsigned)((npts + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, ws->h_ext.fr());
     ZK_LAUNCH_CHECK(ctx);
     const Fr g = mont_u64(COSET_G);
-    CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)ws->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));
+    if (q_rows == 4) {
+      CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)ws->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));
+    } else {
+      // three size-n inverse transforms, then the 3x3 Vandermonde solve per coefficient (prover_kernels.cuh: k_ext3_combine)
+      Fr *rows3 = ws->partials.fr();            // the partials are dead after the combine; 3n values
+      Fr *pw = rows3 + 4 * n;                    // 3n values
+      CK(zk_copy_d2d(ctx, rows3, ws->h_ext.p, 3 * n * 32));
+      CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)rows3, 3, (int)k, 1));
+      Fr gk[3], c[3];
+      gk[0] = g;
+      gk[1] = g * wext;
+      gk[2] = gk[1] * wext;
+      zkp::Mat3 vinv;
+      {
+        for (int t = 0; t < 3; ++t) c[t] = fr_pow(gk[t], n);
+        // inverse of V[k1][m] = c_k1^m by Lagrange basis polynomials: column k1 of V^-1 holds the coefficients of
+        // L_k1(X) = prod_{j != k1} (X - c_j) / (c_k1 - c_j)
+        for (int k1 = 0; k1 < 3; ++k1) {
+          const Fr &a = c[(k1 + 1) % 3], &b = c[(k1 + 2) % 3];
+          const Fr den = fr_inv((c[k1] - a) * (c[k1] - b));
+          vinv.v[0 * 3 + k1] = a * b * den;              // X^0
+          vinv.v[1 * 3 + k1] = (Fr::zero() - (a + b)) * den;  // X^1
+          vinv.v[2 * 3 + k1] = den;                      // X^2
+        }
+      }
+      for (int t = 0; t < 3; ++t) {
+        zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(Fr::one(), fr_inv(gk[t]), pw + (size_t)t * n, n);
+        ZK_LAUNCH_CHECK(ctx);
+      }
+      zkp::k_ext3_combine<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(rows3, pw, vinv, n, ws->h_c.fr());
+      ZK_LAUNCH_CHECK(ctx);
+    }
   }
   std::vector<AffinePoint> h_commit;
   CK(commit_cols(ctx, srs->g, ws->h_c.fr(), 3, (G1Affine *)ws->points.p, h_commit));
-  {
+  if (q_rows == 4) {
     // the quotient must have degree < 3n: a non-zero top quarter means a violated constraint
     std::vector<U256> top(8);
     CK(zkfhe_download(ctx, top.data(), ws->h_c.fr() + 3 * n, 8 * 32));

@@ -145,12 +145,13 @@ struct QArgs {
   Fr *partials;  // [n_groups][4n]
   Fr y, beta, gamma, gamma_rlc;
   unsigned log_n, u, n_gate, n_rlc, adv_rlc0, fix_qrlc0, fix_const, fix_table, adv_lookup0, n_advice, n_perm, chunk, n_chunks;
+  unsigned rows;  // cosets evaluated (3 or 4); the layout always has 4 rows per column
 };
 
 __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
   const size_t n = (size_t)1 << a.log_n, ne = n << 2;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= ne) return;
+  if (p >= n * a.rows) return;
   const QGroup g = a.groups[blockIdx.y];
   const size_t row0 = p & ~(n - 1);           // k1 * n
   const size_t k2 = p & (n - 1);
@@ -221,13 +222,30 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
 
 // h_ext[p] = (sum_g ypow[g] * partials[g][p]) * zinv[k1]
 __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
-                                                          const Fr *__restrict__ zinv, unsigned log_n, Fr *__restrict__ h_ext) {
+                                                          const Fr *__restrict__ zinv, unsigned log_n, unsigned rows, Fr *__restrict__ h_ext) {
   const size_t n = (size_t)1 << log_n, ne = n << 2;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= ne) return;
+  if (p >= n * rows) return;
   Fr acc = Fr::zero();
   for (unsigned g = 0; g < n_groups; ++g) acc = acc + ypow[g] * partials[(size_t)g * ne + p];
   h_ext[p] = acc * zinv[p >> log_n];
+}
+
+// Quotient from three cosets.  rows3[k1][i] = i-th coefficient (already scaled by 1/n) of h restricted to the coset
+// g_k1 <w>, i.e. g_k1^i * sum_m h_m[i] c_k1^m with c_k1 = g_k1^n; pw[k1][i] = g_k1^-i; vinv = inverse of the 3x3
+// Vandermonde matrix (c_k1^m).  h_c[m * n + i] = sum_k1 vinv[m][k1] * rows3[k1][i] * pw[k1][i]; the fourth piece is zero.
+struct Mat3 {
+  Fr v[9];
+};
+__global__ void __launch_bounds__(256) k_ext3_combine(const Fr *__restrict__ rows3, const Fr *__restrict__ pw, Mat3 vinv, size_t n, Fr *__restrict__ h_c) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr t[3];
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) t[k1] = rows3[(size_t)k1 * n + i] * pw[(size_t)k1 * n + i];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) h_c[(size_t)m * n + i] = vinv.v[3 * m] * t[0] + vinv.v[3 * m + 1] * t[1] + vinv.v[3 * m + 2] * t[2];
+  h_c[3 * n + i] = Fr::zero();
 }
 
 // ------------------------------------------------------------------------------------------- evaluations
