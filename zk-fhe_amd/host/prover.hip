@@ -278,7 +278,7 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
   CK(ws->den.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
   CK(ws->small.alloc(ctx, 1 << 20));
   const size_t max_items = (size_t)c.n_advice() + c.n_fixed() + 2 + c.n_perm() + c.n_chunks() + 3 * c.n_lookup;
-  CK(ws->jobs.alloc(ctx, max_items * sizeof(zkp::EvalJob) + max_items * (sizeof(void *) + 32)));
+  CK(ws->jobs.alloc(ctx, max_items * sizeof(zkp::EvalJob) + max_items * (sizeof(void *) + 32) + 256));
   CK(ws->evout.alloc(ctx, max_items * 4 * 32));
   CK(ws->polyio.alloc(ctx, 4 * c.n() * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_adv, (size_t)c.n_advice() * col, hipHostMallocDefault));
@@ -1275,9 +1275,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   {
     size_t max_m = 0;
     for (const auto &s : sets) max_m = std::max(max_m, s.members.size());
-    struct { void *p; } pd, sd;  // pointer and scalar tables live behind the eval-job table
-    pd.p = (char *)ws->jobs.p + items.size() * sizeof(zkp::EvalJob);
-    sd.p = (char *)pd.p + ((max_m * sizeof(void *) + 31) / 32) * 32;
+    // pointer and scalar tables live behind the eval-job table, one slice per set (no host round trip between the sets)
+    (void)max_m;
+    char *const ptab = (char *)ws->jobs.p + items.size() * sizeof(zkp::EvalJob);
+    char *const stab = ptab + ((items.size() * sizeof(void *) + 31) / 32) * 32;
+    size_t tab_off = 0;
     for (size_t j = 0; j < ns; ++j) {
       const auto &mem = sets[j].members;
       std::vector<const Fr *> ptrs(mem.size());
@@ -1291,11 +1293,22 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         for (size_t t = 0; t < np; ++t) comb[t] = comb[t] + cur * mont(items[mem[m]].ev[t]);
         cur = cur * yq;
       }
+      struct { void *p; } pd, sd;
+      pd.p = ptab + tab_off * sizeof(void *);
+      sd.p = stab + tab_off * 32;
+      tab_off += mem.size();
       CK(zkfhe_upload(ctx, pd.p, ptrs.data(), mem.size() * sizeof(void *)));
       CK(zkfhe_upload(ctx, sd.p, pw.data(), mem.size() * 32));
-      zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>((const Fr *const *)pd.p, (const Fr *)sd.p, (unsigned)mem.size(), n, F + j * n);
+      const unsigned per = 48, chunks = (unsigned)((mem.size() + per - 1) / per);
+      if (chunks > 1 && (size_t)chunks * n * 32 <= ws->partials.bytes) {
+        dim3 lg(grid_for(ctx, n), chunks);
+        zkp::k_lincomb_ptrs_chunked<<<lg, 256, 0, ctx->stream>>>((const Fr *const *)pd.p, (const Fr *)sd.p, (unsigned)mem.size(), per, n, ws->partials.fr());
+        ZK_LAUNCH_CHECK(ctx);
+        zkp::k_sum_rows<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ws->partials.fr(), chunks, n, F + j * n);
+      } else {
+        zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>((const Fr *const *)pd.p, (const Fr *)sd.p, (unsigned)mem.size(), n, F + j * n);
+      }
       ZK_LAUNCH_CHECK(ctx);
-      CK(zkfhe_sync(ctx));
       // r_j: interpolation through (pts, comb), ascending coefficients
       zkp::ShSet &S = shsets[j];
       for (int t = 0; t < 4; ++t) S.rc[t] = S.pts[t] = Fr::zero();
