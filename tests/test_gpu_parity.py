@@ -154,7 +154,7 @@ def test_msm_golden(ctx, vec):
         B.destroy()
 
 
-@pytest.mark.parametrize("n,c", [(64, 0), (1000, 0), (1000, 4), (4096, 0), (8192, 0), (8192, 10)])
+@pytest.mark.parametrize("n,c", [(64, 0), (1000, 0), (1000, 4), (1000, 7), (4096, 0), (8192, 0), (8192, 10), (8192, 14), (8192, 16)])
 def test_msm_vs_oracle(ctx, n, c):
     import zk_fhe_amd as zk
     rng = np.random.default_rng(n + c)
@@ -168,6 +168,25 @@ def test_msm_vs_oracle(ctx, n, c):
     sc[3] = [0] * n
     sc[0][:6] = [0, 1, pyref.R - 1, (pyref.R - 1) // 2, (pyref.R + 1) // 2, 2]
     S = np.stack([orc.ints_to_mont(col) for col in sc])
+    B = zk.Basis(ctx, bases, c)
+    got = ctx.msm(B, S)
+    assert np.array_equal(got, orc.msm(S, bases))
+    B.destroy()
+
+
+@pytest.mark.parametrize("c", [10, 13, 16])
+def test_msm_many_columns_all_reduction_paths(ctx, c):
+    """More than 16 columns switches the bucket reduction to 8 lanes per marginal sum (64 lanes for the column sums when
+    K > 4096) and the task list mixes slice lengths across columns: every column against the oracle."""
+    import zk_fhe_amd as zk
+    rng = np.random.default_rng(700 + c)
+    n, n_cols = 2048, 20
+    bases = _bases(n, seed=c)
+    S = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    small = [[int(rng.integers(0, 256)) for _ in range(n)] for _ in range(3)]
+    for i, col in enumerate(small):
+        S[3 * i + 1] = orc.ints_to_mont(col)
+    S[7] = orc.ints_to_mont([5] * n)           # one scalar repeated: a few buckets hold every entry (the heavy merge path)
     B = zk.Basis(ctx, bases, c)
     got = ctx.msm(B, S)
     assert np.array_equal(got, orc.msm(S, bases))
