@@ -2,6 +2,8 @@
 // :63-165 (phase 0 + out-of-circuit precomputation), :171-301 (the phase-1 callback), restated on the
 // host.  The operation order below fixes the cell stream, which the reference's configs/bfv.json pins.
 #pragma once
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <array>
 #include <cctype>
@@ -96,6 +98,15 @@ struct BfvState {
 inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvParams &prm, std::vector<Cell> &make_public) {
   const size_t N = prm.N;
   const uint64_t Q = prm.Q;
+  const bool tr_on = getenv("ZKFHE_TRACE0") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tl = tnow();
+  auto mark = [&](const char *w) {
+    if (!tr_on) return;
+    const double t = tnow();
+    fprintf(stderr, "[phase0] +%.3f ms %s\n", t - tl, w);
+    tl = t;
+  };
   Poly pk0_un = Poly::from_string(input.pk0, Q);
   Poly pk1_un = Poly::from_string(input.pk1, Q);
   Poly m_un = Poly::from_string(input.m, Q);
@@ -105,6 +116,7 @@ inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvPar
   Poly c0_un = Poly::from_string(input.c0, Q);
   Poly c1_un = Poly::from_string(input.c1, Q);
   Poly cyclo_un = Poly::from_string(input.cyclo, Q);
+  mark("from_string x9");
   ZK_ASSERT(pk0_un.deg() == N - 1 && pk1_un.deg() == N - 1 && m_un.deg() == N - 1 && u_un.deg() == N - 1 && e0_un.deg() == N - 1 &&
                 e1_un.deg() == N - 1 && c0_un.deg() == N - 1 && c1_un.deg() == N - 1,
             "input polynomials must have degree N - 1 (examples/bfv.rs:82-89)");
@@ -126,23 +138,30 @@ inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvPar
   st.expected_c0.to_public(make_public);
   st.expected_c1.to_public(make_public);
   st.cyclo.to_public(make_public);
+  mark("from_poly x9 + to_public");
   // PRECOMPUTATION (examples/bfv.rs:124-150)
   Poly pk0_u_un = pk0_un.mul(u_un);
   Poly pk1_u_un = pk1_un.mul(u_un);
+  mark("mul x2 (GPU)");
   st.pk0_u = PolyChip::from_poly(pk0_u_un, ctx);
   st.pk1_u = PolyChip::from_poly(pk1_u_un, ctx);
+  mark("from_poly pk_u x2");
   Poly pk0_u_red = pk0_u_un.reduce_by_modulus(Q);
   Poly pk1_u_red = pk1_u_un.reduce_by_modulus(Q);
+  mark("reduce_by_modulus x2");
   auto qr0 = pk0_u_red.divide_by_cyclo(cyclo_un, Q);
   auto qr1 = pk1_u_red.divide_by_cyclo(cyclo_un, Q);
+  mark("divide_by_cyclo x2");
   Poly q0c = qr0.first.mul(cyclo_un);
   Poly q1c = qr1.first.mul(cyclo_un);
+  mark("mul cyclo x2");
   st.quotient_0 = PolyChip::from_poly(qr0.first, ctx);
   st.quotient_1 = PolyChip::from_poly(qr1.first, ctx);
   st.quotient_0_times_cyclo = PolyChip::from_poly(q0c, ctx);
   st.quotient_1_times_cyclo = PolyChip::from_poly(q1c, ctx);
   st.remainder_0 = PolyChip::from_poly(qr0.second, ctx);
   st.remainder_1 = PolyChip::from_poly(qr1.second, ctx);
+  mark("from_poly x6");
   return st;
 }
 
