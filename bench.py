@@ -66,10 +66,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("ZKFHE_BENCH_BACKEND", "nccl")   # "gloo": control-flow test of the N > 1 path on one GPU
+    n_dev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= max(1, n_dev)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
     import zk_fhe_amd as zk
 
     ctx = zk.Context(local_rank)
@@ -115,7 +122,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     si += args.steps
-    dt = batch.max_over_ranks(dt, device="cuda" if world > 1 else None)
+    dt = batch.max_over_ranks(dt, device="cuda" if (world > 1 and backend == "nccl") else None)
     stage /= max(1, args.steps)
 
     # dominant kernel (k_msm_accumulate) timed live with HIP events on the library's stream, in a separate untimed pass
