@@ -35,6 +35,11 @@ EXPORTS = [
 ]
 
 
+# concurrent proofs run on one HIP stream each; give every stream its own hardware queue (ROCm's default is 4 per process,
+# streams sharing a queue serialise).  Only effective if the HIP runtime has not been initialised yet in this process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
 class ZkfheError(RuntimeError):
     pass
 
@@ -441,6 +446,44 @@ class Srs:
             self.h = None
 
 
+class Instances:
+    """The public inputs of a proof: a read-only sequence of ints over the 32-byte little-endian words the C ABI returns.
+    Decoded on demand -- turning 5121 words into Python ints costs more host time than the C side of a k = 13 proof
+    spends outside the GPU, and holds the GIL while other proving threads wait for it."""
+
+    __slots__ = ("raw", "_ints")
+
+    def __init__(self, raw):
+        self.raw = bytes(raw)
+        self._ints = None
+
+    def _decode(self):
+        if self._ints is None:
+            r = self.raw
+            self._ints = [int.from_bytes(r[i:i + 32], "little") for i in range(0, len(r), 32)]
+        return self._ints
+
+    def __len__(self):
+        return len(self.raw) // 32
+
+    def __iter__(self):
+        return iter(self._decode())
+
+    def __getitem__(self, i):
+        return self._decode()[i]
+
+    def __eq__(self, other):
+        if isinstance(other, Instances):
+            return self.raw == other.raw
+        try:
+            return self._decode() == list(other)
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        return "Instances(%d words)" % len(self)
+
+
 class BfvProvingKey:
     """zkfhe_bfv_keygen: fixed + sigma polynomials, commitments and extended-domain tables resident in HBM."""
 
@@ -529,11 +572,10 @@ class BfvProvingKey:
         ninst = ctypes.c_size_t(5 * int(self.params[0]) + 8)   # 4 polynomials of N coefficients + cyclo (N + 1) are public
         ibuf = ctypes.create_string_buffer(32 * ninst.value)
         tm = (ctypes.c_float * 5)()
-        ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, input_json_text.encode(), seed, buf, cap, ctypes.byref(plen),
+        text = input_json_text if isinstance(input_json_text, bytes) else input_json_text.encode()
+        ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, text, seed, buf, cap, ctypes.byref(plen),
                                            ibuf, ctypes.byref(ninst), tm))
-        raw = ibuf.raw[: 32 * ninst.value]
-        inst = [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(ninst.value)]
-        return buf.raw[: plen.value], inst, list(tm)
+        return buf.raw[: plen.value], Instances(ibuf.raw[: 32 * ninst.value]), list(tm)
 
     def export_vk(self):
         lib = self.ctx.lib
@@ -566,7 +608,7 @@ def bfv_verify(vk_bytes, instances, proof, srs_seed=b"zkfhe-unsafe-srs"):
     lib = load_library()
     lib.zkfhe_bfv_verify.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
                                      ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]
-    inst = b"".join(int(v).to_bytes(32, "little") for v in instances)
+    inst = instances.raw if isinstance(instances, Instances) else b"".join(int(v).to_bytes(32, "little") for v in instances)
     ok = ctypes.c_int(0)
     err = ctypes.create_string_buffer(256)
     rc = lib.zkfhe_bfv_verify(vk_bytes, len(vk_bytes), inst, len(instances), proof, len(proof), bytes(srs_seed), len(srs_seed), ctypes.byref(ok), err, 256)

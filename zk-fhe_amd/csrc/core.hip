@@ -76,6 +76,9 @@ extern "C" {
 const char *zkfhe_version(void) { return "zkfhe-mi355x 0.1 (gfx950)"; }
 
 int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
+  // one hardware queue per concurrent context (ROCm default: 4 per process, streams sharing a queue serialise); a no-op
+  // when the host application already initialised the HIP runtime or set the variable itself
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   if (!out) return zk_fail_msg(nullptr, ZKFHE_EINVAL, "out is NULL");
   *out = nullptr;
   int count = 0;
