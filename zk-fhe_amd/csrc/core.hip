@@ -101,6 +101,7 @@ int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
     if (e != hipSuccess) { delete ctx; return zk_fail(nullptr, ZKFHE_EHIP, "hipStreamCreate", e, __FILE__, __LINE__); }
     ctx->own_stream = true;
   }
+  if (hipHostMalloc(&ctx->bounce, zkfhe_ctx::BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) ctx->bounce = nullptr;
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
   hipEventCreate(&ctx->pe0);
@@ -114,6 +115,7 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
   if (!ctx) return ZKFHE_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->bounce) (void)hipHostFree(ctx->bounce);
   for (auto &kv : ctx->domains) {
     hipFree(kv.second.fwd);
     hipFree(kv.second.inv);
@@ -164,12 +166,27 @@ int zkfhe_dev_free(zkfhe_ctx *ctx, void *dptr) {
 }
 int zkfhe_upload(zkfhe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
   ZK_ENTER(ctx);
-  ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!bytes) return ZKFHE_OK;
+  if (ctx->bounce && bytes <= zkfhe_ctx::BOUNCE_BYTES) {
+    // small transfers (tables of a few KB, dozens per proof) through the context's own pinned buffer: a pageable copy goes
+    // through the runtime's process-wide staging path and serialises the proving threads
+    memcpy(ctx->bounce, src_host, bytes);
+    ZK_HIP(ctx, hipMemcpyAsync(dst_dev, ctx->bounce, bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKFHE_OK;
 }
 int zkfhe_download(zkfhe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
   ZK_ENTER(ctx);
+  if (!bytes) return ZKFHE_OK;
+  if (ctx->bounce && bytes <= zkfhe_ctx::BOUNCE_BYTES) {
+    ZK_HIP(ctx, hipMemcpyAsync(ctx->bounce, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst_host, ctx->bounce, bytes);
+    return ZKFHE_OK;
+  }
   ZK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ZKFHE_OK;

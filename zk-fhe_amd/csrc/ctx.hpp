@@ -31,6 +31,9 @@ struct zkfhe_ctx {
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0}, prof_ops[2] = {0, 0};
   uint64_t prof_launches[2] = {0, 0};
+  // pinned bounce buffer for small host<->device transfers (pageable copies go through the runtime's shared staging path)
+  void *bounce = nullptr;
+  static constexpr size_t BOUNCE_BYTES = (size_t)1 << 20;
   void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[4] = {0, 0, 0, 0};
 };
