@@ -13,12 +13,14 @@
 //   * Scalars are taken out of Montgomery form and folded to sign-magnitude (s > r/2 -> r - s with the
 //     point negated), so the "negative small" witness values (r - x) cost as little as small ones,
 //     and zero digits are skipped.
-//   * entries (bucket, table index, sign) are counting-sorted per MSM (global-atomic histogram,
-//     exclusive scan, scatter).  Every bucket is cut into tasks of <= 32 entries; one thread sums one task
-//     with XYZZ mixed additions, so the dependent chain is bounded however skewed a column is (witness
-//     columns hold thousands of 0/1 cells); a bucket's partials are merged by a thread (<= 8) or a wave.
-//   * bucket reduction sum_b b*B_b: 256 threads per MSM, running sums over groups of buckets, then a
-//     weighted tree in LDS; the result is normalised to affine in the same kernel.
+//   * entries (bucket, table index, sign) are counting-sorted per MSM (LDS-privatised histogram per 2048-scalar chunk,
+//     exclusive scan, scatter).  Every bucket is cut into equal slices of <= E entries (E ~ bucket load / 3); the task
+//     list is counting-sorted by slice length, so the 64 lanes of a wave sum slices of the same length with XYZZ mixed
+//     additions and the dependent chain is bounded however skewed a column is (witness columns hold thousands of 0/1
+//     cells).  A bucket's partials are merged by a thread (<= 8), by eight lanes (<= 128) or by a wave.
+//   * bucket reduction sum_b b*B_b for K <= 32768 buckets: idx = 64 a + b; row and column marginal sums, then per MSM a
+//     lane-parallel double-and-add over the marginals and a shuffle tree; the result is normalised to affine in the
+//     same kernel (k_msm_marginals, k_msm_weighted; k_msm_reduce is the generic fallback for larger K).
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
 #include <vector>
 #include <cstring>
