@@ -296,17 +296,19 @@ __global__ void __launch_bounds__(256) k_scatter(Fr *__restrict__ dst, const uns
 
 // halo2 permute_expression_pair for an 8-bit table, one workgroup per lookup column.
 // in: Lagrange column (Montgomery), rows < u are the inputs.  out_a / out_s rows < u (Montgomery); err set if a value > 255.
-__global__ void __launch_bounds__(256) k_lookup_permute(const Fr *__restrict__ in, size_t n, unsigned u, Fr *__restrict__ out_a, Fr *__restrict__ out_s,
+__global__ void __launch_bounds__(1024) k_lookup_permute(const Fr *__restrict__ in, size_t n, unsigned u, Fr *__restrict__ out_a, Fr *__restrict__ out_s,
                                                         int *__restrict__ err) {
   __shared__ unsigned cnt[256], start[257], hole0[257], left0[257];
   __shared__ Fr mont[256];
   const Fr *col = in + (size_t)blockIdx.x * n;
   Fr *oa = out_a + (size_t)blockIdx.x * n, *os = out_s + (size_t)blockIdx.x * n;
-  const unsigned t = threadIdx.x;
-  cnt[t] = 0;
-  mont[t] = zk::fp_to_mont<FrP>(c_u64(t));
+  const unsigned t = threadIdx.x, T = blockDim.x;  // T >= 256: the first 256 threads own the table values
+  if (t < 256) {
+    cnt[t] = 0;
+    mont[t] = zk::fp_to_mont<FrP>(c_u64(t));
+  }
   __syncthreads();
-  for (unsigned i = t; i < u; i += 256) {
+  for (unsigned i = t; i < u; i += T) {
     const Fr v = zk::fp_from_mont<FrP>(col[i]);
     if (v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7] || v.l[0] > 255u) {
       atomicExch(err, 1);
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(256) k_lookup_permute(const Fr *__restrict__ i
   __syncthreads();
   // row i of the sorted column: value v = the run containing i; first row of a run keeps v in S', the others are holes
   // that take the leftover table values in ascending order
-  for (unsigned i = t; i < u; i += 256) {
+  for (unsigned i = t; i < u; i += T) {
     if (i >= start[256]) {  // only when an out-of-table value was skipped: leave the row, err is set
       continue;
     }

@@ -913,7 +913,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       // the commit_cols above synchronised the stream, so the staging block is free again
       lookup_err = (int *)(ws->wblind.fr() + 2 * (size_t)cfg.n_lookup * nbl);
       ZK_HIP(ctx, hipMemsetAsync(lookup_err, 0, 4, ctx->stream));
-      zkw::k_lookup_permute<<<cfg.n_lookup, 256, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
+      zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
       ZK_LAUNCH_CHECK(ctx);
       // blinding rows: la_i then ls_i, lookup by lookup; staged as [la columns | ls columns]
       for (unsigned i = 0; i < cfg.n_lookup; ++i) {
@@ -1237,7 +1237,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     }
     DevBuf &jd = ws->jobs, &od = ws->evout;
     CK(zkfhe_upload(ctx, jd.p, jobs.data(), jobs.size() * sizeof(zkp::EvalJob)));
-    zkp::k_eval_jobs<<<(unsigned)jobs.size(), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, od.fr());
+    // long columns: 16 row slices per job (partial sums in the dead quotient buffer), then one small reduction
+    const unsigned slices = (n > 32768 && (size_t)16 * jobs.size() * 4 * 32 <= ws->partials.bytes) ? 16u : 1u;
+    if (slices == 1) {
+      zkp::k_eval_jobs<<<(unsigned)jobs.size(), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, od.fr());
+    } else {
+      zkp::k_eval_jobs<<<dim3((unsigned)jobs.size(), slices), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, ws->partials.fr());
+      ZK_LAUNCH_CHECK(ctx);
+      zkp::k_sum_rows<<<grid_for(ctx, jobs.size() * 4), 256, 0, ctx->stream>>>(ws->partials.fr(), slices, jobs.size() * 4, od.fr());
+    }
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)od.p, (zkfhe_fr *)od.p, jobs.size() * 4));
     std::vector<U256> ev(jobs.size() * 4);

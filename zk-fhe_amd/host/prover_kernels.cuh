@@ -266,13 +266,15 @@ struct EvalJob {
   int n_rot;
   int rot[4];  // indices into the weight table
 };
+// gridDim.y row slices (long columns): slice y sums rows [y n / Y, (y + 1) n / Y) into out[(y * jobs + job) * 4 + r]
 __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ jobs, const Fr *__restrict__ bw, size_t n, Fr *__restrict__ out) {
   __shared__ Fr sh[256];
   const EvalJob job = jobs[blockIdx.x];
   Fr acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = Fr::zero();
-  for (size_t i = threadIdx.x; i < n; i += 256) {
+  const size_t lo = (n / gridDim.y) * blockIdx.y, hi = blockIdx.y + 1 == gridDim.y ? n : lo + n / gridDim.y;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
     const Fr v = job.col[i];
     for (int r = 0; r < job.n_rot; ++r) acc[r] = acc[r] + v * bw[(size_t)job.rot[r] * n + i];
   }
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ j
       if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)blockIdx.x * 4 + r] = sh[0];
+    if (threadIdx.x == 0) out[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + r] = sh[0];
     __syncthreads();
   }
 }
