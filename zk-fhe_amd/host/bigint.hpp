@@ -136,10 +136,16 @@ class BigInt {
     bool ng = false;
     if (i < s.size() && (s[i] == '-' || s[i] == '+')) ng = s[i++] == '-';
     if (i >= s.size()) throw std::invalid_argument("empty integer literal");
-    for (; i < s.size(); ++i) {
-      if (s[i] < '0' || s[i] > '9') throw std::invalid_argument("bad decimal digit in '" + s + "'");
-      r.mul_small(10);
-      r.add_small((uint32_t)(s[i] - '0'));
+    // digits are consumed nine at a time (10^9 < 2^32): one multiply-add of the limb vector per group
+    while (i < s.size()) {
+      uint32_t group = 0, scale = 1;
+      for (int k = 0; k < 9 && i < s.size(); ++k, ++i) {
+        if (s[i] < '0' || s[i] > '9') throw std::invalid_argument("bad decimal digit in '" + s + "'");
+        group = group * 10 + (uint32_t)(s[i] - '0');
+        scale *= 10;
+      }
+      r.mul_small(scale);
+      r.add_small(group);
     }
     r.neg = ng && !r.is_zero();
     return r;
