@@ -227,6 +227,36 @@ def test_concurrent_proofs_on_two_streams(ctx):
     ctx2.close()
 
 
+def test_twelve_concurrent_k13_proofs_match_sequential(ctx):
+    """The bench configuration: 12 contexts prove different k = 13 inputs against one key at the same time (zk_fhe_amd.batch
+    .run_concurrent); every proof must equal the one the same input and seed give alone, and the C++ verifier accepts a sample."""
+    import zk_fhe_amd as zk
+    import zk_fhe_amd.batch as batch
+    from zk_fhe_amd import inputs as gen
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    prm = C.BfvParams()
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, json.dumps(gen.empty(1024)), (1024, prm.Q, prm.T, prm.B), zk.BfvConfig.from_pinning(cfgj), replay=True)
+    texts = [json.dumps(gen.generate(1024, prm.Q, prm.T, prm.B, seed=100 + i)) for i in range(6)]
+    jobs = list(range(36))
+    alone = {j: pk.prove(texts[j % 6], b"c%d" % j)[0] for j in jobs[:12]}
+    ctxs = [ctx] + [zk.Context(0) for _ in range(11)]
+    got = batch.run_concurrent(jobs, ctxs, lambda c, j: pk.prove(texts[j % 6], b"c%d" % j, ctx=c))
+    for j in jobs[:12]:
+        assert got[j][0] == alone[j], "proof %d differs when proved concurrently" % j
+    # jobs 12.. repeat the inputs with other seeds: different bytes, same instances, all valid
+    vk = pk.export_vk()
+    for j in (12, 23, 35):
+        assert got[j][1] == got[j % 6][1]
+        assert got[j][0] != got[j % 6][0]
+        ok, why = zk.bfv_verify(vk, got[j][1], got[j][0])
+        assert ok, why
+    for c in ctxs[1:]:
+        c.close()
+    pk.destroy()
+    srs.destroy()
+
+
 def test_k14_proof_bytes_match_oracle(ctx):
     """A circuit with more rows than one NTT tile (k = 14 > 13): exercises the long-row NTT / coset paths in the prover."""
     import zk_fhe_amd as zk

@@ -48,16 +48,19 @@ struct zkfhe_srs {
 };
 
 struct DevBuf {
-  zkfhe_ctx *ctx = nullptr;
+  int device = 0;  // not the context: a workspace outlives the zkfhe_ctx it was made for if the caller destroys that first
   void *p = nullptr;
   size_t bytes = 0;
   int alloc(zkfhe_ctx *c, size_t b) {
-    ctx = c;
+    device = c->device;
     bytes = b;
     return zkfhe_dev_alloc(c, b, &p);
   }
   void release() {
-    if (p) zkfhe_dev_free(ctx, p);
+    if (p) {
+      (void)hipSetDevice(device);
+      (void)hipFree(p);
+    }
     p = nullptr;
   }
   Fr *fr() const { return (Fr *)p; }
