@@ -160,6 +160,11 @@ int zkfhe_dev_alloc(zkfhe_ctx *ctx, size_t bytes, void **dptr) {
 }
 int zkfhe_dev_free(zkfhe_ctx *ctx, void *dptr) {
   ZK_ENTER(ctx);
+  if (!dptr) return ZKFHE_OK;
+  if (!ctx) {  // the owning context is gone already (hipFree synchronises on its own)
+    (void)hipFree(dptr);
+    return ZKFHE_OK;
+  }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ZK_HIP(ctx, hipFree(dptr));
   return ZKFHE_OK;

@@ -812,6 +812,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   } guard(&gpu_mul);
   // ------------------------------------------------------------ phase 0 witness
   const zkfhe_basis *small_basis = srs->g_lagrange_small ? srs->g_lagrange_small : srs->g_lagrange;
+  // a previous proof on this context may have been abandoned on an error with copies from the pinned staging buffers still
+  // queued: drain the stream before the buffers are rewritten (free when the stream is idle)
+  CK(zkfhe_sync(ctx));
   trace.mark("setup (rng thread, workspace)");
   const CircuitInput in = CircuitInput::parse_json(input_json);
   trace.mark("parse_json");
