@@ -174,6 +174,10 @@ int zkfhe_bfv_tables_copy_break_points(const zkfhe_bfv_tables *t, int which, uin
  * from the seed, g[i] = s^i G, g_lagrange[i] = L_i(s) G, both computed on the GPU and kept as MSM bases. */
 typedef struct zkfhe_srs zkfhe_srs;
 int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out);
+/* An SRS from outside (a ceremony file such as the reference's params/kzg_bn254_<k>.srs, README.md:34-38, read by the
+ * caller): 2^k points g[i] = s^i G and g_lagrange[i] = L_i(s) G, host memory, affine, Montgomery limbs (halo2curves'
+ * in-memory G1Affine).  The library only builds its MSM tables from them; nothing is checked about the ceremony. */
+int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_host, const zkfhe_g1_affine *g_lagrange_host, zkfhe_srs **out);
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs);
 
 /* keygen (README.md:28-38): circuit structure from the (empty) input, fixed + sigma polynomials, their
@@ -202,6 +206,10 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
  * malformed proof is reported as accepted = 0 with the reason in err. */
 int zkfhe_bfv_verify(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof,
                      size_t proof_len, const uint8_t *srs_seed, size_t seed_len, int *accepted, char *err, size_t err_len);
+/* The same check against the verifier's half of an external SRS: G2 and s*G2 as four 32-byte little-endian canonical Fq values
+ * each (x.c0, x.c1, y.c0, y.c1), the layout of halo2curves' G2Affine coordinates. */
+int zkfhe_bfv_verify_g2(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof, size_t proof_len,
+                        const uint8_t g2[128], const uint8_t s_g2[128], int *accepted, char *err, size_t err_len);
 
 /* prove (README.md:42-44): witness generation + create_proof.  seed: 32 bytes for the blinding stream.
  * proof_out must hold proof_cap bytes; *proof_len receives the length.  instances_out (may be NULL): canonical

@@ -199,6 +199,25 @@ def test_proving_key_save_and_load(ctx, tmp_path):
     srs.destroy()
 
 
+def test_external_srs_points(ctx):
+    """zkfhe_srs_from_points: an SRS computed elsewhere (here: by the oracle, same secret as the seeded setup) gives the same
+    key and the same proof bytes as zkfhe_srs_create."""
+    import zk_fhe_amd as zk
+    prm = C.BfvParams(N=8)
+    inp = synth_input(8, prm.Q, prm.T, prm.B, 1)
+    circ = H.BfvCircuit(inp, prm)
+    hcfg = H.auto_config(9, 9, circ)
+    srs_o = H.make_srs(9)
+    zcfg = zk.BfvConfig(9, hcfg.n_gate0, hcfg.n_gate1, hcfg.n_lookup, hcfg.n_rlc, 9)
+    out = []
+    for srs in (zk.Srs(ctx, 9), zk.Srs.from_points(ctx, 9, srs_o["g"], srs_o["g_lagrange"])):
+        pk = zk.BfvProvingKey(ctx, srs, json.dumps(inp), (8, prm.Q, prm.T, prm.B), zcfg)
+        out.append((pk.info(), pk.prove(json.dumps(inp), b"ext")[0]))
+        pk.destroy()
+        srs.destroy()
+    assert out[0] == out[1]
+
+
 def test_concurrent_proofs_on_two_streams(ctx):
     """Two contexts (streams + workspaces) of the same GPU prove against one key at the same time: same bytes as alone."""
     import threading

@@ -43,3 +43,19 @@ def test_rejects_tampering(toy):
     vk2 = bytearray(vkb)
     vk2[100] ^= 1
     assert not zk.bfv_verify(bytes(vk2), inst, proof)[0]
+
+
+def test_external_srs_verifier_half(toy):
+    """zkfhe_bfv_verify_g2: the same check with G2 and s*G2 passed in (an external ceremony) instead of derived from a seed."""
+    from oracle import pairing_ref as PR
+    vkb, inst, proof = toy
+    srs = H.srs_verifier_half(9)
+    pt = lambda P: ((P[0].c[0], P[0].c[1]), (P[1].c[0], P[1].c[1]))  # noqa: E731
+    g2, s_g2 = pt(PR.G2_GEN), pt(srs["s_g2"])
+    ok, why = zk.bfv_verify(vkb, inst, proof, g2=g2, s_g2=s_g2)
+    assert ok, why
+    other = pt(PR.ec_mul(PR.G2_GEN, srs["s"] + 1))
+    assert not zk.bfv_verify(vkb, inst, proof, g2=g2, s_g2=other)[0]
+    off_curve = ((s_g2[0][0] + 1, s_g2[0][1]), s_g2[1])
+    ok, why = zk.bfv_verify(vkb, inst, proof, g2=g2, s_g2=off_curve)
+    assert not ok and "curve" in why

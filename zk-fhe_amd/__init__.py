@@ -29,8 +29,8 @@ EXPORTS = [
     "zkfhe_bfv_build_tables", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points",
-    "zkfhe_srs_create", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
-    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_verify",
+    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_version",
 ]
 
@@ -440,6 +440,23 @@ class Srs:
         ctx._check(lib.zkfhe_srs_create(ctx.h, k, bytes(seed), len(seed), ctypes.byref(h)))
         self.h = h
 
+    @classmethod
+    def from_points(cls, ctx, k, g, g_lagrange):
+        """zkfhe_srs_from_points: an SRS computed elsewhere.  g, g_lagrange: (2^k, 8) uint64 arrays, affine Montgomery limbs."""
+        lib = ctx.lib
+        lib.zkfhe_srs_from_points.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.zkfhe_srs_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        a = np.ascontiguousarray(g, dtype=np.uint64).reshape(-1, 8)
+        b = np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(-1, 8)
+        if a.shape[0] != 1 << k or b.shape[0] != 1 << k:
+            raise ValueError("an SRS for k = %d needs 2^k points in both bases" % k)
+        self = cls.__new__(cls)
+        self.ctx, self.k = ctx, k
+        h = ctypes.c_void_p()
+        ctx._check(lib.zkfhe_srs_from_points(ctx.h, k, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+        self.h = h
+        return self
+
     def destroy(self):
         if self.h:
             self.ctx.lib.zkfhe_srs_destroy(self.ctx.h, self.h)
@@ -603,9 +620,24 @@ def make_vk_bytes(k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bi
     return out
 
 
-def bfv_verify(vk_bytes, instances, proof, srs_seed=b"zkfhe-unsafe-srs"):
-    """Host-only verifier (C++: transcript replay, quotient identity, one pairing-product check). Returns (accepted, reason)."""
+def bfv_verify(vk_bytes, instances, proof, srs_seed=b"zkfhe-unsafe-srs", g2=None, s_g2=None):
+    """Host-only verifier (C++: transcript replay, quotient identity, one pairing-product check). Returns (accepted, reason).
+    g2 / s_g2: the verifier's half of an external SRS, each ((x.c0, x.c1), (y.c0, y.c1)) as ints; default: the seeded setup."""
     lib = load_library()
+    if g2 is not None or s_g2 is not None:
+        lib.zkfhe_bfv_verify_g2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                            ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]
+
+        def enc(p):
+            (x0, x1), (y0, y1) = p
+            return b"".join(int(v).to_bytes(32, "little") for v in (x0, x1, y0, y1))
+        inst = instances.raw if isinstance(instances, Instances) else b"".join(int(v).to_bytes(32, "little") for v in instances)
+        ok = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(256)
+        rc = lib.zkfhe_bfv_verify_g2(vk_bytes, len(vk_bytes), inst, len(instances), proof, len(proof), enc(g2), enc(s_g2), ctypes.byref(ok), err, 256)
+        if rc != 0:
+            raise ZkfheError("zkfhe_bfv_verify_g2: bad arguments (%d)" % rc)
+        return bool(ok.value), err.value.decode()
     lib.zkfhe_bfv_verify.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
                                      ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]
     inst = instances.raw if isinstance(instances, Instances) else b"".join(int(v).to_bytes(32, "little") for v in instances)

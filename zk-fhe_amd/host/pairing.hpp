@@ -231,6 +231,16 @@ inline Pt<Fq2> g2_generator() {
   return g;
 }
 
+// y^2 = x^3 + 3/(9+i) (the sextic twist)
+inline bool g2_on_curve(const Pt<Fq2> &p) {
+  if (p.inf) return false;
+  Fq2 nine_i, three = Fq2::zero();
+  nine_i.c = {fq_from_u64(9), fq_from_u64(1)};
+  three.c[0] = fq_from_u64(3);
+  const Fq2 b2 = three * inv(nine_i);
+  return p.y * p.y == p.x * p.x * p.x + b2;
+}
+
 inline Fq12 w_pow(int e) {
   Fq12 w = Fq12::zero();
   w.c[e] = Fq::one();

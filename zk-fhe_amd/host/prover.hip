@@ -220,6 +220,23 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
   return ZKFHE_OK;
 }
 
+int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_host, const zkfhe_g1_affine *g_lagrange_host, zkfhe_srs **out) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, out != nullptr && g_host != nullptr && g_lagrange_host != nullptr && k >= 3 && k <= 20);
+  const size_t n = (size_t)1 << k;
+  zkfhe_srs *srs = new zkfhe_srs();
+  srs->k = k;
+  int rc = zkfhe_basis_create(ctx, g_host, n, 0, &srs->g);
+  if (!rc) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 0, &srs->g_lagrange);
+  if (!rc && k >= 12 && k <= 14) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
+  if (rc) {
+    zkfhe_srs_destroy(ctx, srs);
+    return rc;
+  }
+  *out = srs;
+  return ZKFHE_OK;
+}
+
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {
   ZK_ENTER(ctx);
   if (!srs) return ZKFHE_OK;

@@ -185,7 +185,23 @@ struct Item {  // one opened polynomial
   std::vector<Fr> evals;
 };
 
-bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *proof, size_t proof_len, const uint8_t *srs_seed, size_t seed_len) {
+// the verifier's half of an SRS: G2 and s*G2 (the library's own setups derive s from a seed; an external ceremony supplies them)
+struct SrsG2 {
+  pairing::Pt<pairing::Fq2> g2, sg2;
+};
+SrsG2 srs_g2_from_seed(const uint8_t *srs_seed, size_t seed_len) {
+  Blake2b hs(64, "zkfhe-srs");
+  hs.update(srs_seed, seed_len);
+  uint8_t d[64];
+  hs.digest(d);
+  const U256 s = from_bytes_wide(d);
+  SrsG2 r;
+  r.g2 = pairing::g2_generator();
+  r.sg2 = pairing::ec_mul(r.g2, s);
+  return r;
+}
+
+bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *proof, size_t proof_len, const SrsG2 &srs) {
   const CircuitConfig &cfg = vk.cfg;
   const size_t n = cfg.n(), u = cfg.u();
   const Fr w = zk_fr_root_of_unity((int)cfg.k);
@@ -415,13 +431,7 @@ bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *pro
   scal.push_back(uu);
   const AffinePoint F = msm_host(scal, pts);
   // e(F + u W', G2) = e(W', s G2)
-  Blake2b hs(64, "zkfhe-srs");
-  hs.update(srs_seed, seed_len);
-  uint8_t d[64];
-  hs.digest(d);
-  const U256 s = from_bytes_wide(d);
-  const pairing::Pt<pairing::Fq2> g2 = pairing::g2_generator();
-  const pairing::Pt<pairing::Fq2> sg2 = pairing::ec_mul(g2, s);
+  const pairing::Pt<pairing::Fq2> &g2 = srs.g2, &sg2 = srs.sg2;
   pairing::G1 Fp{F.x, F.y}, nW;
   nW.x = w_commit.x;
   nW.y = w_commit.is_identity() ? fe::zero() : [&] {
@@ -447,11 +457,45 @@ int zkfhe_bfv_verify(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *inst
     if (n_instances) memcpy(inst.data(), instances, n_instances * 32);
     for (const auto &v : inst)
       if (!(v < fe::MOD)) throw std::runtime_error("instance not reduced");
-    *accepted = verify_impl(vk, inst, proof, proof_len, srs_seed, seed_len) ? 1 : 0;
+    *accepted = verify_impl(vk, inst, proof, proof_len, srs_g2_from_seed(srs_seed, seed_len)) ? 1 : 0;
     return ZKFHE_OK;
   } catch (const std::exception &e) {
     if (err && err_len) snprintf(err, err_len, "%s", e.what());
     return ZKFHE_OK;  // a malformed proof is a rejected proof, not an API error
+  }
+}
+
+int zkfhe_bfv_verify_g2(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof, size_t proof_len,
+                        const uint8_t g2[128], const uint8_t s_g2[128], int *accepted, char *err, size_t err_len) {
+  if (!vk_bytes || !proof || !accepted || !g2 || !s_g2 || (!instances && n_instances)) return ZKFHE_EINVAL;
+  *accepted = 0;
+  try {
+    const Vk vk = parse_vk(vk_bytes, vk_len);
+    std::vector<U256> inst(n_instances);
+    if (n_instances) memcpy(inst.data(), instances, n_instances * 32);
+    for (const auto &v : inst)
+      if (!(v < fe::MOD)) throw std::runtime_error("instance not reduced");
+    auto load = [](const uint8_t *b) {
+      static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+      U256 c[4];
+      memcpy(c, b, 128);
+      for (const auto &x : c)
+        if (!(x < QMOD)) throw std::runtime_error("G2 coordinate not reduced");
+      pairing::Pt<pairing::Fq2> p;
+      p.x.c = {pairing::fq_from_canon(c[0]), pairing::fq_from_canon(c[1])};
+      p.y.c = {pairing::fq_from_canon(c[2]), pairing::fq_from_canon(c[3])};
+      // on the twist y^2 = x^3 + 3/(9+i)?  (subgroup membership is the caller's responsibility, as in halo2's ParamsKZG::read)
+      if (!pairing::g2_on_curve(p)) throw std::runtime_error("G2 point not on the curve");
+      return p;
+    };
+    SrsG2 srs;
+    srs.g2 = load(g2);
+    srs.sg2 = load(s_g2);
+    *accepted = verify_impl(vk, inst, proof, proof_len, srs) ? 1 : 0;
+    return ZKFHE_OK;
+  } catch (const std::exception &e) {
+    if (err && err_len) snprintf(err, err_len, "%s", e.what());
+    return ZKFHE_OK;
   }
 }
 
