@@ -194,6 +194,11 @@ int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, 
 /* Serialised verifying key: magic "ZKFHEVK1", 7 x u32 configuration, u32 n_fixed, u32 n_sigma, 32-byte vk digest, then
  * the fixed and sigma commitments as canonical affine x||y (64 B each).  What `keygen` writes to data/<name>.vk. */
 int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, size_t *len);
+/* Parity hook for the GPU witness generator: the phase-1 gate-context cell stream of examples/bfv.rs:171-301 (1 231 992 cells at
+ * the reference's parameters) as produced on the device, canonical 32-byte little-endian values, for a caller-chosen challenge
+ * gamma.  cells_out == NULL only returns the cell count. */
+int zkfhe_bfv_witness_stream(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, const char *input_json, const uint8_t gamma_le[32], uint8_t *cells_out,
+                             size_t cap_cells, size_t *n_cells);
 /* Proving key on disk (the reference's keygen writes data/<name>.pk, README.md:38): configuration, break points, commitments
  * and the fixed / permutation columns; the extended-domain tables are rebuilt on load.  A key is bound to the SRS it was
  * generated with. */

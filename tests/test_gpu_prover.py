@@ -96,6 +96,63 @@ def test_bfv_in_k13_proof_bytes_match_oracle(ctx):
     srs.destroy()
 
 
+def test_gpu_gate_stream_matches_oracle_cell_for_cell(ctx):
+    """SURVEY.md 8a rows A8-A14 directly: the 1 231 992 phase-1 gate cells the GPU gadget kernels emit for the reference's
+    data/bfv/bfv.in equal the oracle's restatement of src/poly_chip.rs + halo2-base (oracle/circuit_ref.py), for a fixed gamma."""
+    import numpy as np
+    import zk_fhe_amd as zk
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    prm = C.BfvParams()
+    inp = C.load_input(os.path.join(G, "bfv.in"))
+    gamma = 0x1F3A5C7E9B2D4F60123456789ABCDEF0FEDCBA9876543210
+    _, _, st = C.bfv_phase0(inp, prm)
+    ctx_gate, _ = C.bfv_phase1(st, prm, gamma)
+    want = ctx_gate.advice
+    assert len(want) == 1231992
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, open(os.path.join(G, "bfv_empty.in")).read(), (1024, prm.Q, prm.T, prm.B), zk.BfvConfig.from_pinning(cfgj))
+    got = pk.witness_stream(open(os.path.join(G, "bfv.in")).read(), gamma)
+    assert got.shape == (len(want), 4)
+    mask = (1 << 64) - 1
+    ref = np.array([[(v >> (64 * j)) & mask for j in range(4)] for v in want], dtype=np.uint64)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, "first differing cell: %d" % bad[0]
+    pk.destroy()
+    srs.destroy()
+
+
+def test_gpu_gate_stream_60bit_modulus(ctx):
+    """Same cell-for-cell check with a 60-bit Q (BASELINE config 4 shape at N = 256): div_mod on 130-bit values, 17-limb range
+    checks -- the widths the k = 13 parameters never reach."""
+    import numpy as np
+    import zk_fhe_amd as zk
+    from zk_fhe_amd import inputs as gen
+    N, Q, T, B, k = 256, (1 << 60) - 93, 7, 19, 12
+    inp = gen.generate(N, Q, T, B, seed=9)
+    text = json.dumps(inp)
+    prm = C.BfvParams(N=N, Q=Q, T=T, B=B)
+    gamma = 0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF
+    _, _, st = C.bfv_phase0(inp, prm)
+    ctx_gate, _ = C.bfv_phase1(st, prm, gamma)
+    want = ctx_gate.advice
+    probe = zk.bfv_build_tables(text, (N, Q, T, B), zk.BfvConfig(k, 8, 400, 120, 16, 109), 1, keygen_mode=False)
+    n0, n1, nr = (len(probe["break_points"][w]) + 1 for w in ("gate0", "gate1", "rlc"))
+    nl = -(-probe["lookups"] // ((1 << k) - 109))
+    srs = zk.Srs(ctx, k)
+    pk = zk.BfvProvingKey(ctx, srs, text, (N, Q, T, B), zk.BfvConfig(k, n0, n1, nl, nr, 109))
+    got = pk.witness_stream(text, gamma)
+    mask = (1 << 64) - 1
+    ref = np.array([[(v >> (64 * j)) & mask for j in range(4)] for v in want], dtype=np.uint64)
+    assert got.shape == ref.shape
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, "first differing cell: %d" % bad[0]
+    proof, inst, _ = pk.prove(text, b"q60")
+    ok, why = zk.bfv_verify(pk.export_vk(), inst, proof)
+    assert ok, why
+    pk.destroy()
+    srs.destroy()
+
+
 def test_device_and_host_witness_generators_agree(ctx):
     """The phase-1 gate stream is generated on the GPU by default; ZKFHE_WITNESS=host keeps the host generator.  Same
     seed -> identical bytes, on the reference's input and on a second random one."""

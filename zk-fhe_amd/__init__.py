@@ -30,7 +30,7 @@ EXPORTS = [
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points",
     "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
-    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_version",
 ]
 
@@ -593,6 +593,20 @@ class BfvProvingKey:
         ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, text, seed, buf, cap, ctypes.byref(plen),
                                            ibuf, ctypes.byref(ninst), tm))
         return buf.raw[: plen.value], Instances(ibuf.raw[: 32 * ninst.value]), list(tm)
+
+    def witness_stream(self, input_json_text, gamma):
+        """zkfhe_bfv_witness_stream: the phase-1 gate-context cells as the GPU generates them, as an (n_cells, 4) uint64 array
+        of canonical values (little-endian limbs)."""
+        lib = self.ctx.lib
+        vp = ctypes.c_void_p
+        lib.zkfhe_bfv_witness_stream.argtypes = [vp, vp, ctypes.c_char_p, ctypes.c_char_p, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        text = input_json_text if isinstance(input_json_text, bytes) else input_json_text.encode()
+        g = int(gamma).to_bytes(32, "little")
+        n = ctypes.c_size_t()
+        self.ctx._check(lib.zkfhe_bfv_witness_stream(self.ctx.h, self.h, text, g, None, 0, ctypes.byref(n)))
+        out = np.empty((n.value, 4), dtype=np.uint64)
+        self.ctx._check(lib.zkfhe_bfv_witness_stream(self.ctx.h, self.h, text, g, out.ctypes.data_as(vp), n.value, ctypes.byref(n)))
+        return out
 
     def export_vk(self):
         lib = self.ctx.lib

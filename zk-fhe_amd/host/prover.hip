@@ -1703,4 +1703,45 @@ int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk
   }
 }
 
+// The phase-1 gate stream exactly as the GPU witness generator produces it (gpu_witness.cuh), for a caller-chosen
+// challenge: the cells of examples/bfv.rs:171-301 in halo2-base order, canonical values.  This is the parity hook of
+// tests compare it cell for cell with the oracle's restatement of src/poly_chip.rs.
+int zkfhe_bfv_witness_stream(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk_c, const char *input_json, const uint8_t gamma_le[32], uint8_t *cells_out,
+                             size_t cap_cells, size_t *n_cells) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, pk_c && input_json && gamma_le && n_cells);
+  zkfhe_bfv_pk *pk = const_cast<zkfhe_bfv_pk *>(pk_c);
+  *n_cells = pk->gate1_cells;
+  if (!cells_out) return ZKFHE_OK;
+  ZK_ARG(ctx, cap_cells >= pk->gate1_cells);
+  try {
+    Workspace *ws;
+    CK(get_workspace(ctx, pk, &ws));
+    CK(zkfhe_sync(ctx));
+    GpuPolyMul gpu_mul(ctx, ws);
+    struct BackendGuard {
+      explicit BackendGuard(PolyMulBackend *b) { poly_mul_backend() = b; }
+      ~BackendGuard() { poly_mul_backend() = nullptr; }
+    } guard(&gpu_mul);
+    const CircuitInput in = CircuitInput::parse_json(input_json);
+    Context ctx0(CTX_PHASE0, false, false), ctx_rlc(CTX_RLC1, true, false);
+    std::vector<Cell> make_public;
+    BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
+    U256 gamma, evals[12];
+    memcpy(gamma.l, gamma_le, 32);
+    if (!(gamma < fe::MOD)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "gamma is not a canonical Fr value");
+    CK(alloc_witness_buffers(ctx, pk, ws));
+    GpuPhase1 g1(ctx, pk, ws);
+    CK(g1.launch(st));
+    bfv_phase1_rlc(st, ctx_rlc, gamma, evals);
+    CK(g1.finish(evals));
+    CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)ws->stream.p, (zkfhe_fr *)ws->stream.p, pk->gate1_cells));
+    ZK_HIP(ctx, hipMemcpyAsync(cells_out, ws->stream.p, pk->gate1_cells * 32, hipMemcpyDeviceToHost, ctx->stream));
+    CK(zkfhe_sync(ctx));
+    return ZKFHE_OK;
+  } catch (const std::exception &e) {
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, e.what());
+  }
+}
+
 }  // extern "C"
