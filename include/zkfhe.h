@@ -160,6 +160,10 @@ typedef struct zkfhe_bfv_tables zkfhe_bfv_tables;
 int zkfhe_bfv_build_tables(const char *input_json, const zkfhe_bfv_params *params, const zkfhe_bfv_config *config,
                            const uint8_t gamma[32], int keygen_mode, zkfhe_bfv_tables **out, char *err, size_t err_len);
 void zkfhe_bfv_tables_free(zkfhe_bfv_tables *t);
+/* Column counts the circuit needs at 2^k rows (halo2-base auto-configuration, the first half of the reference's keygen):
+ * counts_out = { n_gate0, n_gate1, n_lookup, n_rlc }.  Host only. */
+int zkfhe_bfv_auto_config(const char *input_json, const zkfhe_bfv_params *params, uint32_t k, uint32_t unusable_rows, uint32_t lookup_bits,
+                          uint32_t counts_out[4], char *err, size_t err_len);
 /* what: 0 n_advice, 1 n_fixed, 2 n rows, 3 n_instance, 4 n_copies, 5/6/7 number of break points gate0/gate1/rlc,
  *       8/9/10 cells in the phase-0 / phase-1 gate / RLC stream, 11 lookup cells */
 size_t zkfhe_bfv_tables_count(const zkfhe_bfv_tables *t, int what);

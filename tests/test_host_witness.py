@@ -74,3 +74,23 @@ def test_bad_inputs_fail_with_status():
         zk.bfv_build_tables(json.dumps(bad), PRM, zcfg, 1, True)
     with pytest.raises(zk.ZkfheError):
         zk.bfv_build_tables("{not json", PRM, zcfg, 1, True)
+
+
+def test_auto_config_reproduces_the_pinned_column_counts():
+    """zkfhe_bfv_auto_config (halo2-base auto-configuration, the first half of the reference's keygen) on bfv_empty.in at k = 13
+    gives exactly the column counts of the reference's configs/bfv.json; k too small is an error, larger k needs fewer columns."""
+    import json
+    import os
+    import zk_fhe_amd as zk
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bfv")
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    want = zk.BfvConfig.from_pinning(cfgj)
+    text = open(os.path.join(G, "bfv_empty.in")).read()
+    prm = (1024, 536870909, 7, 19)
+    got = zk.bfv_auto_config(text, prm, 13)
+    assert (got.n_gate0, got.n_gate1, got.n_lookup, got.n_rlc) == (want.n_gate0, want.n_gate1, want.n_lookup, want.n_rlc) == (3, 153, 36, 5)
+    big = zk.bfv_auto_config(text, prm, 15)
+    assert big.n_gate1 < got.n_gate1 and big.n_lookup < got.n_lookup
+    import pytest
+    with pytest.raises(zk.ZkfheError):
+        zk.bfv_auto_config(text, prm, 6)

@@ -26,7 +26,7 @@ EXPORTS = [
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
     "zkfhe_g1_add", "zkfhe_g1_mul",
     "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",
-    "zkfhe_bfv_build_tables", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
+    "zkfhe_bfv_build_tables", "zkfhe_bfv_auto_config", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points",
     "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
@@ -387,6 +387,21 @@ def _bfv_sigs(lib):
     for f in ("advice", "fixed", "instance", "copies"):
         getattr(lib, "zkfhe_bfv_tables_copy_" + f).argtypes = [vp, vp]
     lib.zkfhe_bfv_tables_copy_break_points.argtypes = [vp, ci, vp]
+
+
+def bfv_auto_config(input_json_text, params, k, unusable_rows=109, lookup_bits=8):
+    """zkfhe_bfv_auto_config: the BfvConfig (column counts) the circuit needs at 2^k rows; host only."""
+    lib = load_library()
+    lib.zkfhe_bfv_auto_config.argtypes = [ctypes.c_char_p, ctypes.POINTER(BfvParamsC), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                          ctypes.POINTER(ctypes.c_uint32), ctypes.c_char_p, ctypes.c_size_t]
+    prm = BfvParamsC(*params)
+    counts = (ctypes.c_uint32 * 4)()
+    err = ctypes.create_string_buffer(256)
+    text = input_json_text if isinstance(input_json_text, bytes) else input_json_text.encode()
+    rc = lib.zkfhe_bfv_auto_config(text, ctypes.byref(prm), k, unusable_rows, lookup_bits, counts, err, 256)
+    if rc != 0:
+        raise ZkfheError("zkfhe_bfv_auto_config failed (%d): %s" % (rc, err.value.decode()))
+    return BfvConfig(k, counts[0], counts[1], counts[2], counts[3], unusable_rows, lookup_bits)
 
 
 def bfv_build_tables(input_json_text, params, config, gamma, keygen_mode, replay=False):

@@ -211,8 +211,16 @@ int main(int argc, char **argv) {
     zkfhe_bfv_config c{};
     if (have_pin) c = pin.c;
     else {
-      fprintf(stderr, "keygen: %s not found; column counts must be given by a pinning file (auto-configuration: SURVEY.md 8f)\n", pin_path.c_str());
-      return 1;
+      // no pinning yet: halo2-base auto-configuration, as the reference's keygen does (README.md:28-38)
+      uint32_t counts[4];
+      char aerr[256] = {0};
+      if (zkfhe_bfv_auto_config(text.c_str(), &prm, k, 109, 8, counts, aerr, sizeof(aerr))) {
+        fprintf(stderr, "keygen: auto-configuration failed: %s\n", aerr);
+        return 1;
+      }
+      c.n_gate0 = counts[0], c.n_gate1 = counts[1], c.n_lookup = counts[2], c.n_rlc = counts[3];
+      c.unusable_rows = 109, c.lookup_bits = 8;
+      printf("auto-configured columns: gate %u + %u, lookup %u, rlc %u\n", counts[0], counts[1], counts[2], counts[3]);
     }
     c.replay = 0;
     c.k = k;

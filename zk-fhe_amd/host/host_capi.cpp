@@ -83,6 +83,34 @@ int zkfhe_bfv_build_tables(const char *input_json, const zkfhe_bfv_params *param
   }
 }
 
+// halo2-base's auto-configuration (what the reference's `keygen` does before it writes configs/<name>.json, README.md:28-38):
+// run the circuit once, walk the three cell streams with the break-point rule and count the columns they need at 2^k rows.
+int zkfhe_bfv_auto_config(const char *input_json, const zkfhe_bfv_params *params, uint32_t k, uint32_t unusable_rows, uint32_t lookup_bits,
+                          uint32_t counts_out[4], char *err, size_t err_len) {
+  if (!input_json || !params || !counts_out || k < 3 || k > 24) return ZKFHE_EINVAL;
+  try {
+    const BfvParams prm = params_from_c(params);
+    const CircuitInput in = CircuitInput::parse_json(input_json);
+    Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
+    std::vector<Cell> make_public;
+    BfvState st = bfv_phase0(ctx0, in, prm, make_public);
+    bfv_phase1(st, prm, ctx_gate, ctx_rlc, fe::zero());
+    const size_t n = (size_t)1 << k;
+    if (unusable_rows + 8 >= n) throw std::runtime_error("k too small for the blinding rows");
+    const size_t max_rows = n - unusable_rows;
+    if (((size_t)1 << lookup_bits) > max_rows) throw std::runtime_error("lookup table does not fit the rows");
+    if (make_public.size() > max_rows) throw std::runtime_error("too many instances for this k");
+    counts_out[0] = ctx0.advice.empty() ? 0 : place_stream(ctx0.advice.size(), ctx0.selector, max_rows, false, nullptr).n_columns;
+    counts_out[1] = ctx_gate.advice.empty() ? 0 : place_stream(ctx_gate.advice.size(), ctx_gate.selector, max_rows, false, nullptr).n_columns;
+    counts_out[2] = (uint32_t)((ctx_gate.lookup.size() + max_rows - 1) / max_rows);
+    counts_out[3] = ctx_rlc.advice.empty() ? 0 : place_stream(ctx_rlc.advice.size(), ctx_rlc.selector, max_rows, true, nullptr).n_columns;
+    return ZKFHE_OK;
+  } catch (const std::exception &e) {
+    if (err && err_len) snprintf(err, err_len, "%s", e.what());
+    return ZKFHE_EINVAL;
+  }
+}
+
 void zkfhe_bfv_tables_free(zkfhe_bfv_tables *t) { delete t; }
 
 size_t zkfhe_bfv_tables_count(const zkfhe_bfv_tables *t, int what) {
