@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(256) k_pow_table_scaled(Fr start, Fr base, Fr 
 // LEF in {1,2,3}.
 // large-n forward coset extension, step 1: out[c][k1][i] = in[c][i] * pre[k1][i]
 __global__ void __launch_bounds__(256) k_coset_prescale(const Fr *__restrict__ in, const Fr *__restrict__ pre, Fr *__restrict__ out, size_t n_cols,
-                                                        int log_n, int lef) {
-  const size_t n = (size_t)1 << log_n, ne = n << lef;
+                                                        int log_n, int rows) {
+  const size_t n = (size_t)1 << log_n, ne = n * (size_t)rows;
   const size_t total = n_cols * ne;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t c = g / ne, r = g - c * ne, i = r & (n - 1);
@@ -324,20 +324,20 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   return ZKFHE_OK;
 }
 
-// Forward coset extension of the first `rows` cosets only (rows <= 2^lef; same coset-major layout, the remaining rows of
-// every column are left untouched).  The prover's quotient has degree < 3n, so three of the four cosets determine it.
+// Forward coset extension of the first `rows` cosets only (rows <= 2^lef), written DENSELY: column c, coset k1 at
+// out + (c * rows + k1) * n.  The prover's quotient has degree < 3n, so three of the four cosets determine it.
 extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev, size_t n_cols, int log_n, int lef, const Fr &g, int rows) {
   const int E = 1 << lef;
-  if (rows >= E || log_n > MAX_TILE_LOG) return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)in_dev, (zkfhe_fr *)out_dev, n_cols, log_n, lef, (const zkfhe_fr *)&g, 0);
+  if (rows >= E) return zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)in_dev, (zkfhe_fr *)out_dev, n_cols, log_n, lef, (const zkfhe_fr *)&g, 0);
   if (!n_cols) return ZKFHE_OK;
-  const size_t n = (size_t)1 << log_n, ne = n * E;
+  const size_t n = (size_t)1 << log_n, nr = n * (size_t)rows;
   const NttDomain *dom, *edom;
   int rc = zk_domain(ctx, log_n, &dom);
   if (rc) return rc;
   rc = zk_domain(ctx, log_n + lef, &edom);
   if (rc) return rc;
   void *p;
-  rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
+  rc = zk_scratch(ctx, 1, nr * sizeof(Fr), &p);
   if (rc) return rc;
   Fr *pre = (Fr *)p;
   Fr shift = g;
@@ -346,12 +346,20 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
     ZK_LAUNCH_CHECK(ctx);
     shift = shift * edom->omega;
   }
+  if (log_n > MAX_TILE_LOG) {
+    unsigned gr = zk_blocks(n_cols * nr, 256);
+    const unsigned capg = (unsigned)ctx->num_cu * 16;
+    if (gr > capg) gr = capg;
+    k_coset_prescale<<<gr, 256, 0, ctx->stream>>>(in_dev, pre, out_dev, n_cols, log_n, rows);
+    ZK_LAUNCH_CHECK(ctx);
+    return zkfhe_ntt_batch(ctx, (zkfhe_fr *)out_dev, n_cols * (size_t)rows, log_n, 0);
+  }
   TileArgs a{};
   a.in = in_dev;
   a.out = out_dev;
   a.in_tile_stride = 0;
   a.col_stride_in = n;
-  a.col_stride_out = ne;
+  a.col_stride_out = nr;
   a.tw = dom->fwd;
   a.pre = pre;
   a.pre_tile_stride = n;
@@ -396,7 +404,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
       unsigned gr = zk_blocks(n_cols * ne, 256);
       const unsigned capg = (unsigned)ctx->num_cu * 16;
       if (gr > capg) gr = capg;
-      k_coset_prescale<<<gr, 256, 0, ctx->stream>>>((const Fr *)in_dev, pre, (Fr *)out_dev, n_cols, log_n, lef);
+      k_coset_prescale<<<gr, 256, 0, ctx->stream>>>((const Fr *)in_dev, pre, (Fr *)out_dev, n_cols, log_n, E);
       ZK_LAUNCH_CHECK(ctx);
       return zkfhe_ntt_batch(ctx, out_dev, n_cols * E, log_n, 0);
     }

@@ -159,6 +159,9 @@ struct zkfhe_bfv_pk {
   U256 vk_digest;
   // structure of the phase-1 gate stream, recorded at keygen for the GPU witness generator
   size_t gate1_cells = 0, n_lookup_cells = 0, n_inv_slots = 0;
+  // cosets of the extended domain the quotient is evaluated on: 3 (degree < 3n), or all 4 with ZKFHE_CHECK_QUOTIENT set when
+  // the key is built (the fourth gives the degree check).  Every extended array has this many rows per column.
+  int ext_rows = 3;
   DevBuf lookup_src, inv_slots, place_start, place_len;   // device: u32 lists
   // per-context prover workspaces: one proof at a time per zkfhe_ctx, any number of contexts (streams)
   // may prove concurrently against the same key (everything above is read-only after keygen)
@@ -268,8 +271,8 @@ std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const st
   return out;
 }
 
-int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
-  const size_t n = c.n(), ne = 4 * n, col = n * 32, ecol = ne * 32;
+int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int ext_rows) {
+  const size_t n = c.n(), ne = (size_t)ext_rows * n, col = n * 32, ecol = ne * 32;
   const size_t n_all = (size_t)c.n_advice() + 3 * c.n_lookup + c.n_chunks() + 1;
   ws->n_all = n_all;
   CK(ws->all_l.alloc(ctx, n_all * col));
@@ -289,9 +292,9 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws) {
     take(ws->inst_l, ws->inst_ext, 1);
   }
   CK(ws->tmp_c.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * col));
-  CK(ws->partials.alloc(ctx, 96 * ecol));
-  CK(ws->h_ext.alloc(ctx, ecol));
-  CK(ws->h_c.alloc(ctx, ecol));
+  CK(ws->partials.alloc(ctx, 96 * 4 * col));
+  CK(ws->h_ext.alloc(ctx, 4 * col));
+  CK(ws->h_c.alloc(ctx, 4 * col));
   CK(ws->misc.alloc(ctx, 32 * col));
   CK(ws->points.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * 64 + 64));
   CK(ws->num.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
@@ -328,7 +331,7 @@ int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
   auto it = pk->workspaces.find(ctx);
   if (it == pk->workspaces.end()) {
     Workspace *ws = new Workspace();
-    int rc = alloc_workspace(ctx, pk->cfg, ws);
+    int rc = alloc_workspace(ctx, pk->cfg, ws, pk->ext_rows);
     if (rc) {
       for (DevBuf *b : ws->all()) b->release();
       delete ws;
@@ -341,8 +344,9 @@ int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
 }
 
 // coefficient form of `count` Lagrange columns (copy into tmp, iNTT), then coset-extend into ext
-int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext, int rows = 4) {
+int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext) {
   if (!count) return ZKFHE_OK;
+  const int rows = pk->ext_rows;
   const size_t n = pk->cfg.n();
   const Fr g = mont_u64(COSET_G);
   CK(zk_copy_d2d(ctx, ws->tmp_c.p, lagr, count * n * 32));
@@ -357,10 +361,11 @@ int build_resident_tables(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws) {
   const size_t n = cfg.n(), cells = (size_t)cfg.n_perm() * n;
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)cfg.k, &dom));
-  CK(pk->fixed_ext.alloc(ctx, (size_t)cfg.n_fixed() * 4 * n * 32));
-  CK(pk->sigma_ext.alloc(ctx, cells * 4 * 32));
-  CK(pk->l_ext.alloc(ctx, 3 * 4 * n * 32));
-  CK(pk->xs_ext.alloc(ctx, 4 * n * 32));
+  const size_t R = (size_t)pk->ext_rows;
+  CK(pk->fixed_ext.alloc(ctx, (size_t)cfg.n_fixed() * R * n * 32));
+  CK(pk->sigma_ext.alloc(ctx, cells * R * 32));
+  CK(pk->l_ext.alloc(ctx, 3 * R * n * 32));
+  CK(pk->xs_ext.alloc(ctx, R * n * 32));
   CK(extend_cols(ctx, pk, ws, pk->fixed_l.fr(), cfg.n_fixed(), pk->fixed_ext.fr()));
   CK(extend_cols(ctx, pk, ws, pk->sigma_l.fr(), cfg.n_perm(), pk->sigma_ext.fr()));
   {
@@ -375,7 +380,7 @@ int build_resident_tables(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws) {
   {
     const Fr wext = zk_fr_root_of_unity((int)cfg.k + 2);
     Fr shift = mont_u64(COSET_G);
-    for (int k1 = 0; k1 < 4; ++k1) {
+    for (int k1 = 0; k1 < pk->ext_rows; ++k1) {
       zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(shift, dom->omega, pk->xs_ext.fr() + (size_t)k1 * n, n);
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * wext;
@@ -424,6 +429,7 @@ int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, co
   zkfhe_bfv_pk *pk = new zkfhe_bfv_pk();
   pk->cfg = cfg;
   pk->prm = prm;
+  pk->ext_rows = getenv("ZKFHE_CHECK_QUOTIENT") ? 4 : 3;
   {
     // structure of the phase-1 gate stream for the GPU witness generator: where looked-up cells and deferred
     // inverses sit in the stream, and which stream range each gate column holds (break points)
@@ -1061,10 +1067,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // ------------------------------------------------------------ quotient
   // The quotient has degree < 3n, so three cosets determine it (one quarter less extension and evaluation work).  The
   // fourth coset is only needed for the degree check below (a violated gate shows up as a non-zero top quarter):
-  // ZKFHE_CHECK_QUOTIENT=1 turns it back on.  Rows longer than one NTT tile keep the four-coset path.
-  static const bool check_quotient = getenv("ZKFHE_CHECK_QUOTIENT") != nullptr;
-  const int q_rows = (k <= 13 && !check_quotient) ? 3 : 4;
-  CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr(), q_rows));
+  // a key built with ZKFHE_CHECK_QUOTIENT=1 in the environment keeps it (pk->ext_rows).
+  const int q_rows = pk->ext_rows;
+  CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr()));
   {
     // expression groups, in the folding order of oracle/halo2_ref.py expressions_at
     std::vector<zkp::QGroup> groups;
@@ -1560,6 +1565,7 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
     return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + " is not a ZKFHEPK1 proving key");
   }
   zkfhe_bfv_pk *pk = new zkfhe_bfv_pk();
+  pk->ext_rows = getenv("ZKFHE_CHECK_QUOTIENT") ? 4 : 3;
   auto fail = [&](const std::string &why) {
     fclose(f);
     zkfhe_bfv_pk_destroy(ctx, pk);

@@ -145,13 +145,13 @@ struct QArgs {
   Fr *partials;  // [n_groups][4n]
   Fr y, beta, gamma, gamma_rlc;
   unsigned log_n, u, n_gate, n_rlc, adv_rlc0, fix_qrlc0, fix_const, fix_table, adv_lookup0, n_advice, n_perm, chunk, n_chunks;
-  unsigned rows;  // cosets evaluated (3 or 4); the layout always has 4 rows per column
+  unsigned rows;  // cosets evaluated (3 or 4) = rows per column of every extended array (column stride rows * n)
 };
 
 __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
-  const size_t n = (size_t)1 << a.log_n, ne = n << 2;
+  const size_t n = (size_t)1 << a.log_n, ne = n * a.rows;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= n * a.rows) return;
+  if (p >= ne) return;
   const QGroup g = a.groups[blockIdx.y];
   const size_t row0 = p & ~(n - 1);           // k1 * n
   const size_t k2 = p & (n - 1);
@@ -223,9 +223,9 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
 // h_ext[p] = (sum_g ypow[g] * partials[g][p]) * zinv[k1]
 __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
                                                           const Fr *__restrict__ zinv, unsigned log_n, unsigned rows, Fr *__restrict__ h_ext) {
-  const size_t n = (size_t)1 << log_n, ne = n << 2;
+  const size_t n = (size_t)1 << log_n, ne = n * rows;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= n * rows) return;
+  if (p >= ne) return;
   Fr acc = Fr::zero();
   for (unsigned g = 0; g < n_groups; ++g) acc = acc + ypow[g] * partials[(size_t)g * ne + p];
   h_ext[p] = acc * zinv[p >> log_n];
