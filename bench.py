@@ -121,11 +121,13 @@ def main():
     si = n_streams + args.warmup
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     batch.run_concurrent(list(range(si, si + args.steps)), ctxs, one_proof)   # exactly K proofs, n_streams in flight
     for c in ctxs:
         c.sync()
     barrier()
     dt = time.perf_counter() - t0
+    host_cpu_ms = (time.process_time() - cpu0) * 1e3 / max(1, args.steps)   # all threads of this rank
     si += args.steps
     dt = batch.max_over_ranks(dt, device="cuda" if (world > 1 and backend == "nccl") else None)
     stage /= max(1, args.steps)
@@ -169,7 +171,7 @@ def main():
             "scaling": "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if world == 1 else None,
             "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
             "config": {"workload": "one proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout",
-                       "concurrent_proofs_per_gpu": n_streams,
+                       "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

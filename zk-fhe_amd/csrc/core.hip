@@ -79,6 +79,13 @@ int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
   // one hardware queue per concurrent context (ROCm default: 4 per process, streams sharing a queue serialise); a no-op
   // when the host application already initialised the HIP runtime or set the variable itself
   setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  // host threads that wait for the GPU sleep instead of spinning (a dozen proving threads per GPU would otherwise keep a
+  // dozen cores busy doing nothing); ZKFHE_SPIN_WAIT=1 keeps the runtime's default
+  if (!getenv("ZKFHE_SPIN_WAIT")) {
+    (void)hipSetDevice(device_id);
+    (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    (void)hipGetLastError();
+  }
   if (!out) return zk_fail_msg(nullptr, ZKFHE_EINVAL, "out is NULL");
   *out = nullptr;
   int count = 0;
@@ -102,6 +109,7 @@ int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
     ctx->own_stream = true;
   }
   if (hipHostMalloc(&ctx->bounce, zkfhe_ctx::BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) ctx->bounce = nullptr;
+  if (hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) ctx->wait_ev = nullptr;
   hipEventCreate(&ctx->ev0);
   hipEventCreate(&ctx->ev1);
   hipEventCreate(&ctx->pe0);
@@ -122,6 +130,7 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
   }
   for (int i = 0; i < 4; ++i)
     if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+  if (ctx->wait_ev) hipEventDestroy(ctx->wait_ev);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -133,7 +142,7 @@ const char *zkfhe_last_error(const zkfhe_ctx *ctx) { return ctx ? ctx->err.c_str
 
 int zkfhe_sync(zkfhe_ctx *ctx) {
   ZK_ENTER(ctx);
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_wait(ctx));
   return ZKFHE_OK;
 }
 
@@ -180,7 +189,7 @@ int zkfhe_upload(zkfhe_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
   } else {
     ZK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   }
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_wait(ctx));
   return ZKFHE_OK;
 }
 int zkfhe_download(zkfhe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
@@ -188,12 +197,12 @@ int zkfhe_download(zkfhe_ctx *ctx, void *dst_host, const void *src_dev, size_t b
   if (!bytes) return ZKFHE_OK;
   if (ctx->bounce && bytes <= zkfhe_ctx::BOUNCE_BYTES) {
     ZK_HIP(ctx, hipMemcpyAsync(ctx->bounce, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_wait(ctx));
     memcpy(dst_host, ctx->bounce, bytes);
     return ZKFHE_OK;
   }
   ZK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_wait(ctx));
   return ZKFHE_OK;
 }
 int zkfhe_copy_dev(zkfhe_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {

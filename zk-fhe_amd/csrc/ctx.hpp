@@ -29,6 +29,7 @@ struct zkfhe_ctx {
   // profiling (zkfhe_prof_*): [0] = k_msm_accumulate, [1] = k_ntt_tile
   bool prof_on = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: host waits sleep instead of spinning (zk_wait)
   double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0}, prof_ops[2] = {0, 0};
   uint64_t prof_launches[2] = {0, 0};
   // pinned bounce buffer for small host<->device transfers (pageable copies go through the runtime's shared staging path)
@@ -81,6 +82,16 @@ inline void zk_prof_end(zkfhe_ctx *ctx, int which, double bytes) {
   ctx->prof_ms[which] += ms;
   ctx->prof_bytes[which] += bytes;
   ctx->prof_launches[which] += 1;
+}
+
+// Wait for everything queued on the context's stream.  hipStreamSynchronize spins; with a dozen proving threads per GPU
+// that is a dozen cores per GPU doing nothing, so the wait goes through an event created with hipEventBlockingSync.
+inline hipError_t zk_wait(zkfhe_ctx *ctx) {
+  static const bool spin = getenv("ZKFHE_SPIN_WAIT") != nullptr;
+  if (spin || !ctx->wait_ev) return hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipEventRecord(ctx->wait_ev, ctx->stream);
+  if (e != hipSuccess) return e;
+  return hipEventSynchronize(ctx->wait_ev);
 }
 
 // returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse

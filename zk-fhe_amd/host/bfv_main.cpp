@@ -199,6 +199,7 @@ int main(int argc, char **argv) {
     printf("Snark verified successfully in %.3fms\n", ms);
     return 0;
   }
+  setenv("ZKFHE_SPIN_WAIT", "1", 0);  // one proof at a time: spinning waits are ~1.4 ms faster per proof than sleeping ones
   zkfhe_ctx *ctx = nullptr;
   if (zkfhe_ctx_create(0, nullptr, &ctx)) {
     fprintf(stderr, "no gfx950 device: %s\n", zkfhe_last_error(nullptr));

@@ -322,7 +322,7 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   CK(ws->wblind.alloc(ctx, (nblind + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_wblind, (nblind + 8) * 32, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
-  ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming));
+  ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming | hipEventBlockingSync));
   return ZKFHE_OK;
 }
 
@@ -782,7 +782,7 @@ class PreRng {
   }
   U256 next() {
     if (idx >= vals.size()) throw std::logic_error("blinding stream exhausted");
-    while (done.load(std::memory_order_acquire) <= idx) std::this_thread::yield();
+    while (done.load(std::memory_order_acquire) <= idx) std::this_thread::sleep_for(std::chrono::microseconds(20));
     return vals[idx++];
   }
 
