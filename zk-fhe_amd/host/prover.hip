@@ -318,7 +318,9 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   CK(ws->pool.alloc(ctx, 40 * (2 * N + 8) * 32));
   CK(ws->invtmp.alloc(ctx, (pk->n_inv_slots + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pool, 24 * (2 * N + 8) * 32, hipHostMallocDefault));
-  const size_t nblind = ((size_t)std::max(pk->cfg.n_gate1 + pk->cfg.n_lookup, 2 * pk->cfg.n_lookup) + 1) * (pk->cfg.n() - pk->cfg.u());
+  // blinding rows of the device-generated advice columns, then those of the permuted lookup columns (staged back to back:
+  // both are in flight when the merged commitment is launched)
+  const size_t nblind = ((size_t)pk->cfg.n_gate1 + 3 * pk->cfg.n_lookup + 1) * (pk->cfg.n() - pk->cfg.u());
   CK(ws->wblind.alloc(ctx, (nblind + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_wblind, (nblind + 8) * 32, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
@@ -917,14 +919,44 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
   }
   trace.mark("blind + upload phase 1");
-  CK(commit_cols(ctx, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+  std::vector<AffinePoint> la_commit, ls_commit;
+  const bool merged = !host_witness && cfg.n_lookup > 0;   // permuted lookup columns committed together with the advice
+  if (merged) {
+    // Single-expression lookups do not use theta, so the permuted columns can be built before the advice commitment is
+    // hashed: one MSM call over [phase-1 advice | la | ls] (contiguous in all_l) instead of two, same points, same
+    // transcript order, same draw order of the blinding values.
+    if (cfg.lookup_bits != 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "the device lookup permutation is built for lookup_bits = 8");
+    const size_t nc = cfg.adv_rlc0() - cfg.n_gate0;       // staging slots already used by the advice blinding rows
+    U256 *hst = ws->host_wblind + nc * nbl;
+    Fr *dst = ws->wblind.fr() + nc * nbl;
+    lookup_err = (int *)(dst + 2 * (size_t)cfg.n_lookup * nbl);
+    ZK_HIP(ctx, hipMemsetAsync(lookup_err, 0, 4, ctx->stream));
+    zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
+    ZK_LAUNCH_CHECK(ctx);
+    for (unsigned i = 0; i < cfg.n_lookup; ++i) {   // la_i then ls_i, lookup by lookup; staged as [la columns | ls columns]
+      U256 *a = hst + (size_t)i * nbl, *s = hst + ((size_t)cfg.n_lookup + i) * nbl;
+      for (size_t r = 0; r < nbl; ++r) a[r] = rng.next();
+      for (size_t r = 0; r < nbl; ++r) s[r] = rng.next();
+    }
+    CK(upload_canon(ctx, dst, hst, 2 * (size_t)cfg.n_lookup * nbl));
+    ZK_HIP(ctx, hipMemcpy2DAsync(ws->la_l.fr() + u, n * 32, dst, nbl * 32, nbl * 32, 2 * cfg.n_lookup, hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t n_adv1 = cfg.n_advice() - cfg.n_gate0;
+    CK(commit_cols(ctx, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_adv1 + 2 * cfg.n_lookup, (G1Affine *)ws->points.p, pts));
+    int e = 0;
+    CK(zkfhe_download(ctx, &e, lookup_err, 4));
+    if (e) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
+    la_commit.assign(pts.begin() + n_adv1, pts.begin() + n_adv1 + cfg.n_lookup);
+    ls_commit.assign(pts.begin() + n_adv1 + cfg.n_lookup, pts.end());
+    pts.resize(n_adv1);
+  } else {
+    CK(commit_cols(ctx, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+  }
   trace.mark("commit phase 1 (GPU)");
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
   tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
   // ------------------------------------------------------------ lookups: permuted input / table
-  std::vector<AffinePoint> la_commit, ls_commit;
   if (cfg.n_lookup) {
-    if (host_witness) {
+    if (!merged) {
       std::vector<U256> ap, sp;
       U256 *stA = ws->host_blind, *stS = ws->host_blind + (size_t)cfg.n_lookup * n;  // la | ls, as on the device
       for (unsigned i = 0; i < cfg.n_lookup; ++i) {
@@ -937,31 +969,10 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       }
       ZK_HIP(ctx, hipMemcpyAsync(ws->la_l.p, ws->host_blind, 2 * (size_t)cfg.n_lookup * n * 32, hipMemcpyHostToDevice, ctx->stream));
       CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
-    } else {
-      if (cfg.lookup_bits != 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "the device lookup permutation is built for lookup_bits = 8");
-      // the commit_cols above synchronised the stream, so the staging block is free again
-      lookup_err = (int *)(ws->wblind.fr() + 2 * (size_t)cfg.n_lookup * nbl);
-      ZK_HIP(ctx, hipMemsetAsync(lookup_err, 0, 4, ctx->stream));
-      zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
-      ZK_LAUNCH_CHECK(ctx);
-      // blinding rows: la_i then ls_i, lookup by lookup; staged as [la columns | ls columns]
-      for (unsigned i = 0; i < cfg.n_lookup; ++i) {
-        U256 *a = ws->host_wblind + (size_t)i * nbl, *s = ws->host_wblind + ((size_t)cfg.n_lookup + i) * nbl;
-        for (size_t r = 0; r < nbl; ++r) a[r] = rng.next();
-        for (size_t r = 0; r < nbl; ++r) s[r] = rng.next();
-      }
-      CK(upload_canon(ctx, ws->wblind.fr(), ws->host_wblind, 2 * (size_t)cfg.n_lookup * nbl));
-      // la_l | ls_l are contiguous: one strided copy covers both
-      ZK_HIP(ctx, hipMemcpy2DAsync(ws->la_l.fr() + u, n * 32, ws->wblind.fr(), nbl * 32, nbl * 32, 2 * cfg.n_lookup, hipMemcpyDeviceToDevice, ctx->stream));
+      CK(commit_cols(ctx, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
+      ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
+      la_commit.resize(cfg.n_lookup);
     }
-    CK(commit_cols(ctx, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
-    if (lookup_err) {
-      int e = 0;
-      CK(zkfhe_download(ctx, &e, lookup_err, 4));
-      if (e) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
-    }
-    ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
-    la_commit.resize(cfg.n_lookup);
     for (unsigned i = 0; i < cfg.n_lookup; ++i) {
       tr.write_point(la_commit[i]);
       tr.write_point(ls_commit[i]);
