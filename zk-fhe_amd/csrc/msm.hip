@@ -212,6 +212,13 @@ __device__ __forceinline__ Slices slices_of(unsigned cnt, unsigned TASK_E) {
 __device__ __forceinline__ unsigned partial_pos(const Slices &s, unsigned posA, unsigned posB, unsigned j) { return j < s.r ? posA + j : posB + (j - s.r); }
 
 // per column: number of slices of every length
+// zero the bucket histogram and the heavy-bucket counter of a call (one launch instead of two runtime fills)
+__global__ void __launch_bounds__(256) k_msm_clear(unsigned *__restrict__ hist, size_t words, unsigned *__restrict__ heavy_count) {
+  const size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i0 < 4) heavy_count[i0] = 0;
+  for (size_t i = i0; i < words; i += (size_t)gridDim.x * blockDim.x) hist[i] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_msm_task_count(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, unsigned *__restrict__ col_hist /* [n_cols][TASK_BINS] */) {
   __shared__ unsigned h[TASK_BINS];
   for (unsigned i = threadIdx.x; i < TASK_BINS; i += 256) h[i] = 0;
@@ -707,8 +714,12 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   unsigned *entries = (unsigned *)p2;
   G1X *buckets = (G1X *)p0;
   G1X *partials = buckets + n_cols * (size_t)K;
-  ZK_HIP(ctx, hipMemsetAsync(hist, 0, n_cols * K1 * sizeof(unsigned), ctx->stream));
-  ZK_HIP(ctx, hipMemsetAsync(heavy_count, 0, 4 * sizeof(unsigned), ctx->stream));
+  {
+    unsigned gc = zk_blocks(n_cols * K1, 256);
+    if (gc > (unsigned)ctx->num_cu * 8) gc = (unsigned)ctx->num_cu * 8;
+    k_msm_clear<<<gc, 256, 0, ctx->stream>>>(hist, n_cols * K1, heavy_count);
+    ZK_LAUNCH_CHECK(ctx);
+  }
   const unsigned chunks_per_col = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
   const unsigned grid = (unsigned)(n_cols * chunks_per_col);
   const size_t sort_lds = (size_t)K1 * sizeof(unsigned);
