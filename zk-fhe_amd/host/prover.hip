@@ -81,6 +81,9 @@ struct Workspace {
   U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
   U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
   U256 *host_pool = nullptr;   // pinned staging for the coefficient arrays of the GPU witness generator
+  uint8_t *ring = nullptr;      // pinned bump arena for the small tables of one proof: uploads from it need no host wait
+  size_t ring_off = 0;
+  static constexpr size_t RING_BYTES = (size_t)4 << 20;
   G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
   hipEvent_t ev_pts = nullptr;
   U256 *host_wblind = nullptr; // pinned staging for the blinding rows of device-generated columns
@@ -130,6 +133,10 @@ int upload_canon(zkfhe_ctx *ctx, Fr *dst, const U256 *src, size_t count) {
   ZK_HIP(ctx, hipMemcpyAsync(dst, src, count * 32, hipMemcpyHostToDevice, ctx->stream));
   return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)dst, (zkfhe_fr *)dst, count);
 }
+
+// Small host -> device tables of a proof (expression groups, powers, pointer lists, ...): staged in the workspace's pinned
+// arena and copied without waiting -- the arena is only recycled at the start of the next proof, after a stream sync.
+int up(zkfhe_ctx *ctx, Workspace *ws, void *dst, const void *src, size_t bytes);
 
 // commit `n_cols` columns (device, Montgomery) and return canonical affine points
 int commit_cols(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
@@ -271,6 +278,17 @@ std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const st
   return out;
 }
 
+int up(zkfhe_ctx *ctx, Workspace *ws, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return ZKFHE_OK;
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (!ws->ring || ws->ring_off + need > Workspace::RING_BYTES) return zkfhe_upload(ctx, dst, src, bytes);
+  uint8_t *slot = ws->ring + ws->ring_off;
+  ws->ring_off += need;
+  memcpy(slot, src, bytes);
+  ZK_HIP(ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return ZKFHE_OK;
+}
+
 int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int ext_rows) {
   const size_t n = c.n(), ne = (size_t)ext_rows * n, col = n * 32, ecol = ne * 32;
   const size_t n_all = (size_t)c.n_advice() + 3 * c.n_lookup + c.n_chunks() + 1;
@@ -323,6 +341,7 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   const size_t nblind = ((size_t)pk->cfg.n_gate1 + 3 * pk->cfg.n_lookup + 1) * (pk->cfg.n() - pk->cfg.u());
   CK(ws->wblind.alloc(ctx, (nblind + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_wblind, (nblind + 8) * 32, hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->ring, Workspace::RING_BYTES, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming | hipEventBlockingSync));
   return ZKFHE_OK;
@@ -840,6 +859,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // a previous proof on this context may have been abandoned on an error with copies from the pinned staging buffers still
   // queued: drain the stream before the buffers are rewritten (free when the stream is idle)
   CK(zkfhe_sync(ctx));
+  CK(alloc_witness_buffers(ctx, pk, ws));
+  ws->ring_off = 0;
   trace.mark("setup (rng thread, workspace)");
   const CircuitInput in = CircuitInput::parse_json(input_json);
   trace.mark("parse_json");
@@ -1023,7 +1044,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       acc = acc * totals[j];
     }
     if (!(acc == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "permutation argument does not close: a copy constraint is violated");
-    CK(zkfhe_upload(ctx, totals_dev, carry.data(), nch * 32));
+    CK(up(ctx, ws, totals_dev, carry.data(), nch * 32));
     zkp::k_scale_rows<<<grid_for(ctx, nch * (u + 1)), 256, 0, ctx->stream>>>(ws->pz_l.fr(), totals_dev, n, (unsigned)(u + 1), (unsigned)nch);
     ZK_LAUNCH_CHECK(ctx);
     // blinding rows u+1 .. n-1 (drawn per chunk, in order)
@@ -1104,8 +1125,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     zkp::QGroup *groups_dev = (zkp::QGroup *)((char *)ws->small.p + 256 * 1024);
     Fr *ypow_dev = (Fr *)((char *)ws->small.p + 384 * 1024);
     Fr *zinv_dev = (Fr *)((char *)ws->small.p + 512 * 1024);
-    CK(zkfhe_upload(ctx, groups_dev, groups.data(), G * sizeof(zkp::QGroup)));
-    CK(zkfhe_upload(ctx, ypow_dev, ypow.data(), G * 32));
+    CK(up(ctx, ws, groups_dev, groups.data(), G * sizeof(zkp::QGroup)));
+    CK(up(ctx, ws, ypow_dev, ypow.data(), G * 32));
     const Fr wext = zk_fr_root_of_unity((int)k + 2);
     const Fr gn = fr_pow(mont_u64(COSET_G), n), i4 = fr_pow(wext, n);
     Fr zinv[4], cur = gn;
@@ -1113,7 +1134,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       zinv[t] = fr_inv(cur - Fr::one());
       cur = cur * i4;
     }
-    CK(zkfhe_upload(ctx, zinv_dev, zinv, 4 * 32));
+    CK(up(ctx, ws, zinv_dev, zinv, 4 * 32));
     zkp::QArgs qa;
     qa.adv = ws->adv_ext.fr();
     qa.fix = pk->fixed_ext.fr();
@@ -1208,8 +1229,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     const Fr *ptrs[3] = {ws->h_c.fr(), ws->h_c.fr() + n, ws->h_c.fr() + 2 * n};
     const Fr **ptrs_dev = (const Fr **)((char *)ws->small.p + 640 * 1024);
     Fr *sc_dev = (Fr *)((char *)ws->small.p + 648 * 1024);
-    CK(zkfhe_upload(ctx, ptrs_dev, ptrs, sizeof(ptrs)));
-    CK(zkfhe_upload(ctx, sc_dev, sc, sizeof(sc)));
+    CK(up(ctx, ws, ptrs_dev, ptrs, sizeof(ptrs)));
+    CK(up(ctx, ws, sc_dev, sc, sizeof(sc)));
     zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
     ZK_LAUNCH_CHECK(ctx);
     CK(zk_copy_d2d(ctx, H_l, H_c, n * 32));
@@ -1231,7 +1252,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Fr *bw = ws->misc.fr();  // [6][n] barycentric weights
   {
     Fr *pts_dev = (Fr *)((char *)ws->small.p + 656 * 1024);
-    CK(zkfhe_upload(ctx, pts_dev, pts_rot, sizeof(pts_rot)));
+    CK(up(ctx, ws, pts_dev, pts_rot, sizeof(pts_rot)));
     zkp::k_bary_den<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, pts_dev, 6, n, bw);
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)bw, 6 * n));
@@ -1275,7 +1296,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       for (int r = 0; r < 4; ++r) jobs[i].rot[r] = r < items[i].n_rot ? items[i].rot[r] : 0;
     }
     DevBuf &jd = ws->jobs, &od = ws->evout;
-    CK(zkfhe_upload(ctx, jd.p, jobs.data(), jobs.size() * sizeof(zkp::EvalJob)));
+    CK(up(ctx, ws, jd.p, jobs.data(), jobs.size() * sizeof(zkp::EvalJob)));
     // long columns: 16 row slices per job (partial sums in the dead quotient buffer), then one small reduction
     const unsigned slices = (n > 32768 && (size_t)16 * jobs.size() * 4 * 32 <= ws->partials.bytes) ? 16u : 1u;
     if (slices == 1) {
@@ -1344,8 +1365,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       pd.p = ptab + tab_off * sizeof(void *);
       sd.p = stab + tab_off * 32;
       tab_off += mem.size();
-      CK(zkfhe_upload(ctx, pd.p, ptrs.data(), mem.size() * sizeof(void *)));
-      CK(zkfhe_upload(ctx, sd.p, pw.data(), mem.size() * 32));
+      CK(up(ctx, ws, pd.p, ptrs.data(), mem.size() * sizeof(void *)));
+      CK(up(ctx, ws, sd.p, pw.data(), mem.size() * 32));
       const unsigned per = 48, chunks = (unsigned)((mem.size() + per - 1) / per);
       if (chunks > 1 && (size_t)chunks * n * 32 <= ws->partials.bytes) {
         dim3 lg(grid_for(ctx, n), chunks);
@@ -1394,7 +1415,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Fr *hq = ws->misc.fr() + 28 * n;   // [n]
   Fr *Wq = ws->misc.fr() + 29 * n;   // [n]
   Fr *dinv = ws->misc.fr() + 30 * n; // [n]
-  CK(zkfhe_upload(ctx, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
+  CK(up(ctx, ws, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
   zkp::k_sh_zs<<<grid_for(ctx, ns * n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, dom->fwd, n, zs);
   ZK_LAUNCH_CHECK(ctx);
   CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)zs, ns * n));
@@ -1418,7 +1439,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       ru = ru * uu + shsets[j].rc[0];
       shsets[j].r_u = ru;
     }
-    CK(zkfhe_upload(ctx, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
+    CK(up(ctx, ws, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
     zkp::k_sh_den<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(dom->fwd, uu, n, dinv);
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)dinv, n));
@@ -1469,6 +1490,7 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
     if (kv.second->host_pool) (void)hipHostFree(kv.second->host_pool);
     if (kv.second->host_wblind) (void)hipHostFree(kv.second->host_wblind);
     if (kv.second->host_pts) (void)hipHostFree(kv.second->host_pts);
+    if (kv.second->ring) (void)hipHostFree(kv.second->ring);
     if (kv.second->ev_pts) (void)hipEventDestroy(kv.second->ev_pts);
     delete kv.second;
   }
