@@ -240,6 +240,52 @@ ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
   return fp_mul<P>(a, a);
 }
 
+// (a*b + c*d) * R^-1 mod p with ONE Montgomery reduction: 128 product multiply-adds + 64 for the reduction instead of the
+// 256 of two products (the Y coordinate of every point addition / doubling is such a sum).  (ab + cd)/R + p < 1.4 p.
+template <class P>
+ZK_HD Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 m[8];
+  u32 r[8];
+  u64 acc = 0;
+  u32 top = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      zk_mac(acc, top, a.l[j], b.l[k - j]);
+      zk_mac(acc, top, c.l[j], d.l[k - j]);
+      zk_mac_s(acc, top, m[j], P::MOD[k - j]);
+    }
+    zk_mac(acc, top, a.l[k], b.l[0]);
+    zk_mac(acc, top, c.l[k], d.l[0]);
+    m[k] = (u32)acc * P::INV;
+    zk_mac_s(acc, top, m[k], P::MOD[0]);  // low word becomes 0
+    acc = (acc >> 32) | ((u64)top << 32);
+    top = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; ++k) {
+#pragma unroll
+    for (int j = k - 7; j < 8; ++j) {
+      zk_mac(acc, top, a.l[j], b.l[k - j]);
+      zk_mac(acc, top, c.l[j], d.l[k - j]);
+      zk_mac_s(acc, top, m[j], P::MOD[k - j]);
+    }
+    r[k - 8] = (u32)acc;
+    acc = (acc >> 32) | ((u64)top << 32);
+    top = 0;
+  }
+  Fp<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.l[i] = r[i];
+  fp_reduce_once<P>(o.l);
+  return o;
+#else
+  return fp_add<P>(fp_mul<P>(a, b), fp_mul<P>(c, d));
+#endif
+}
+
 // Montgomery form <-> canonical integer.
 template <class P>
 ZK_HD Fp<P> fp_to_mont(const Fp<P>& a) {
@@ -524,7 +570,7 @@ ZK_HD G1X g1x_from_affine_dbl(const G1Affine& p) {
   Fq xx = fp_sqr<FqP>(p.x);
   Fq m = fp_add<FqP>(fp_dbl<FqP>(xx), xx);  // a = 0
   r.x = fp_sqr<FqP>(m) - fp_dbl<FqP>(s);
-  r.y = m * (s - r.x) - w * p.y;
+  r.y = fp_mul2<FqP>(m, s - r.x, fp_neg<FqP>(w), p.y);
   r.zz = v;
   r.zzz = w;
   return r;
@@ -551,7 +597,7 @@ ZK_HD G1X g1x_dbl(const G1X& p) {
   Fq xx = fp_sqr<FqP>(p.x);
   Fq m = fp_add<FqP>(fp_dbl<FqP>(xx), xx);
   r.x = fp_sqr<FqP>(m) - fp_dbl<FqP>(s);
-  r.y = m * (s - r.x) - w * p.y;
+  r.y = fp_mul2<FqP>(m, s - r.x, fp_neg<FqP>(w), p.y);
   r.zz = v * p.zz;
   r.zzz = w * p.zzz;
   return r;
@@ -587,7 +633,7 @@ ZK_HD void g1x_add_affine(G1X& acc, const G1Affine& q, bool neg) {
   Fq ppp = p * pp;
   Fq qq = acc.x * pp;
   Fq x3 = fp_sqr<FqP>(r) - ppp - fp_dbl<FqP>(qq);
-  acc.y = r * (qq - x3) - acc.y * ppp;
+  acc.y = fp_mul2<FqP>(r, qq - x3, fp_neg<FqP>(acc.y), ppp);
   acc.x = x3;
   acc.zz = acc.zz * pp;
   acc.zzz = acc.zzz * ppp;
@@ -618,7 +664,7 @@ ZK_HD void g1x_add(G1X& acc, const G1X& q) {
   Fq ppp = p * pp;
   Fq qq = u1 * pp;
   Fq x3 = fp_sqr<FqP>(r) - ppp - fp_dbl<FqP>(qq);
-  acc.y = r * (qq - x3) - s1 * ppp;
+  acc.y = fp_mul2<FqP>(r, qq - x3, fp_neg<FqP>(s1), ppp);
   acc.x = x3;
   acc.zz = acc.zz * q.zz * pp;
   acc.zzz = acc.zzz * q.zzz * ppp;
