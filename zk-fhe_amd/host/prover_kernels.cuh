@@ -158,33 +158,33 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
   auto at = [&](const Fr *base, unsigned col, unsigned rot) -> Fr { return base[(size_t)col * ne + row0 + ((k2 + rot) & (n - 1))]; };
   const Fr one = Fr::one();
   Fr acc = Fr::zero();
+  // acc * y + u * v with one Montgomery reduction (bn254.cuh fp_mul2): the Horner step of every expression
+  auto horner = [&](const Fr &u, const Fr &v) { acc = zk::fp_mul2<zk::FrP>(acc, a.y, u, v); };
   switch (g.type) {
     case QG_GATE:
       for (int j = g.first; j < g.first + g.count; ++j) {
         const Fr q = at(a.fix, j, 0);
-        Fr e = Fr::zero();
-        if (!q.is_zero()) e = q * (at(a.adv, j, 0) + at(a.adv, j, 1) * at(a.adv, j, 2) - at(a.adv, j, 3));
-        acc = acc * a.y + e;
+        if (!q.is_zero()) horner(q, at(a.adv, j, 0) + at(a.adv, j, 1) * at(a.adv, j, 2) - at(a.adv, j, 3));
+        else acc = acc * a.y;
       }
       break;
     case QG_RLC:
       for (int j = g.first; j < g.first + g.count; ++j) {
         const unsigned col = a.adv_rlc0 + j;
         const Fr q = at(a.fix, a.fix_qrlc0 + j, 0);
-        const Fr e = q * (at(a.adv, col, 0) * a.gamma_rlc + at(a.adv, col, 1) - at(a.adv, col, 2));
-        acc = acc * a.y + e;
+        horner(q, at(a.adv, col, 0) * a.gamma_rlc + at(a.adv, col, 1) - at(a.adv, col, 2));
       }
       break;
     case QG_PERM_HEAD: {
       const Fr l0 = a.lext[p], ll = a.lext[ne + p];
       const Fr z0 = at(a.pz, 0, 0), zm = at(a.pz, a.n_chunks - 1, 0);
       acc = l0 * (one - z0);
-      acc = acc * a.y + ll * (zm * zm - zm);
+      horner(ll, zm * zm - zm);
       break;
     }
     case QG_PERM_C: {
       const Fr l0 = a.lext[p];
-      for (int j = g.first; j < g.first + g.count; ++j) acc = acc * a.y + l0 * (at(a.pz, j, 0) - at(a.pz, j - 1, a.u));
+      for (int j = g.first; j < g.first + g.count; ++j) horner(l0, at(a.pz, j, 0) - at(a.pz, j - 1, a.u));
       break;
     }
     case QG_PERM_D: {
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
           left = left * (v + a.beta * at(a.sig, c, 0) + a.gamma);
           right = right * (v + a.beta_delta[c] * x + a.gamma);
         }
-        acc = acc * a.y + lact * (left - right);
+        horner(lact, left - right);
       }
       break;
     }
@@ -208,11 +208,11 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
         const Fr z0 = at(a.lz, i, 0), z1 = at(a.lz, i, 1);
         const Fr av = at(a.adv, a.adv_lookup0 + i, 0);
         const Fr ap = at(a.la, i, 0), apm = at(a.la, i, (unsigned)(n - 1)), sp = at(a.ls, i, 0);
-        acc = acc * a.y + l0 * (one - z0);
-        acc = acc * a.y + ll * (z0 * z0 - z0);
-        acc = acc * a.y + lact * (z1 * ((ap + a.beta) * (sp + a.gamma)) - z0 * ((av + a.beta) * (s + a.gamma)));
-        acc = acc * a.y + l0 * (ap - sp);
-        acc = acc * a.y + lact * ((ap - sp) * (ap - apm));
+        horner(l0, one - z0);
+        horner(ll, z0 * z0 - z0);
+        horner(lact, zk::fp_mul2<zk::FrP>(z1, (ap + a.beta) * (sp + a.gamma), zk::fp_neg<zk::FrP>(z0), (av + a.beta) * (s + a.gamma)));
+        horner(l0, ap - sp);
+        horner(lact, (ap - sp) * (ap - apm));
       }
       break;
     }
