@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
 MODMUL_PEAK_G = 125.0        # G Montgomery products / s, all 256 CUs busy: measured, tools/microbench.py fr_mul (profiles/r1_microbench.md)
-MODMUL_PER_MIXED_ADD = 10.0  # XYZZ += affine: 8 M + 2 S (the first addition into an empty accumulator is free and still counted)
+MODMUL_PER_MIXED_ADD = 10.0  # XYZZ += affine: 8 M + 2 S (the first addition into an empty accumulator is free and still counted; the fused Y3 makes it 9.5 reductions)
 Q, T, B, N = 536870909, 7, 19, 1024
 
 
