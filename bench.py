@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=12, help="concurrent proofs per GPU (one HIP stream + workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
+                    help="Fiat-Shamir hash: poseidon = snark-verifier PoseidonTranscript (the reference's, examples/bfv.rs:311); blake2b = halo2's own")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +88,7 @@ def main():
 
     ctx = zk.Context(local_rank)
     cfgj = json.load(open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv_config.json")))
-    zcfg = zk.BfvConfig.from_pinning(cfgj)
+    zcfg = zk.BfvConfig.from_pinning(cfgj, transcript=args.transcript)
     empty = json.dumps({k: ["0"] * (N + 1 if k == "cyclo" else N) for k in ("pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo")})
     srs = zk.Srs(ctx, 13)
     pk = zk.BfvProvingKey(ctx, srs, empty, (N, Q, T, B), zcfg, replay=True)
@@ -154,7 +156,7 @@ def main():
             from oracle import binding as orc
             from oracle import circuit_ref as C
             from oracle import halo2_ref as H
-            hcfg = H.Config.from_pinning(cfgj)
+            hcfg = H.Config.from_pinning(cfgj, transcript=args.transcript)
             bp = {"gate0": cfgj["break_points"]["gate"][0], "gate1": cfgj["break_points"]["gate"][1], "rlc": cfgj["break_points"]["rlc"]}
             srs_o = H.make_srs(13)
             pk_o, _ = H.keygen_circuit(hcfg, H.BfvCircuit(json.loads(empty), C.BfvParams()), srs_o, bp)
@@ -171,7 +173,7 @@ def main():
             "scaling": "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if world == 1 else None,
             "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
             "config": {"workload": "one proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout",
-                       "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
+                       "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -140,6 +140,26 @@ int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint
 int zkfhe_witness_div_mod(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, uint64_t q, zkfhe_fr *div_dev,
                           zkfhe_fr *rem_dev, size_t n);
 
+/* ---- Fiat-Shamir transcript (host only; replaces snark-verifier `PoseidonTranscript<NativeLoader>` /
+ * halo2_proofs `Blake2bWrite`, reached from reference examples/bfv.rs:311 via gen_snark_shplonk) -------------- */
+#define ZKFHE_TRANSCRIPT_POSEIDON 0   /* T = 3, RATE = 2, R_F = 8, R_P = 57 over BN254 Fr: what the reference proves / verifies with */
+#define ZKFHE_TRANSCRIPT_BLAKE2B 1    /* halo2's "Halo2-Transcript" Blake2b with Challenge255 */
+typedef struct zkfhe_transcript zkfhe_transcript;
+int zkfhe_transcript_create(uint32_t kind, zkfhe_transcript **out);
+void zkfhe_transcript_destroy(zkfhe_transcript *t);
+/* scalars: canonical 32-byte little-endian Fr; points: canonical affine x || y (64 bytes, little-endian Fq each).
+ * common_* only absorb; write_* also append the 32-byte encoding (compressed point / scalar) to the byte stream. */
+int zkfhe_transcript_common_scalar(zkfhe_transcript *t, const uint8_t s_le[32]);
+int zkfhe_transcript_write_scalar(zkfhe_transcript *t, const uint8_t s_le[32]);
+int zkfhe_transcript_common_point(zkfhe_transcript *t, const uint8_t xy_le[64]);
+int zkfhe_transcript_write_point(zkfhe_transcript *t, const uint8_t xy_le[64]);
+int zkfhe_transcript_squeeze(zkfhe_transcript *t, uint8_t challenge_le[32]);
+int zkfhe_transcript_bytes(const zkfhe_transcript *t, uint8_t *out, size_t cap, size_t *len);
+/* The Poseidon instance itself: one permutation of three canonical 32-byte LE words in place, and the generated
+ * constants (65 x 3 round constants, 3 x 3 MDS, canonical 32-byte LE each) for cross-checks. */
+int zkfhe_poseidon_permute(uint8_t state_le[96]);
+int zkfhe_poseidon_constants(uint8_t round_constants_le[65 * 3 * 32], uint8_t mds_le[9 * 32]);
+
 /* ---- BFV circuit: witness tables, keygen, prove (reference examples/bfv.rs + halo2-scaffold run_eth) ---- */
 /* Runtime form of the compile-time constants at examples/bfv.rs:27-30. */
 typedef struct { uint64_t n; uint64_t q; uint64_t t; uint64_t b; } zkfhe_bfv_params;
@@ -151,6 +171,7 @@ typedef struct {
   const uint32_t *bp_gate1; uint32_t n_bp_gate1;
   const uint32_t *bp_rlc;   uint32_t n_bp_rlc;
   int replay;
+  uint32_t transcript;   /* ZKFHE_TRANSCRIPT_*: part of the verifying key (bound into its digest) */
 } zkfhe_bfv_config;
 
 typedef struct zkfhe_bfv_tables zkfhe_bfv_tables;
@@ -174,6 +195,13 @@ int zkfhe_bfv_tables_copy_instance(const zkfhe_bfv_tables *t, uint64_t *out);   
 int zkfhe_bfv_tables_copy_copies(const zkfhe_bfv_tables *t, uint64_t *out);     /* n_copies * 2 (cell = perm_col * n + row) */
 int zkfhe_bfv_tables_copy_break_points(const zkfhe_bfv_tables *t, int which, uint32_t *out);
 
+/* `mock` (README.md:18-22, halo2 MockProver::run(..).assert_satisfied()): evaluates every constraint on every row of
+ * tables built with keygen_mode != 0 and the same gamma -- gate and RLC-gate identities under their selectors, lookup
+ * membership, and both cells of every copy constraint.  *n_failures = number of violated rows / constraints, err = the
+ * first one.  Host only.  zkfhe_bfv_tables_poke_advice overwrites one advice cell (negative tests of the checker). */
+int zkfhe_bfv_mock_check(const zkfhe_bfv_tables *t, const uint8_t gamma_le[32], uint64_t *n_failures, char *err, size_t err_len);
+int zkfhe_bfv_tables_poke_advice(zkfhe_bfv_tables *t, uint32_t column, uint32_t row, const uint8_t value_le[32]);
+
 /* Unsafe seeded test SRS (the reference's gen_srs is an unsafe seeded setup as well, README.md:34): s derived
  * from the seed, g[i] = s^i G, g_lagrange[i] = L_i(s) G, both computed on the GPU and kept as MSM bases. */
 typedef struct zkfhe_srs zkfhe_srs;
@@ -190,13 +218,17 @@ typedef struct zkfhe_bfv_pk zkfhe_bfv_pk;
 int zkfhe_bfv_keygen(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const zkfhe_bfv_params *params,
                      const zkfhe_bfv_config *config, zkfhe_bfv_pk **out);
 int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk);
+/* A key keeps one prover workspace per context that proved against it (0.3 GB at k = 13, several GB at k = 19) until the
+ * key is destroyed.  Call this before zkfhe_ctx_destroy when the key outlives the context. */
+int zkfhe_bfv_pk_release_ctx(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk);
 /* 32-byte LE vk digest; counts of fixed / sigma commitments; the commitments as canonical affine (x||y, 64 B each) */
 int zkfhe_bfv_pk_info(const zkfhe_bfv_pk *pk, uint8_t vk_digest[32], uint32_t *n_fixed, uint32_t *n_sigma);
 int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t *sigma_out);
 int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count);
 
-/* Serialised verifying key: magic "ZKFHEVK1", 7 x u32 configuration, u32 n_fixed, u32 n_sigma, 32-byte vk digest, then
- * the fixed and sigma commitments as canonical affine x||y (64 B each).  What `keygen` writes to data/<name>.vk. */
+/* Serialised verifying key: magic "ZKFHEVK2", 8 x u32 configuration (k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows,
+ * lookup_bits, transcript), u32 n_fixed, u32 n_sigma, 32-byte vk digest, then the fixed and sigma commitments as canonical
+ * affine x||y (64 B each).  What `keygen` writes to data/<name>.vk. */
 int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, size_t *len);
 /* Parity hook for the GPU witness generator: the phase-1 gate-context cell stream of examples/bfv.rs:171-301 (1 231 992 cells at
  * the reference's parameters) as produced on the device, canonical 32-byte little-endian values, for a caller-chosen challenge
@@ -220,9 +252,15 @@ int zkfhe_bfv_verify(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *inst
 int zkfhe_bfv_verify_g2(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof, size_t proof_len,
                         const uint8_t g2[128], const uint8_t s_g2[128], int *accepted, char *err, size_t err_len);
 
-/* prove (README.md:42-44): witness generation + create_proof.  seed: 32 bytes for the blinding stream.
+/* prove (README.md:42-44): witness generation + create_proof.
+ * seed: 32 bytes; every blinding scalar of the proof is derived from it (Blake2b(seed || counter)).  ZERO KNOWLEDGE RESTS
+ * ON THE SEED: it must be fresh, secret randomness for every proof (the reference draws StdRng::from_entropy()); a known
+ * or reused seed makes the blinding rows predictable and the openings then leak the witness (u, e0, e1, m).  A fixed
+ * seed is only for reproducible tests.
  * proof_out must hold proof_cap bytes; *proof_len receives the length.  instances_out (may be NULL): canonical
- * 32-byte LE scalars, *n_instances in/out.  timings_ms (may be NULL): [witness, commit, quotient, open, total]. */
+ * 32-byte LE scalars; *n_instances is its capacity on entry and the instance count on return -- if the capacity is too
+ * small the call fails with ZKFHE_EINVAL and *n_instances holds the required count.
+ * timings_ms (may be NULL): [witness, commit, quotient, open, total]. */
 int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk, const char *input_json,
                     const uint8_t seed[32], uint8_t *proof_out, size_t proof_cap, size_t *proof_len,
                     uint8_t *instances_out, size_t *n_instances, float *timings_ms);

@@ -13,7 +13,11 @@ Deliberate, documented choices (mirrored exactly by zk-fhe_amd/host):
   * constraint system = halo2-base RangeConfig (gate columns per phase, 8-bit lookup columns, one constants
     column) + axiom-eth RlcConfig (challenge gamma after phase 0) + one instance column;
     `unusable_rows` of configs/bfv.json is kept, so blinding_factors = unusable_rows - 3.
-  * transcript: halo2's Blake2b transcript ("Halo2-Transcript"), not snark-verifier's Poseidon.
+  * transcript: snark-verifier's `PoseidonTranscript<NativeLoader>` (oracle/poseidon_ref.py; what the reference's
+    `gen_snark_shplonk` / `verify` use, examples/bfv.rs:311) by default; halo2's Blake2b transcript
+    ("Halo2-Transcript") stays selectable (`Config(transcript="blake2b")`).
+  * multi-open: halo2 `ProverSHPLONK` / `VerifierSHPLONK` (query order of `create_proof`, rotation sets by
+    `construct_intermediate_sets`, final quotient normalised by the first set's difference polynomial).
   * blinding stream: Blake2b-512(person "zkfhe-rng", seed || counter) reduced mod r, fixed draw order.
   * extended-domain coset generator g = 7; sigma cycles ordered by (column, row).
 Heavy vector math goes through the C oracle (oracle/oracle.c); orchestration is Python.
@@ -26,6 +30,7 @@ from . import binding as orc
 from . import pairing_ref as PR
 from . import pyref
 from .circuit_ref import place_stream
+from .poseidon_ref import PoseidonTranscript
 
 R = pyref.R
 Q = pyref.Q
@@ -57,7 +62,8 @@ def from_bytes_wide(b):
 
 class Rng:
     def __init__(self, seed):
-        self.seed = bytes(seed).ljust(32, b"\0")[:32]
+        seed = bytes(seed)   # same rule as zk_fhe_amd.seed32: pad up to 32 bytes, hash anything longer
+        self.seed = seed.ljust(32, b"\0") if len(seed) <= 32 else hashlib.blake2b(seed, digest_size=32, person=b"zkfhe-seed").digest()
         self.ctr = 0
 
     def next(self):
@@ -97,7 +103,9 @@ def point_decompress(b):
     return (x, y)
 
 
-class Transcript:
+class Blake2bTranscript:
+    """halo2_proofs `Blake2bWrite` / `Blake2bRead` with `Challenge255`"""
+
     def __init__(self, proof=None):
         self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
         self.out = bytearray()
@@ -120,12 +128,14 @@ class Transcript:
         self.out += (s % R).to_bytes(32, "little")
 
     def read_point(self):
+        assert self.pos + 32 <= len(self.inp), "proof too short"
         P = point_decompress(self.inp[self.pos:self.pos + 32])
         self.pos += 32
         self.common_point(P)
         return P
 
     def read_scalar(self):
+        assert self.pos + 32 <= len(self.inp), "proof too short"
         s = int.from_bytes(self.inp[self.pos:self.pos + 32], "little")
         assert s < R
         self.pos += 32
@@ -137,10 +147,16 @@ class Transcript:
         return from_bytes_wide(self.h.copy().digest())
 
 
+TRANSCRIPTS = {"poseidon": PoseidonTranscript, "blake2b": Blake2bTranscript}
+TRANSCRIPT_ID = {"poseidon": 0, "blake2b": 1}
+
+
 # ----------------------------------------------------------------------------------------- config
 class Config:
-    def __init__(self, k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits=8):
+    def __init__(self, k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits=8, transcript="poseidon"):
         self.k, self.n = k, 1 << k
+        assert transcript in TRANSCRIPTS
+        self.transcript = transcript
         self.n_gate0, self.n_gate1, self.n_lookup, self.n_rlc = n_gate0, n_gate1, n_lookup, n_rlc
         self.unusable_rows = unusable_rows
         self.bf = unusable_rows - 3          # blinding factors
@@ -173,10 +189,10 @@ class Config:
         return (0, 1, 2)
 
     @staticmethod
-    def from_pinning(cfg_json):
+    def from_pinning(cfg_json, transcript="poseidon"):
         p = cfg_json["params"]
         return Config(p["degree"], p["num_range_advice"][0], p["num_range_advice"][1], p["num_lookup_advice"][1],
-                      p["num_rlc_columns"], p["unusable_rows"], p["lookup_bits"])
+                      p["num_rlc_columns"], p["unusable_rows"], p["lookup_bits"], transcript)
 
 
 # ----------------------------------------------------------------------------------------- SRS
@@ -358,7 +374,7 @@ def keygen(cfg, A, srs):
     pk.fixed_commit = orc.arr_to_points(orc.msm(fixed_l, srs["g_lagrange"]))
     pk.sigma_commit = orc.arr_to_points(orc.msm(sig_l, srs["g_lagrange"]))
     h = hashlib.blake2b(digest_size=64, person=b"zkfhe-vk")
-    for v in (cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits):
+    for v in (cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits, TRANSCRIPT_ID[cfg.transcript]):
         h.update(int(v).to_bytes(4, "little"))
     for P in pk.fixed_commit + pk.sigma_commit:
         x, y = (0, 0) if P is None else P
@@ -402,31 +418,58 @@ def rot(vec_ext_or_lag, r, step):
     return np.roll(vec_ext_or_lag, -r * step, axis=0)
 
 
-class Opening:
-    """bookkeeping of every polynomial opened in SHPLONK: (coeff array or None for verifier, commitment, rotations, evals)"""
-
-    def __init__(self):
-        self.items = []
-
-    def add(self, poly, commit, rots, evals=None):
-        self.items.append([poly, commit, tuple(rots), evals])
-
-
 def rotation_point(cfg, x, w, r):
     e = cfg.u if r == "last" else r
     return x * pow(w, e, R) % R
 
 
-def shplonk_sets(items):
-    order = []
-    sets = {}
-    for it in items:
-        key = it[2]
-        if key not in sets:
-            sets[key] = []
-            order.append(key)
-        sets[key].append(it)
-    return [(key, sets[key]) for key in order]
+def open_queries(cfg):
+    """The prover / verifier query list of halo2 `create_proof` / `verify_proof`, in order, as (polynomial key, rotation):
+    advice queries, permutation products, lookups, fixed queries, the permutation's sigma polynomials, then the vanishing
+    argument's h(X) and random polynomial (halo2_proofs plonk/prover.rs "let queries = ...")."""
+    q = []
+    for c in range(cfg.n_advice):
+        for r in cfg.advice_rotations(c):
+            q.append((("advice", c), r))
+    # permutation::prover::Evaluated::open: every set at x and w x, then w^last x for all but the last set, in reverse
+    for j in range(cfg.n_chunks):
+        q.append((("pz", j), 0))
+        q.append((("pz", j), 1))
+    for j in reversed(range(cfg.n_chunks - 1)):
+        q.append((("pz", j), "last"))
+    # lookup::prover::Evaluated::open: product(x), input(x), table(x), input(w^-1 x), product(w x)
+    for i in range(cfg.n_lookup):
+        q += [(("lz", i), 0), (("la", i), 0), (("ls", i), 0), (("la", i), -1), (("lz", i), 1)]
+    for c in range(cfg.n_fixed):
+        q.append((("fixed", c), 0))
+    for c in range(cfg.n_perm):
+        q.append((("sigma", c), 0))
+    q.append((("H",), 0))
+    q.append((("rand",), 0))
+    return q
+
+
+def intermediate_sets(queries, point_of):
+    """halo2 `construct_intermediate_sets` (poly/kzg/multiopen/shplonk.rs): commitments in order of first appearance with
+    their BTreeSet of points; distinct point sets in order of first appearance, each with its commitments in order.
+    Returns ([(sorted points, [(key, [rotation for each point])])], sorted super point set)."""
+    super_pts = set()
+    com_order, com_pts = [], {}
+    for key, r in queries:
+        p = point_of(r)
+        super_pts.add(p)
+        if key not in com_pts:
+            com_pts[key] = {}
+            com_order.append(key)
+        com_pts[key][p] = r
+    sets, index = [], {}
+    for key in com_order:
+        pts = tuple(sorted(com_pts[key]))   # Fr's Ord compares canonical integer values
+        if pts not in index:
+            index[pts] = len(sets)
+            sets.append((list(pts), []))
+        sets[index[pts]][1].append((key, [com_pts[key][p] for p in pts]))
+    return sets, sorted(super_pts)
 
 
 def lagrange_interp_eval(points, values, at):
@@ -504,7 +547,7 @@ def prove(cfg, pk, srs, circuit, seed, trace=None):
     n, k, u, bf = cfg.n, cfg.k, cfg.u, cfg.bf
     w = pk.omega
     rng = Rng(seed)
-    tr = Transcript()
+    tr = TRANSCRIPTS[cfg.transcript]()
     gl, gm = srs["g_lagrange"], srs["g"]
 
     def commit_l(cols):
@@ -656,67 +699,49 @@ def prove(cfg, pk, srs, circuit, seed, trace=None):
         tr.write_point(P)
     x = tr.squeeze()
     note("x", x)
-    # ---- evaluations
-    Mx = M(x)
-    op = Opening()
+    # ---- evaluations (write order of create_proof: advice, fixed, random poly, sigma, permutation products, lookups)
+    polys, commits, evs = {}, {}, {}
 
     def evals_of(coeff, rots):
         xs = Ms([rotation_point(cfg, x, w, r) for r in rots])
         return I(orc.fr_horner_batch(np.repeat(coeff[None], len(rots), axis=0), xs))
+
+    def register(key, poly, commit, rots, write=True):
+        polys[key], commits[key] = poly, commit
+        for r, e in zip(rots, evals_of(poly, rots)):
+            evs[(key, r)] = e
+            if write:
+                tr.write_scalar(e)
     for c in range(cfg.n_advice):
-        rots = cfg.advice_rotations(c)
-        ev = evals_of(adv_c[c], rots)
-        for e in ev:
-            tr.write_scalar(e)
-        op.add(adv_c[c], adv_commit[c], rots, ev)
+        register(("advice", c), adv_c[c], adv_commit[c], cfg.advice_rotations(c))
     for c in range(cfg.n_fixed):
-        ev = evals_of(pk.fixed_coeff[c], (0,))
-        tr.write_scalar(ev[0])
-        op.add(pk.fixed_coeff[c], pk.fixed_commit[c], (0,), ev)
+        register(("fixed", c), pk.fixed_coeff[c], pk.fixed_commit[c], (0,))
     # combined quotient H(X) = sum x^(n i) h_i(X): its evaluation is implied by the identity (not written)
     xn = pow(x, n, R)
     H = orc.fr_lincomb(h_pieces, Ms([1, xn, xn * xn % R]))
-    op.add(H, "H", (0,), evals_of(H, (0,)))
-    ev = evals_of(rand_coeff, (0,))
-    tr.write_scalar(ev[0])
-    op.add(rand_coeff, rand_commit, (0,), ev)
+    register(("H",), H, "H", (0,), write=False)
+    register(("rand",), rand_coeff, rand_commit, (0,))
     for c in range(cfg.n_perm):
-        ev = evals_of(pk.sigma_coeff[c], (0,))
-        tr.write_scalar(ev[0])
-        op.add(pk.sigma_coeff[c], pk.sigma_commit[c], (0,), ev)
+        register(("sigma", c), pk.sigma_coeff[c], pk.sigma_commit[c], (0,))
     for j in range(cfg.n_chunks):
-        rots = (0, 1, "last") if j != cfg.n_chunks - 1 else (0, 1)
-        ev = evals_of(pz_c[j], rots)
-        for e in ev:
-            tr.write_scalar(e)
-        op.add(pz_c[j], pz_commit[j], rots, ev)
+        register(("pz", j), pz_c[j], pz_commit[j], (0, 1, "last") if j != cfg.n_chunks - 1 else (0, 1))
     for i in range(cfg.n_lookup):
-        for poly, cmt, rots in ((lz_c[i], lz_commit[i], (0, 1)), (la_c[i], la_commit[i], (0, -1)), (ls_c[i], ls_commit[i], (0,))):
-            ev = evals_of(poly, rots)
-            for e in ev:
-                tr.write_scalar(e)
-            op.add(poly, cmt, rots, ev)
-    # ---- SHPLONK
+        register(("lz", i), lz_c[i], lz_commit[i], (0, 1))
+        register(("la", i), la_c[i], la_commit[i], (0, -1))
+        register(("ls", i), ls_c[i], ls_commit[i], (0,))
+    # ---- SHPLONK (halo2 ProverSHPLONK::create_proof)
     yq = tr.squeeze()
-    sets = shplonk_sets(op.items)
-    all_pts = []
-    for key, _ in sets:
-        for r in key:
-            p = rotation_point(cfg, x, w, r)
-            if p not in all_pts:
-                all_pts.append(p)
-    f_polys, r_coeffs, set_pts = [], [], []
-    for key, its in sets:
-        pts = [rotation_point(cfg, x, w, r) for r in key]
-        pw = [pow(yq, i, R) for i in range(len(its))]
-        f = orc.fr_lincomb(np.stack([it[0] for it in its]), Ms(pw))
-        comb = [sum(pw[i] * its[i][3][t] for i in range(len(its))) % R for t in range(len(pts))]
+    sets, super_pts = intermediate_sets(open_queries(cfg), lambda r: rotation_point(cfg, x, w, r))
+    f_polys, r_coeffs = [], []
+    for pts, members in sets:
+        pw = [pow(yq, i, R) for i in range(len(members))]
+        f = orc.fr_lincomb(np.stack([polys[key] for key, _ in members]), Ms(pw))
+        comb = [sum(pw[i] * evs[(key, rots[t])] for i, (key, rots) in enumerate(members)) % R for t in range(len(pts))]
         f_polys.append(f)
         r_coeffs.append(lagrange_interp_coeffs(pts, comb))
-        set_pts.append(pts)
     v = tr.squeeze()
     hq = np.zeros((n, 4), dtype=np.uint64)
-    for j, (f, rc, pts) in enumerate(zip(f_polys, r_coeffs, set_pts)):
+    for j, (f, rc, (pts, _)) in enumerate(zip(f_polys, r_coeffs, sets)):
         num = f.copy()
         num[: len(rc)] = orc.fr_sub(num[: len(rc)], Ms(rc))
         for p in pts:
@@ -726,20 +751,24 @@ def prove(cfg, pk, srs, circuit, seed, trace=None):
     tr.write_point(hq_commit)
     uu = tr.squeeze()
     zt_u = 1
-    for p in all_pts:
+    for p in super_pts:
         zt_u = zt_u * (uu - p) % R
     L = orc.fr_scale(hq, M(-zt_u))
-    for j, (f, rc, pts) in enumerate(zip(f_polys, r_coeffs, set_pts)):
+    z_diff_0 = None
+    for j, (f, rc, (pts, _)) in enumerate(zip(f_polys, r_coeffs, sets)):
         zdiff = 1
-        for p in all_pts:
+        for p in super_pts:
             if p not in pts:
                 zdiff = zdiff * (uu - p) % R
+        if j == 0:
+            z_diff_0 = zdiff
         coef = pow(v, j, R) * zdiff % R
         orc.fr_axpy(L, f, M(coef))
         r_u = sum(c * pow(uu, t, R) for t, c in enumerate(rc)) % R
         L[0] = orc.fr_sub(L[0][None], M(coef * r_u)[None])[0]
     assert I(orc.fr_horner(L, M(uu))) == 0
-    Wq = orc.fr_div_linear(L, M(uu))
+    # normalised by the difference vanishing polynomial of the first set ("z_0_diff_inv")
+    Wq = orc.fr_scale(orc.fr_div_linear(L, M(uu)), M(pow(z_diff_0, -1, R)))
     w_commit = commit_c(Wq[None])[0]
     tr.write_point(w_commit)
     return bytes(tr.out), inst
@@ -753,11 +782,21 @@ class VerifyingKey:
 
 
 def verify(vk, srs, inst, proof):
-    """Returns True iff the proof verifies (one pairing-product check at the end)."""
+    """Returns True iff the proof verifies (one pairing-product check at the end); a proof that does not even decode
+    (point off the curve, non-canonical scalar, wrong length) is rejected, not raised."""
+    try:
+        return _verify(vk, srs, inst, proof)
+    except (AssertionError, ValueError, IndexError):
+        return False
+
+
+def _verify(vk, srs, inst, proof):
     cfg = vk.cfg
     n, k, u = cfg.n, cfg.k, cfg.u
     w = vk.omega
-    tr = Transcript(proof)
+    if len(inst) > cfg.u:   # halo2 verify_proof: Error::InstanceTooLarge when a column exceeds n - (blinding_factors + 1) rows
+        return False
+    tr = TRANSCRIPTS[cfg.transcript](proof)
     tr.common_scalar(vk.vk_digest)
     for v in inst:
         tr.common_scalar(v)
@@ -777,38 +816,26 @@ def verify(vk, srs, inst, proof):
     y = tr.squeeze()
     h_commit = [tr.read_point() for _ in range(3)]
     x = tr.squeeze()
-    op = Opening()
+    commits, evs = {("H",): "H", ("rand",): rand_commit}, {}
     ev = {"advice": {}, "fixed": {}, "sigma": {}, "pz": {}, "lz": {}, "la": {}, "ls": {}}
+
+    def read(kind, idx, commit, rots):
+        commits[(kind, idx)] = commit
+        for r in rots:
+            ev[kind][(idx, r)] = evs[((kind, idx), r)] = tr.read_scalar()
     for c in range(cfg.n_advice):
-        rots = cfg.advice_rotations(c)
-        e = [tr.read_scalar() for _ in rots]
-        for r, val in zip(rots, e):
-            ev["advice"][(c, r)] = val
-        op.add(None, adv_commit[c], rots, e)
+        read("advice", c, adv_commit[c], cfg.advice_rotations(c))
     for c in range(cfg.n_fixed):
-        e = [tr.read_scalar()]
-        ev["fixed"][(c, 0)] = e[0]
-        op.add(None, vk.fixed_commit[c], (0,), e)
-    h_slot = len(op.items)
-    op.add(None, "H", (0,), None)
-    e = [tr.read_scalar()]
-    op.add(None, rand_commit, (0,), e)
+        read("fixed", c, vk.fixed_commit[c], (0,))
+    evs[(("rand",), 0)] = tr.read_scalar()
     for c in range(cfg.n_perm):
-        e = [tr.read_scalar()]
-        ev["sigma"][(c, 0)] = e[0]
-        op.add(None, vk.sigma_commit[c], (0,), e)
+        read("sigma", c, vk.sigma_commit[c], (0,))
     for j in range(cfg.n_chunks):
-        rots = (0, 1, "last") if j != cfg.n_chunks - 1 else (0, 1)
-        e = [tr.read_scalar() for _ in rots]
-        for r, val in zip(rots, e):
-            ev["pz"][(j, r)] = val
-        op.add(None, pz_commit[j], rots, e)
+        read("pz", j, pz_commit[j], (0, 1, "last") if j != cfg.n_chunks - 1 else (0, 1))
     for i in range(cfg.n_lookup):
-        for kind, cmt, rots in (("lz", lz_commit[i], (0, 1)), ("la", la_commit[i], (0, -1)), ("ls", ls_commit[i], (0,))):
-            e = [tr.read_scalar() for _ in rots]
-            for r, val in zip(rots, e):
-                ev[kind][(i, r)] = val
-            op.add(None, cmt, rots, e)
+        read("lz", i, lz_commit[i], (0, 1))
+        read("la", i, la_commit[i], (0, -1))
+        read("ls", i, ls_commit[i], (0,))
     # instance evaluation and Lagrange values at x
     xn = pow(x, n, R)
     zh = (xn - 1) % R
@@ -833,27 +860,16 @@ def verify(vk, srs, inst, proof):
     for e in expressions_at(cfg, get, chal, l0, llast, lactive, x, lambda a, b: a * b % R, lambda a, b: (a + b) % R,
                             lambda a, b: (a - b) % R, lambda a, s: a * s % R, lambda a, s: (a + s) % R, 1):
         acc = (acc * y + e) % R
-    h_eval = acc * pow(zh, -1, R) % R
-    op.items[h_slot][3] = [h_eval]
-    # ---- SHPLONK
+    evs[(("H",), 0)] = acc * pow(zh, -1, R) % R
+    # ---- SHPLONK (halo2 VerifierSHPLONK::verify_proof)
     yq = tr.squeeze()
     v = tr.squeeze()
-    hq_commit = tr.read_point()
+    h1 = tr.read_point()
     uu = tr.squeeze()
-    w_commit = tr.read_point()
+    h2 = tr.read_point()
     assert tr.pos == len(proof), "trailing bytes in proof"
-    sets = shplonk_sets(op.items)
-    all_pts = []
-    for key, _ in sets:
-        for r in key:
-            p = rotation_point(cfg, x, w, r)
-            if p not in all_pts:
-                all_pts.append(p)
-    zt_u = 1
-    for p in all_pts:
-        zt_u = zt_u * (uu - p) % R
+    sets, super_pts = intermediate_sets(open_queries(cfg), lambda r: rotation_point(cfg, x, w, r))
     scal, pts_list = [], []
-    e_total = 0
 
     def add_term(P, s):
         if P == "H":
@@ -863,26 +879,34 @@ def verify(vk, srs, inst, proof):
         else:
             pts_list.append(P)
             scal.append(s % R)
-    for j, (key, its) in enumerate(sets):
-        pts = [rotation_point(cfg, x, w, r) for r in key]
-        zdiff = 1
-        for p in all_pts:
+    r_outer = 0
+    z_0 = z_0_diff_inv = None
+    for j, (pts, members) in enumerate(sets):
+        z_diff = 1
+        for p in super_pts:
             if p not in pts:
-                zdiff = zdiff * (uu - p) % R
-        coef = pow(v, j, R) * zdiff % R
-        comb = [0] * len(pts)
-        for i, it in enumerate(its):
+                z_diff = z_diff * (uu - p) % R
+        if j == 0:
+            z_0 = 1
+            for p in pts:
+                z_0 = z_0 * (uu - p) % R
+            z_0_diff_inv = pow(z_diff, -1, R)
+            z_diff = 1
+        else:
+            z_diff = z_diff * z_0_diff_inv % R
+        coef = pow(v, j, R) * z_diff % R
+        r_inner = 0
+        for i, (key, rots) in enumerate(members):
             pw = pow(yq, i, R)
-            add_term(it[1], coef * pw % R)
-            for t in range(len(pts)):
-                comb[t] = (comb[t] + pw * it[3][t]) % R
-        e_total = (e_total + coef * lagrange_interp_eval(pts, comb, uu)) % R
-    add_term(pyref.G1_GEN, -e_total)
-    add_term(hq_commit, -zt_u)
-    add_term(w_commit, uu)
+            add_term(commits[key], coef * pw % R)
+            r_inner = (r_inner + pw * lagrange_interp_eval(pts, [evs[(key, r)] for r in rots], uu)) % R
+        r_outer = (r_outer + coef * r_inner) % R
+    add_term(pyref.G1_GEN, -r_outer)
+    add_term(h1, -z_0)
+    add_term(h2, uu)
     F = orc.arr_to_points(orc.msm(Ms(scal)[None], orc.points_to_arr(pts_list)))[0]
-    # e(F + u W', G2) = e(W', s G2)   <=>   e(F + u W', G2) * e(-W', s G2) = 1
-    return PR.pairing_product_is_one([(F, PR.G2_GEN), (pyref.g1_neg(w_commit), srs["s_g2"])])
+    # e(h2, s G2) = e(F, G2)   <=>   e(F, G2) * e(-h2, s G2) = 1
+    return PR.pairing_product_is_one([(F, PR.G2_GEN), (pyref.g1_neg(h2), srs["s_g2"])])
 
 
 # ----------------------------------------------------------------------------------------- circuit glue
@@ -909,7 +933,7 @@ def keygen_circuit(cfg, circuit, srs, break_points=None):
     return keygen(cfg, A, srs), A
 
 
-def auto_config(k, unusable_rows, circuit, lookup_bits=8):
+def auto_config(k, unusable_rows, circuit, lookup_bits=8, transcript="poseidon"):
     """halo2-base auto-configuration: column counts that fit the streams (the inverse of KAT 3)."""
     ctx0, pub, st = circuit.phase0()
     ctx_gate, ctx_rlc = circuit.phase1(st, 0)
@@ -918,4 +942,4 @@ def auto_config(k, unusable_rows, circuit, lookup_bits=8):
     n1 = place_stream(len(ctx_gate.advice), ctx_gate.selector, max_rows)[3]
     nr = place_stream(len(ctx_rlc.advice), ctx_rlc.selector, max_rows, rlc=True)[3]
     nl = -(-len(ctx_gate.lookup) // max_rows)
-    return Config(k, n0, n1, nl, nr, unusable_rows, lookup_bits)
+    return Config(k, n0, n1, nl, nr, unusable_rows, lookup_bits, transcript)

@@ -30,18 +30,20 @@ def first_diff(a, b):
     return None if len(a) == len(b) else min(len(a), len(b)) // 32
 
 
-def test_toy_proof_bytes_match_oracle(ctx):
+@pytest.mark.parametrize("transcript", ["poseidon", "blake2b"])
+def test_toy_proof_bytes_match_oracle(ctx, transcript):
+    """Both transcripts: snark-verifier's Poseidon (what the reference proves with, examples/bfv.rs:311) and halo2's Blake2b."""
     import zk_fhe_amd as zk
     prm = C.BfvParams(N=8)
     inp = synth_input(8, prm.Q, prm.T, prm.B, 1)
     circ = H.BfvCircuit(inp, prm)
-    hcfg = H.auto_config(9, 9, circ)
+    hcfg = H.auto_config(9, 9, circ, transcript=transcript)
     srs_o = H.make_srs(9)
     pk_o, _ = H.keygen_circuit(hcfg, circ, srs_o)
     proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, circ, b"seed-1")
     assert H.verify(H.VerifyingKey(pk_o), srs_o, inst_o, proof_o)
     srs = zk.Srs(ctx, 9)
-    zcfg = zk.BfvConfig(9, hcfg.n_gate0, hcfg.n_gate1, hcfg.n_lookup, hcfg.n_rlc, 9)
+    zcfg = zk.BfvConfig(9, hcfg.n_gate0, hcfg.n_gate1, hcfg.n_lookup, hcfg.n_rlc, 9, transcript=transcript)
     pk = zk.BfvProvingKey(ctx, srs, json.dumps(inp), (8, prm.Q, prm.T, prm.B), zcfg)
     info = pk.info()
     assert info["break_points"] == pk_o.break_points
@@ -52,6 +54,8 @@ def test_toy_proof_bytes_match_oracle(ctx):
     assert inst == inst_o
     assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
     assert H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof)
+    ok, why = zk.bfv_verify(pk.export_vk(), inst, proof)
+    assert ok, why
     # a different seed changes the bytes but still verifies; a wrong witness is refused
     proof2, _, _ = pk.prove(json.dumps(inp), b"seed-2")
     assert proof2 != proof and H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof2)
@@ -149,6 +153,16 @@ def test_gpu_gate_stream_60bit_modulus(ctx):
     proof, inst, _ = pk.prove(text, b"q60")
     ok, why = zk.bfv_verify(pk.export_vk(), inst, proof)
     assert ok, why
+    # and the whole proof byte for byte against the oracle prover: the 130-bit columns go through the same blinding draw
+    # order, commitments, quotient and openings as the 29-bit ones
+    hcfg = H.Config(k, n0, n1, nl, nr, 109)
+    srs_o = H.make_srs(k)
+    circ = H.BfvCircuit(inp, prm)
+    pk_o, _ = H.keygen_circuit(hcfg, circ, srs_o)
+    assert pk.info()["vk_digest"] == pk_o.vk_digest
+    proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, circ, b"q60")
+    assert inst == inst_o
+    assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
     pk.destroy()
     srs.destroy()
 
@@ -400,12 +414,19 @@ def _prove_and_verify_large(ctx, N, k, tag):
     vk = H.RawVerifyingKey(hcfg, info["fixed_commit"], info["sigma_commit"], info["vk_digest"])
     srs_v = H.srs_verifier_half(k)
     assert H.verify(vk, srs_v, inst, proof)
-    bad = bytearray(proof)
-    bad[-40] ^= 1
-    try:
-        assert not H.verify(vk, srs_v, inst, bytes(bad))
-    except AssertionError:
-        pass
+    vkb = pk.export_vk()
+    ok, why = zk.bfv_verify(vkb, inst, proof)
+    assert ok, why
+    # negative coverage at this size: a flipped bit in a commitment, an evaluation and both opening points, and a changed
+    # public input -- each rejected by the oracle verifier and by the C++ verifier
+    for pos in (5, len(proof) // 2, len(proof) - 40, len(proof) - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        assert not H.verify(vk, srs_v, inst, bytes(bad)), "oracle verifier accepts a proof tampered at byte %d" % pos
+        assert not zk.bfv_verify(vkb, inst, bytes(bad))[0], "C++ verifier accepts a proof tampered at byte %d" % pos
+    inst2 = list(inst)
+    inst2[N + 2] = (inst2[N + 2] + 1) % H.R
+    assert not H.verify(vk, srs_v, inst2, proof) and not zk.bfv_verify(vkb, inst2, proof)[0]
     pk.destroy()
     srs.destroy()
     return (n0, n1, nl, nr), probe["cells"]

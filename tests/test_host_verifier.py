@@ -8,18 +8,34 @@ from oracle import halo2_ref as H
 from tests.test_proof_oracle import synth_input
 
 
-@pytest.fixture(scope="module")
-def toy():
+def make(transcript):
     prm = C.BfvParams(N=8)
     inp = synth_input(8, prm.Q, prm.T, prm.B, 1)
     circ = H.BfvCircuit(inp, prm)
-    cfg = H.auto_config(9, 9, circ)
+    cfg = H.auto_config(9, 9, circ, transcript=transcript)
     srs = H.make_srs(9)
     pk, _ = H.keygen_circuit(cfg, circ, srs)
     proof, inst = H.prove(cfg, pk, srs, circ, b"seed-v")
     vkb = zk.make_vk_bytes(cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits,
-                           pk.vk_digest, pk.fixed_commit, pk.sigma_commit)
+                           pk.vk_digest, pk.fixed_commit, pk.sigma_commit, transcript)
     return vkb, inst, proof
+
+
+@pytest.fixture(scope="module")
+def toy():
+    return make("poseidon")   # the reference's transcript (snark-verifier PoseidonTranscript)
+
+
+def test_accepts_oracle_proof_blake2b_transcript():
+    vkb, inst, proof = make("blake2b")
+    ok, why = zk.bfv_verify(vkb, inst, proof)
+    assert ok, why
+    bad = bytearray(proof)
+    bad[len(proof) // 2] ^= 1
+    assert not zk.bfv_verify(vkb, inst, bytes(bad))[0]
+    # a proof made for one transcript does not verify under the other: the kind is part of the verifying key
+    vkp, instp, proofp = make("poseidon")
+    assert not zk.bfv_verify(vkb, instp, proofp)[0] and not zk.bfv_verify(vkp, inst, proof)[0]
 
 
 def test_accepts_oracle_proof(toy):
@@ -42,7 +58,15 @@ def test_rejects_tampering(toy):
     assert not zk.bfv_verify(vkb, inst, proof, srs_seed=b"another-srs")[0]
     vk2 = bytearray(vkb)
     vk2[100] ^= 1
-    assert not zk.bfv_verify(bytes(vk2), inst, proof)[0]
+    ok, why = zk.bfv_verify(bytes(vk2), inst, proof)
+    assert not ok and "digest" in why     # the vk digest is recomputed from the file's contents, not trusted
+    # halo2 Error::InstanceTooLarge: L_{i+n}(x) = L_i(x), so a longer instance vector could alias the committed one
+    n, u = 1 << 9, (1 << 9) - (9 - 3) - 1
+    moved = list(inst) + [0] * (n + 4 - len(inst))
+    moved[3], moved[n + 3] = (moved[3] - 5) % H.R, 5
+    ok, why = zk.bfv_verify(vkb, moved, proof)
+    assert not ok and "instances" in why
+    assert len(inst) <= u
 
 
 def test_external_srs_verifier_half(toy):

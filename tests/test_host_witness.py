@@ -94,3 +94,42 @@ def test_auto_config_reproduces_the_pinned_column_counts():
     import pytest
     with pytest.raises(zk.ZkfheError):
         zk.bfv_auto_config(text, prm, 6)
+
+
+def test_mock_checks_every_row(pinned):
+    """`mock` (README.md:18-22, MockProver::assert_satisfied): the reference's bfv.in satisfies every gate, lookup and copy
+    constraint row by row; a single changed cell is caught as the gate / lookup / copy violation it causes."""
+    cfgj, zcfg, hcfg = pinned
+    text = open(os.path.join(G, "bfv.in")).read()
+    zcfg_nobp = zk.BfvConfig(zcfg.k, zcfg.n_gate0, zcfg.n_gate1, zcfg.n_lookup, zcfg.n_rlc, zcfg.unusable_rows, zcfg.lookup_bits)
+    fails, first = zk.bfv_mock(text, PRM, zcfg_nobp, GAMMA)
+    assert fails == 0, first
+    t = zk.bfv_build_tables(text, PRM, zcfg_nobp, GAMMA, keygen_mode=True)
+    fixed = np.array(ints(t["fixed"]), dtype=object).reshape(t["fixed"].shape[0], -1)
+    # a gate output cell (row 3 of the gate enabled at row 0 of the first phase-1 gate column)
+    col = zcfg.n_gate0
+    assert fixed[col][0] == 1
+    old = ints(t["advice"][col][3:4])[0]
+    fails, first = zk.bfv_mock(text, PRM, zcfg_nobp, GAMMA, pokes=[(col, 3, (old + 1) % H.R)])
+    assert fails >= 1 and "gate" in first and "row 0" in first
+    # a looked-up cell pushed out of the 8-bit table: lookup failure (and the copy constraint to its source cell)
+    lcol = zcfg.n_gate0 + zcfg.n_gate1
+    fails, first = zk.bfv_mock(text, PRM, zcfg_nobp, GAMMA, pokes=[(lcol, 5, 256)])
+    assert fails == 2 and "lookup" in first
+    # an RLC accumulator cell
+    rcol = lcol + zcfg.n_lookup
+    old = ints(t["advice"][rcol][2:3])[0]
+    fails, first = zk.bfv_mock(text, PRM, zcfg_nobp, GAMMA, pokes=[(rcol, 2, (old + 5) % H.R)])
+    assert fails >= 1 and "RLC" in first
+    # a public input cell changed consistently nowhere else: the copy constraint to the instance column breaks
+    fails, first = zk.bfv_mock(text, PRM, zcfg_nobp, GAMMA, pokes=[(0, 0, 12345)])
+    assert fails >= 1
+    # a wrong ciphertext coefficient: witness generation goes through, is_equal yields 0 and its copy to the constant 1 fails
+    bad = json.loads(text)
+    bad["c0"][2] = str((int(bad["c0"][2]) + 1) % PRM[1])
+    fails, first = zk.bfv_mock(json.dumps(bad), PRM, zcfg_nobp, GAMMA)
+    assert fails >= 1 and "copy constraint" in first
+    # a coefficient above the modulus never reaches the table: Poly::from_string asserts (src/poly.rs:28)
+    bad["c0"][2] = str(PRM[1] + 1)
+    with pytest.raises(zk.ZkfheError):
+        zk.bfv_mock(json.dumps(bad), PRM, zcfg_nobp, GAMMA)

@@ -61,12 +61,11 @@ def test_toy_prove_verify(toy):
     proof2, _ = H.prove(cfg, pk, srs, circ, b"seed-1")
     assert proof2 == proof, "same seed must give the same bytes"
     assert H.prove(cfg, pk, srs, circ, b"seed-2")[0] != proof
-    bad = bytearray(proof)
-    bad[len(bad) // 2] ^= 1
-    try:
+    for pos in (0, len(proof) // 2, len(proof) - 1):   # a commitment, an evaluation, the last opening point
+        bad = bytearray(proof)
+        bad[pos] ^= 1
         assert not H.verify(vk, srs, inst, bytes(bad))
-    except AssertionError:
-        pass  # decoding a tampered point/scalar may already fail
+    assert not H.verify(vk, srs, inst, proof[:-32]) and not H.verify(vk, srs, inst, proof + bytes(32))
     inst2 = list(inst)
     inst2[3] = (inst2[3] + 1) % H.R
     assert not H.verify(vk, srs, inst2, proof)

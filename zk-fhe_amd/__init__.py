@@ -28,9 +28,12 @@ EXPORTS = [
     "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",
     "zkfhe_bfv_build_tables", "zkfhe_bfv_auto_config", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
-    "zkfhe_bfv_tables_copy_break_points",
-    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_info",
+    "zkfhe_bfv_tables_copy_break_points", "zkfhe_bfv_mock_check", "zkfhe_bfv_tables_poke_advice",
+    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info",
     "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
+    "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
+    "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
+    "zkfhe_poseidon_permute", "zkfhe_poseidon_constants",
     "zkfhe_version",
 ]
 
@@ -331,6 +334,97 @@ def version():
     return load_library().zkfhe_version().decode()
 
 
+def seed32(seed):
+    """The 32-byte blinding seed of zkfhe_bfv_prove from arbitrary bytes: up to 32 bytes are zero-padded, anything longer
+    is hashed (BLAKE2b-256, person "zkfhe-seed") so that long seeds sharing a prefix do not collide."""
+    import hashlib
+    seed = bytes(seed)
+    if len(seed) <= 32:
+        return seed.ljust(32, b"\x00")
+    return hashlib.blake2b(seed, digest_size=32, person=b"zkfhe-seed").digest()
+
+
+# ----------------------------------------------------------------------------- transcript (host only)
+class HostTranscript:
+    """zkfhe_transcript_*: the prover's Fiat-Shamir transcript (Poseidon as in snark-verifier, or halo2's Blake2b)."""
+
+    def __init__(self, kind="poseidon"):
+        self.lib = load_library()
+        self.lib.zkfhe_transcript_destroy.restype = None
+        self.lib.zkfhe_transcript_destroy.argtypes = [ctypes.c_void_p]
+        for f in ("common_scalar", "write_scalar", "common_point", "write_point", "squeeze"):
+            getattr(self.lib, "zkfhe_transcript_" + f).argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        self.lib.zkfhe_transcript_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        self.h = ctypes.c_void_p()
+        rc = self.lib.zkfhe_transcript_create(ctypes.c_uint32(TRANSCRIPT_ID[kind]), ctypes.byref(self.h))
+        if rc != 0:
+            raise ZkfheError("zkfhe_transcript_create failed (%d)" % rc)
+
+    def _call(self, name, payload):
+        rc = getattr(self.lib, "zkfhe_transcript_" + name)(self.h, payload)
+        if rc != 0:
+            raise ZkfheError("zkfhe_transcript_%s refused its argument (%d)" % (name, rc))
+
+    def common_scalar(self, s):
+        self._call("common_scalar", int(s).to_bytes(32, "little"))
+
+    def write_scalar(self, s):
+        self._call("write_scalar", int(s).to_bytes(32, "little"))
+
+    def common_point(self, P):
+        x, y = (0, 0) if P is None else P
+        self._call("common_point", x.to_bytes(32, "little") + y.to_bytes(32, "little"))
+
+    def write_point(self, P):
+        x, y = (0, 0) if P is None else P
+        self._call("write_point", x.to_bytes(32, "little") + y.to_bytes(32, "little"))
+
+    def squeeze(self):
+        buf = ctypes.create_string_buffer(32)
+        self._call("squeeze", buf)
+        return int.from_bytes(buf.raw, "little")
+
+    def stream(self):
+        n = ctypes.c_size_t(0)
+        self.lib.zkfhe_transcript_bytes(self.h, None, 0, ctypes.byref(n))
+        buf = ctypes.create_string_buffer(max(1, n.value))
+        self.lib.zkfhe_transcript_bytes(self.h, buf, n.value, ctypes.byref(n))
+        return buf.raw[:n.value]
+
+    def close(self):
+        if self.h:
+            self.lib.zkfhe_transcript_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def poseidon_permute(state):
+    """one Poseidon permutation (BN254 Fr, t = 3, R_F = 8, R_P = 57) of three python ints, by the host library"""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(b"".join(int(v).to_bytes(32, "little") for v in state), 96)
+    lib.zkfhe_poseidon_permute.argtypes = [ctypes.c_char_p]
+    rc = lib.zkfhe_poseidon_permute(buf)
+    if rc != 0:
+        raise ZkfheError("zkfhe_poseidon_permute refused its argument (%d)" % rc)
+    return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(3)]
+
+
+def poseidon_constants():
+    lib = load_library()
+    rc = ctypes.create_string_buffer(65 * 3 * 32)
+    mds = ctypes.create_string_buffer(9 * 32)
+    lib.zkfhe_poseidon_constants.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lib.zkfhe_poseidon_constants(rc, mds)
+    rcv = [int.from_bytes(rc.raw[32 * i:32 * i + 32], "little") for i in range(195)]
+    mdv = [int.from_bytes(mds.raw[32 * i:32 * i + 32], "little") for i in range(9)]
+    return [rcv[3 * r:3 * r + 3] for r in range(65)], [mdv[3 * i:3 * i + 3] for i in range(3)]
+
+
 # ----------------------------------------------------------------------------- BFV circuit (host layer)
 class BfvParamsC(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("q", ctypes.c_uint64), ("t", ctypes.c_uint64), ("b", ctypes.c_uint64)]
@@ -342,26 +436,32 @@ class BfvConfigC(ctypes.Structure):
                 ("bp_gate0", ctypes.POINTER(ctypes.c_uint32)), ("n_bp_gate0", ctypes.c_uint32),
                 ("bp_gate1", ctypes.POINTER(ctypes.c_uint32)), ("n_bp_gate1", ctypes.c_uint32),
                 ("bp_rlc", ctypes.POINTER(ctypes.c_uint32)), ("n_bp_rlc", ctypes.c_uint32),
-                ("replay", ctypes.c_int)]
+                ("replay", ctypes.c_int), ("transcript", ctypes.c_uint32)]
+
+
+TRANSCRIPT_ID = {"poseidon": 0, "blake2b": 1}
 
 
 class BfvConfig:
     """configs/<name>.json: column counts + break points (the reference's pinning, README.md:38)."""
 
-    def __init__(self, k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits=8, break_points=None):
+    def __init__(self, k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits=8, break_points=None, transcript="poseidon"):
         self.k, self.n_gate0, self.n_gate1, self.n_lookup, self.n_rlc = k, n_gate0, n_gate1, n_lookup, n_rlc
         self.unusable_rows, self.lookup_bits = unusable_rows, lookup_bits
         self.break_points = break_points  # dict gate0/gate1/rlc or None
+        if transcript not in TRANSCRIPT_ID:
+            raise ValueError("transcript must be 'poseidon' (the reference's) or 'blake2b'")
+        self.transcript = transcript
 
     @staticmethod
-    def from_pinning(cfg_json):
+    def from_pinning(cfg_json, transcript="poseidon"):
         p = cfg_json["params"]
         bp = cfg_json.get("break_points")
         bpd = None
         if bp:
             bpd = {"gate0": bp["gate"][0], "gate1": bp["gate"][1], "rlc": bp["rlc"]}
         return BfvConfig(p["degree"], p["num_range_advice"][0], p["num_range_advice"][1], p["num_lookup_advice"][1],
-                         p["num_rlc_columns"], p["unusable_rows"], p["lookup_bits"], bpd)
+                         p["num_rlc_columns"], p["unusable_rows"], p["lookup_bits"], bpd, transcript)
 
     def to_c(self, replay):
         c = BfvConfigC(self.k, self.n_gate0, self.n_gate1, self.n_lookup, self.n_rlc, self.unusable_rows, self.lookup_bits)
@@ -373,6 +473,7 @@ class BfvConfig:
                 setattr(c, "bp_" + name, ctypes.cast(arr, ctypes.POINTER(ctypes.c_uint32)))
                 setattr(c, "n_bp_" + name, len(self.break_points[name]))
         c.replay = 1 if (replay and self.break_points) else 0
+        c.transcript = TRANSCRIPT_ID[self.transcript]
         return c
 
 
@@ -389,7 +490,7 @@ def _bfv_sigs(lib):
     lib.zkfhe_bfv_tables_copy_break_points.argtypes = [vp, ci, vp]
 
 
-def bfv_auto_config(input_json_text, params, k, unusable_rows=109, lookup_bits=8):
+def bfv_auto_config(input_json_text, params, k, unusable_rows=109, lookup_bits=8, transcript="poseidon"):
     """zkfhe_bfv_auto_config: the BfvConfig (column counts) the circuit needs at 2^k rows; host only."""
     lib = load_library()
     lib.zkfhe_bfv_auto_config.argtypes = [ctypes.c_char_p, ctypes.POINTER(BfvParamsC), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
@@ -401,7 +502,7 @@ def bfv_auto_config(input_json_text, params, k, unusable_rows=109, lookup_bits=8
     rc = lib.zkfhe_bfv_auto_config(text, ctypes.byref(prm), k, unusable_rows, lookup_bits, counts, err, 256)
     if rc != 0:
         raise ZkfheError("zkfhe_bfv_auto_config failed (%d): %s" % (rc, err.value.decode()))
-    return BfvConfig(k, counts[0], counts[1], counts[2], counts[3], unusable_rows, lookup_bits)
+    return BfvConfig(k, counts[0], counts[1], counts[2], counts[3], unusable_rows, lookup_bits, transcript=transcript)
 
 
 def bfv_build_tables(input_json_text, params, config, gamma, keygen_mode, replay=False):
@@ -442,6 +543,36 @@ def bfv_build_tables(input_json_text, params, config, gamma, keygen_mode, replay
     out["break_points"] = bps
     lib.zkfhe_bfv_tables_free(h)
     return out
+
+
+def bfv_mock(input_json_text, params, config, gamma=7, pokes=()):
+    """`mock` (README.md:18-22): build the table (keygen mode: values, fixed columns, copy constraints) and check every
+    constraint on every row.  pokes: [(advice column, row, value)] overwritten before the check (negative tests).
+    Returns (number of violated rows / constraints, description of the first)."""
+    lib = load_library()
+    _bfv_sigs(lib)
+    lib.zkfhe_bfv_mock_check.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]
+    lib.zkfhe_bfv_tables_poke_advice.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p]
+    prm = BfvParamsC(*params)
+    cfg = config.to_c(False)
+    h = ctypes.c_void_p()
+    err = ctypes.create_string_buffer(512)
+    g = int(gamma).to_bytes(32, "little")
+    text = input_json_text if isinstance(input_json_text, bytes) else input_json_text.encode()
+    rc = lib.zkfhe_bfv_build_tables(text, ctypes.byref(prm), ctypes.byref(cfg), g, 1, ctypes.byref(h), err, 512)
+    if rc != 0:
+        raise ZkfheError("circuit is not satisfied (%d): %s" % (rc, err.value.decode()))
+    try:
+        for col, row, val in pokes:
+            if lib.zkfhe_bfv_tables_poke_advice(h, col, row, int(val).to_bytes(32, "little")) != 0:
+                raise ZkfheError("zkfhe_bfv_tables_poke_advice refused (%d, %d)" % (col, row))
+        nf = ctypes.c_uint64(0)
+        rc = lib.zkfhe_bfv_mock_check(h, g, ctypes.byref(nf), err, 512)
+        if rc != 0:
+            raise ZkfheError("zkfhe_bfv_mock_check failed (%d): %s" % (rc, err.value.decode()))
+        return int(nf.value), err.value.decode()
+    finally:
+        lib.zkfhe_bfv_tables_free(h)
 
 
 # ----------------------------------------------------------------------------- SRS / keygen / prove (GPU)
@@ -593,20 +724,26 @@ class BfvProvingKey:
         return {"vk_digest": int.from_bytes(d.raw, "little"), "fixed_commit": pts(fx, nf.value), "sigma_commit": pts(sg, ns.value),
                 "break_points": bps}
 
-    def prove(self, input_json_text, seed, ctx=None):
+    def prove(self, input_json_text, seed=None, ctx=None):
         """One proof. `ctx`: the context (stream + workspace) to run on -- several contexts of the same GPU may
-        prove concurrently against this key from different threads (ctypes releases the GIL)."""
+        prove concurrently against this key from different threads (ctypes releases the GIL).
+        seed: the 32-byte blinding seed.  Zero knowledge rests on it being fresh and secret: None draws os.urandom(32);
+        a fixed seed is for reproducible tests.  Shorter seeds are zero-padded, longer ones hashed (seed32())."""
         ctx = ctx or self.ctx
-        seed = bytes(seed).ljust(32, b"\x00")[:32]
+        seed = os.urandom(32) if seed is None else seed32(seed)
         cap = 1 << 18
         buf = ctypes.create_string_buffer(cap)
         plen = ctypes.c_size_t()
         ninst = ctypes.c_size_t(5 * int(self.params[0]) + 8)   # 4 polynomials of N coefficients + cyclo (N + 1) are public
-        ibuf = ctypes.create_string_buffer(32 * ninst.value)
         tm = (ctypes.c_float * 5)()
         text = input_json_text if isinstance(input_json_text, bytes) else input_json_text.encode()
-        ctx._check(ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, text, seed, buf, cap, ctypes.byref(plen),
-                                           ibuf, ctypes.byref(ninst), tm))
+        for _ in range(2):
+            ibuf = ctypes.create_string_buffer(32 * ninst.value)
+            have = ninst.value
+            rc = ctx.lib.zkfhe_bfv_prove(ctx.h, self.srs.h, self.h, text, seed, buf, cap, ctypes.byref(plen), ibuf, ctypes.byref(ninst), tm)
+            if rc == 0 or ninst.value <= have:
+                break      # otherwise: the library reported the instance count it needs -- retry once with that capacity
+        ctx._check(rc)
         return buf.raw[: plen.value], Instances(ibuf.raw[: 32 * ninst.value]), list(tm)
 
     def witness_stream(self, input_json_text, gamma):
@@ -638,10 +775,11 @@ class BfvProvingKey:
             self.h = None
 
 
-def make_vk_bytes(k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits, vk_digest, fixed_commit, sigma_commit):
+def make_vk_bytes(k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits, vk_digest, fixed_commit, sigma_commit, transcript="poseidon"):
     """Serialise a verifying key (same layout as zkfhe_bfv_pk_export_vk) from python values; points are (x, y) or None."""
     import struct
-    out = b"ZKFHEVK1" + struct.pack("<9I", k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits, len(fixed_commit), len(sigma_commit))
+    out = b"ZKFHEVK2" + struct.pack("<10I", k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows, lookup_bits, TRANSCRIPT_ID[transcript],
+                                    len(fixed_commit), len(sigma_commit))
     out += int(vk_digest).to_bytes(32, "little")
     for p in list(fixed_commit) + list(sigma_commit):
         x, y = (0, 0) if p is None else p

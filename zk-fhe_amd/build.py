@@ -43,9 +43,11 @@ def units():
     return u
 
 
-def newest_header():
+def newest_header(host):
+    """csrc/ units depend on csrc/ + include/ headers only; host/ units on every header"""
     t = 0.0
-    for d in (CSRC, os.path.join(HERE, "host"), os.path.join(HERE, "..", "include")):
+    dirs = (CSRC, os.path.join(HERE, "..", "include")) + ((os.path.join(HERE, "host"),) if host else ())
+    for d in dirs:
         for f in os.listdir(d):
             if f.endswith((".cuh", ".hpp", ".h")):
                 t = max(t, os.path.getmtime(os.path.join(d, f)))
@@ -62,11 +64,12 @@ def compile_one(src, obj, extra):
 
 def build(force=False, jobs=None, verbose=True):
     os.makedirs(OUT, exist_ok=True)
-    hdr_t = newest_header()
+    hdr_csrc, hdr_host = newest_header(False), newest_header(True)
     todo = []
     objs = []
     for src, obj, extra in units():
         objs.append(obj)
+        hdr_t = hdr_host if os.path.basename(obj).startswith("host_") else hdr_csrc
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             todo.append((src, obj, extra))
     if todo:

@@ -1,4 +1,5 @@
 // Context, device memory, timing and coefficient-wise Fr kernels of the C ABI (include/zkfhe.h).
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -99,6 +100,8 @@ int zkfhe_ctx_create(int device_id, void *hip_stream, zkfhe_ctx **out) {
     return zk_fail_msg(nullptr, ZKFHE_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   ZK_HIP(nullptr, hipSetDevice(device_id));
   zkfhe_ctx *ctx = new zkfhe_ctx();
+  static std::atomic<uint64_t> next_uid{1};
+  ctx->uid = next_uid.fetch_add(1);
   ctx->device = device_id;
   ctx->num_cu = prop.multiProcessorCount;
   if (hip_stream) {

@@ -18,6 +18,7 @@ struct NttDomain {
 };
 
 struct zkfhe_ctx {
+  uint64_t uid = 0;   // never reused (an address can be): what per-context caches such as the prover workspaces are keyed by
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;

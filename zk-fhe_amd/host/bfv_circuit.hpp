@@ -12,6 +12,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "poly.hpp"
@@ -95,7 +96,10 @@ struct BfvState {
 };
 
 // examples/bfv.rs:63-165
-inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvParams &prm, std::vector<Cell> &make_public) {
+// on_public (optional) is called as soon as the public inputs are complete (examples/bfv.rs:118-122), before the
+// precomputation: the prover starts hashing them into the transcript while the products and divisions below run.
+inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvParams &prm, std::vector<Cell> &make_public,
+                           const std::function<void(const std::vector<Cell> &)> &on_public = nullptr) {
   const size_t N = prm.N;
   const uint64_t Q = prm.Q;
   const bool tr_on = getenv("ZKFHE_TRACE0") != nullptr;
@@ -138,6 +142,7 @@ inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvPar
   st.expected_c0.to_public(make_public);
   st.expected_c1.to_public(make_public);
   st.cyclo.to_public(make_public);
+  if (on_public) on_public(make_public);
   mark("from_poly x9 + to_public");
   // PRECOMPUTATION (examples/bfv.rs:124-150)
   Poly pk0_u_un = pk0_un.mul(u_un);
@@ -249,6 +254,7 @@ struct CircuitConfig {  // configs/<name>.json "params"
   unsigned k = 13;
   unsigned n_gate0 = 3, n_gate1 = 153, n_lookup = 36, n_rlc = 5;
   unsigned unusable_rows = 109, lookup_bits = 8;
+  unsigned transcript = 0;  // TranscriptKind (transcript.hpp): 0 = Poseidon (the reference's), 1 = Blake2b
   std::vector<uint32_t> bp_gate0, bp_gate1, bp_rlc;  // break points (replayed by the prover)
 
   size_t n() const { return (size_t)1 << k; }

@@ -1,8 +1,8 @@
 // `bfv` -- command-line driver with the reference's surface (README.md:18-52; clap `Cli` of halo2-scaffold,
 // examples/bfv.rs:306-312):   bfv --name bfv -k 13 --input bfv/bfv.in {mock|keygen|prove|verify}
 // Files: reads data/<input>, configs/<name>.json (prove); writes configs/<name>.json (keygen), data/<name>.snark (prove).
-// keygen also writes data/<name>.vk; `verify` reads it with the snark on the host CPU.  The proving key is rebuilt in
-// memory by `prove` (an on-disk pk is section 8f work: it is 95 MB of columns that keygen recomputes in < 1 s).
+// keygen also writes data/<name>.vk and data/<name>.pk; `prove` loads the pk, `verify` reads vk + snark on the host CPU.
+// --transcript poseidon|blake2b (keygen; default poseidon = the reference's PoseidonTranscript) is recorded in pk and vk.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +11,8 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <sys/random.h>
 
 #include "../../include/zkfhe.h"
 
@@ -122,6 +124,7 @@ static void write_pinning(const std::string &path, const zkfhe_bfv_config &c, co
 int main(int argc, char **argv) {
   std::string name = "bfv", input, cmd, config_path = "configs", data_path = "data";
   unsigned k = 13;
+  uint32_t transcript = ZKFHE_TRANSCRIPT_POSEIDON;
   zkfhe_bfv_params prm = {1024, 536870909ULL, 7, 19};  // examples/bfv.rs:27-30
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -133,6 +136,15 @@ int main(int argc, char **argv) {
     else if (a == "--data-path" || a == "-d") data_path = next();
     else if (a == "--ring-degree") prm.n = strtoull(next().c_str(), nullptr, 10);
     else if (a == "--modulus") prm.q = strtoull(next().c_str(), nullptr, 10);
+    else if (a == "--transcript") {
+      const std::string t = next();
+      if (t == "poseidon") transcript = ZKFHE_TRANSCRIPT_POSEIDON;
+      else if (t == "blake2b") transcript = ZKFHE_TRANSCRIPT_BLAKE2B;
+      else {
+        fprintf(stderr, "--transcript must be poseidon or blake2b\n");
+        return 2;
+      }
+    }
     else if (a == "mock" || a == "keygen" || a == "prove" || a == "verify") cmd = a;
     else if (a == "--") continue;
     else {
@@ -149,8 +161,10 @@ int main(int argc, char **argv) {
   const std::string pin_path = config_path + "/" + name + ".json";
   Pinning pin;
   const bool have_pin = load_pinning(pin_path, pin);
+  pin.c.transcript = transcript;
   if (cmd == "mock") {
-    // MockProver: the circuit's asserts + gate / copy / lookup consistency of the witness table, on the host
+    // MockProver::run(..).assert_satisfied(): the circuit's own asserts while the witness is generated, then every gate,
+    // lookup and copy constraint on every row of the assigned table
     if (!have_pin) {
       fprintf(stderr, "mock needs %s (run keygen first)\n", pin_path.c_str());
       return 1;
@@ -165,9 +179,15 @@ int main(int argc, char **argv) {
       fprintf(stderr, "circuit is not satisfied: %s\n", err);
       return 1;
     }
-    printf("Mock prover: witness table built (%zu advice columns x %zu rows, %zu copy constraints), all circuit assertions hold\n",
-           zkfhe_bfv_tables_count(t, 0), zkfhe_bfv_tables_count(t, 2), zkfhe_bfv_tables_count(t, 4));
+    uint64_t failures = 0;
+    rc = zkfhe_bfv_mock_check(t, gamma, &failures, err, sizeof(err));
+    const size_t n_adv = zkfhe_bfv_tables_count(t, 0), n_rows = zkfhe_bfv_tables_count(t, 2), n_copies = zkfhe_bfv_tables_count(t, 4);
     zkfhe_bfv_tables_free(t);
+    if (rc || failures) {
+      fprintf(stderr, "Mock prover: circuit is NOT satisfied: %llu violated constraint(s); first: %s\n", (unsigned long long)failures, err);
+      return 1;
+    }
+    printf("Mock prover: %zu advice columns x %zu rows, %zu copy constraints: every gate, lookup and copy constraint holds\n", n_adv, n_rows, n_copies);
     return 0;
   }
   const char *seed = "zkfhe-unsafe-srs";
@@ -221,6 +241,7 @@ int main(int argc, char **argv) {
       }
       c.n_gate0 = counts[0], c.n_gate1 = counts[1], c.n_lookup = counts[2], c.n_rlc = counts[3];
       c.unusable_rows = 109, c.lookup_bits = 8;
+      c.transcript = transcript;
       printf("auto-configured columns: gate %u + %u, lookup %u, rlc %u\n", counts[0], counts[1], counts[2], counts[3]);
     }
     c.replay = 0;
@@ -266,11 +287,11 @@ int main(int argc, char **argv) {
     }
     std::vector<uint8_t> proof(1 << 20), instb((size_t)32 << 20);
     size_t len = 0, ninst = instb.size() / 32;
-    uint8_t seed32[32] = {0};
-    FILE *ur = fopen("/dev/urandom", "rb");
-    if (ur) {
-      if (fread(seed32, 1, 32, ur) != 32) memset(seed32, 1, 32);
-      fclose(ur);
+    // the blinding stream: zero knowledge rests on this seed being fresh and secret, so no fallback if the OS has none
+    uint8_t seed32[32];
+    if (getrandom(seed32, 32, 0) != 32) {
+      fprintf(stderr, "prove: the operating system gave no randomness (getrandom): refusing to prove with a predictable blinding seed\n");
+      return 1;
     }
     float tm[5];
     auto t0 = std::chrono::steady_clock::now();

@@ -3,11 +3,18 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <string>
 
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
+#include "transcript.hpp"
 
 using namespace zkhost;
+
+struct zkfhe_transcript {
+  Transcript tr;
+  explicit zkfhe_transcript(uint32_t kind) : tr(kind) {}
+};
 
 struct zkfhe_bfv_tables {
   CircuitConfig cfg;
@@ -26,6 +33,7 @@ CircuitConfig config_from_c(const zkfhe_bfv_config *c) {
   cfg.n_rlc = c->n_rlc;
   cfg.unusable_rows = c->unusable_rows;
   cfg.lookup_bits = c->lookup_bits;
+  cfg.transcript = c->transcript;
   if (c->bp_gate0) cfg.bp_gate0.assign(c->bp_gate0, c->bp_gate0 + c->n_bp_gate0);
   if (c->bp_gate1) cfg.bp_gate1.assign(c->bp_gate1, c->bp_gate1 + c->n_bp_gate1);
   if (c->bp_rlc) cfg.bp_rlc.assign(c->bp_rlc, c->bp_rlc + c->n_bp_rlc);
@@ -155,6 +163,177 @@ int zkfhe_bfv_tables_copy_copies(const zkfhe_bfv_tables *t, uint64_t *out) {
 int zkfhe_bfv_tables_copy_break_points(const zkfhe_bfv_tables *t, int which, uint32_t *out) {
   const auto &v = which == 0 ? t->t.bp_gate0 : which == 1 ? t->t.bp_gate1 : t->t.bp_rlc;
   memcpy(out, v.data(), v.size() * 4);
+  return ZKFHE_OK;
+}
+
+// ---- MockProver (README.md:18-22: `mock` = halo2 MockProver::run(..).assert_satisfied()): every constraint of the
+// constraint system is evaluated on every row of the assigned table -- the gate a + b*c = d under each gate selector, the
+// RLC gate a*gamma + b = c under each RLC selector, membership of every lookup cell in the table column, and equality of
+// the two cells of every copy constraint (break-point duplicates, constants, lookups, public inputs).
+int zkfhe_bfv_tables_poke_advice(zkfhe_bfv_tables *t, uint32_t column, uint32_t row, const uint8_t value_le[32]) {
+  if (!t || !value_le || column >= t->t.advice.size() || row >= t->cfg.n()) return ZKFHE_EINVAL;
+  U256 v;
+  memcpy(v.l, value_le, 32);
+  if (!(v < fe::MOD)) return ZKFHE_EINVAL;
+  t->t.advice[column][row] = v;
+  return ZKFHE_OK;
+}
+
+int zkfhe_bfv_mock_check(const zkfhe_bfv_tables *t, const uint8_t gamma_le[32], uint64_t *n_failures, char *err, size_t err_len) {
+  if (!t || !gamma_le || !n_failures) return ZKFHE_EINVAL;
+  const CircuitConfig &cfg = t->cfg;
+  if (t->t.fixed.size() != cfg.n_fixed()) {
+    if (err && err_len) snprintf(err, err_len, "tables were not built in keygen mode (no fixed columns / copy constraints)");
+    return ZKFHE_EINVAL;
+  }
+  U256 gamma;
+  memcpy(gamma.l, gamma_le, 32);
+  if (!(gamma < fe::MOD)) return ZKFHE_EINVAL;
+  const size_t n = cfg.n(), usable = cfg.u();
+  uint64_t fails = 0;
+  std::string first;
+  auto fail = [&](const std::string &what) {
+    if (!fails) first = what;
+    ++fails;
+  };
+  auto at = [](const char *kind, size_t col, size_t row) { return std::string(kind) + " column " + std::to_string(col) + ", row " + std::to_string(row); };
+  // gates: q(X) * (a(X) + a(wX) a(w^2 X) - a(w^3 X)) on every usable row (rotations wrap like the polynomial identity does)
+  for (unsigned j = 0; j < cfg.n_gate(); ++j) {
+    const U256 *a = t->t.advice[j];
+    const std::vector<U256> &q = t->t.fixed[j];
+    for (size_t r = 0; r < usable; ++r) {
+      if (q[r].is_zero()) continue;
+      const U256 lhs = fe::add(a[r], fe::mul(a[(r + 1) % n], a[(r + 2) % n]));
+      if (!(fe::mul(q[r], fe::sub(lhs, a[(r + 3) % n])).is_zero())) fail("gate a + b*c = d not satisfied at " + at("gate", j, r));
+    }
+  }
+  for (unsigned j = 0; j < cfg.n_rlc; ++j) {
+    const U256 *a = t->t.advice[cfg.adv_rlc0() + j];
+    const std::vector<U256> &q = t->t.fixed[cfg.fix_qrlc0() + j];
+    for (size_t r = 0; r < usable; ++r) {
+      if (q[r].is_zero()) continue;
+      const U256 lhs = fe::add(fe::mul(a[r], gamma), a[(r + 1) % n]);
+      if (!(fe::mul(q[r], fe::sub(lhs, a[(r + 2) % n])).is_zero())) fail("RLC gate a*gamma + b = c not satisfied at " + at("rlc", j, r));
+    }
+  }
+  // lookups: every usable row of a lookup column holds a value of the table column
+  const uint64_t table_size = (uint64_t)1 << cfg.lookup_bits;
+  for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+    const U256 *a = t->t.advice[cfg.adv_lookup0() + i];
+    for (size_t r = 0; r < usable; ++r)
+      if (a[r].l[1] | a[r].l[2] | a[r].l[3] || a[r].l[0] >= table_size) fail("lookup input not in the table at " + at("lookup", i, r));
+  }
+  // copy constraints (permutation argument)
+  auto value = [&](uint64_t id) -> U256 {
+    const size_t col = id / n, row = id % n;
+    if (col < cfg.n_advice()) return t->t.advice[col][row];
+    if (col == cfg.perm_const()) return t->t.fixed[cfg.fix_const()][row];
+    return row < t->t.instance.size() ? t->t.instance[row] : fe::zero();
+  };
+  for (const auto &cp : t->t.copies)
+    if (!(value(cp.first) == value(cp.second)))
+      fail("copy constraint violated between " + at("permutation", cp.first / n, cp.first % n) + " and " + at("permutation", cp.second / n, cp.second % n));
+  *n_failures = fails;
+  if (err && err_len) snprintf(err, err_len, "%s", first.c_str());
+  return ZKFHE_OK;
+}
+
+// ---- Fiat-Shamir transcript and the Poseidon instance behind it (transcript.hpp, poseidon.hpp)
+namespace {
+bool load_fr(const uint8_t b[32], U256 &v) {
+  memcpy(v.l, b, 32);
+  return v < fe::MOD;
+}
+bool load_point(const uint8_t b[64], AffinePoint &p) {
+  static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+  memcpy(p.x.l, b, 32);
+  memcpy(p.y.l, b + 32, 32);
+  return p.x < QMOD && p.y < QMOD;
+}
+}  // namespace
+
+int zkfhe_transcript_create(uint32_t kind, zkfhe_transcript **out) {
+  if (!out || (kind != ZKFHE_TRANSCRIPT_POSEIDON && kind != ZKFHE_TRANSCRIPT_BLAKE2B)) return ZKFHE_EINVAL;
+  try {
+    *out = new zkfhe_transcript(kind);
+    return ZKFHE_OK;
+  } catch (const std::exception &) {
+    return ZKFHE_ENOMEM;
+  }
+}
+void zkfhe_transcript_destroy(zkfhe_transcript *t) { delete t; }
+
+#define ZK_TR_GUARD(body)              \
+  try {                                \
+    body;                              \
+    return ZKFHE_OK;                   \
+  } catch (const std::exception &) {   \
+    return ZKFHE_EINVAL;               \
+  }
+
+int zkfhe_transcript_common_scalar(zkfhe_transcript *t, const uint8_t s_le[32]) {
+  U256 v;
+  if (!t || !s_le || !load_fr(s_le, v)) return ZKFHE_EINVAL;
+  ZK_TR_GUARD(t->tr.common_scalar(v));
+}
+int zkfhe_transcript_write_scalar(zkfhe_transcript *t, const uint8_t s_le[32]) {
+  U256 v;
+  if (!t || !s_le || !load_fr(s_le, v)) return ZKFHE_EINVAL;
+  ZK_TR_GUARD(t->tr.write_scalar(v));
+}
+int zkfhe_transcript_common_point(zkfhe_transcript *t, const uint8_t xy_le[64]) {
+  AffinePoint p;
+  if (!t || !xy_le || !load_point(xy_le, p)) return ZKFHE_EINVAL;
+  ZK_TR_GUARD(t->tr.common_point(p));   // Poseidon refuses the identity (snark-verifier does)
+}
+int zkfhe_transcript_write_point(zkfhe_transcript *t, const uint8_t xy_le[64]) {
+  AffinePoint p;
+  if (!t || !xy_le || !load_point(xy_le, p)) return ZKFHE_EINVAL;
+  ZK_TR_GUARD(t->tr.write_point(p));
+}
+int zkfhe_transcript_squeeze(zkfhe_transcript *t, uint8_t challenge_le[32]) {
+  if (!t || !challenge_le) return ZKFHE_EINVAL;
+  ZK_TR_GUARD({
+    const U256 c = t->tr.squeeze();
+    memcpy(challenge_le, c.l, 32);
+  });
+}
+int zkfhe_transcript_bytes(const zkfhe_transcript *t, uint8_t *out, size_t cap, size_t *len) {
+  if (!t || !len) return ZKFHE_EINVAL;
+  *len = t->tr.out.size();
+  if (!out) return ZKFHE_OK;
+  if (cap < t->tr.out.size()) return ZKFHE_EINVAL;
+  memcpy(out, t->tr.out.data(), t->tr.out.size());
+  return ZKFHE_OK;
+}
+
+int zkfhe_poseidon_permute(uint8_t state_le[96]) {
+  if (!state_le) return ZKFHE_EINVAL;
+  pos::F s[3];
+  for (int i = 0; i < 3; ++i) {
+    U256 v;
+    if (!load_fr(state_le + 32 * i, v)) return ZKFHE_EINVAL;
+    s[i] = pos::from_canon(v);
+  }
+  pos::permute(s);
+  for (int i = 0; i < 3; ++i) {
+    const U256 v = pos::to_canon(s[i]);
+    memcpy(state_le + 32 * i, v.l, 32);
+  }
+  return ZKFHE_OK;
+}
+int zkfhe_poseidon_constants(uint8_t *rc_le, uint8_t *mds_le) {
+  const pos::Constants &c = pos::constants();
+  for (int r = 0; r < pos::ROUNDS && rc_le; ++r)
+    for (int i = 0; i < pos::T; ++i) {
+      const U256 v = pos::to_canon(c.rc[r][i]);
+      memcpy(rc_le + 32 * (r * pos::T + i), v.l, 32);
+    }
+  for (int i = 0; i < pos::T && mds_le; ++i)
+    for (int j = 0; j < pos::T; ++j) {
+      const U256 v = pos::to_canon(c.mds[i][j]);
+      memcpy(mds_le + 32 * (i * pos::T + j), v.l, 32);
+    }
   return ZKFHE_OK;
 }
 

@@ -19,7 +19,9 @@
 #include "bfv_circuit.hpp"
 #include "gpu_witness.cuh"
 #include "prover_kernels.cuh"
+#include "shplonk.hpp"
 #include "transcript.hpp"
+#include "vk.hpp"
 
 using namespace zkhost;
 using zk::Fr;
@@ -172,7 +174,7 @@ struct zkfhe_bfv_pk {
   DevBuf lookup_src, inv_slots, place_start, place_len;   // device: u32 lists
   // per-context prover workspaces: one proof at a time per zkfhe_ctx, any number of contexts (streams)
   // may prove concurrently against the same key (everything above is read-only after keygen)
-  std::map<zkfhe_ctx *, Workspace *> workspaces;
+  std::map<uint64_t, Workspace *> workspaces;   // keyed by zkfhe_ctx::uid (never reused), not by address
   std::mutex mu;
 };
 
@@ -347,9 +349,18 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   return ZKFHE_OK;
 }
 
+void free_workspace(Workspace *ws) {
+  (void)hipSetDevice(ws->all_l.device);
+  for (DevBuf *b : ws->all()) b->release();
+  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_wblind, (void *)ws->host_pts, (void *)ws->ring})
+    if (h) (void)hipHostFree(h);
+  if (ws->ev_pts) (void)hipEventDestroy(ws->ev_pts);
+  delete ws;
+}
+
 int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
   std::lock_guard<std::mutex> lock(pk->mu);
-  auto it = pk->workspaces.find(ctx);
+  auto it = pk->workspaces.find(ctx->uid);
   if (it == pk->workspaces.end()) {
     Workspace *ws = new Workspace();
     int rc = alloc_workspace(ctx, pk->cfg, ws, pk->ext_rows);
@@ -358,8 +369,9 @@ int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out) {
       delete ws;
       return rc;
     }
-    it = pk->workspaces.emplace(ctx, ws).first;
+    it = pk->workspaces.emplace(ctx->uid, ws).first;
   }
+  if (it->second->all_l.device != ctx->device) return zk_fail_msg(ctx, ZKFHE_EINVAL, "prover workspace belongs to another device");
   *out = it->second;
   return ZKFHE_OK;
 }
@@ -410,23 +422,7 @@ int build_resident_tables(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws) {
   return ZKFHE_OK;
 }
 
-U256 vk_digest_of(const zkfhe_bfv_pk *pk) {
-  const CircuitConfig &cfg = pk->cfg;
-  Blake2b h(64, "zkfhe-vk");
-  const uint32_t hdr[7] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits};
-  h.update(hdr, sizeof(hdr));
-  for (const auto &p : pk->fixed_commit) {
-    h.update(p.x.l, 32);
-    h.update(p.y.l, 32);
-  }
-  for (const auto &p : pk->sigma_commit) {
-    h.update(p.x.l, 32);
-    h.update(p.y.l, 32);
-  }
-  uint8_t d[64];
-  h.digest(d);
-  return from_bytes_wide(d);
-}
+U256 vk_digest_of(const zkfhe_bfv_pk *pk) { return vk_digest(pk->cfg, pk->fixed_commit, pk->sigma_commit); }
 
 int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, const BfvParams &prm, CircuitConfig cfg, bool replay,
                 zkfhe_bfv_pk **out) {
@@ -844,7 +840,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Trace trace;
   PreRng rng(seed, (size_t)cfg.n_advice() * (n - u) + 2 * (size_t)cfg.n_lookup * (n - u) +
                         ((size_t)cfg.n_chunks() + cfg.n_lookup) * (n - u - 1) + n);
-  Transcript tr;
+  Transcript tr(cfg.transcript);
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
   Workspace *ws;
@@ -866,15 +862,18 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   trace.mark("parse_json");
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
   std::vector<Cell> make_public;
-  BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
+  instances.clear();
+  tr.common_scalar(pk->vk_digest);
+  // the 5121 public inputs are hashed on a helper thread, started as soon as they are known: it runs beside the phase-0
+  // precomputation, upload and commitment (a Poseidon sponge is one sequential chain of 2561 permutations here)
+  BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public, [&](const std::vector<Cell> &pub) {
+    for (const Cell &c : pub) instances.push_back(c.value);
+    tr.common_scalars_async(instances);
+  });
   trace.mark("bfv_phase0");
   Assigner as(cfg, false, ws->host_adv);
   as.place(ctx0, true);
   trace.mark("place phase 0");
-  instances.clear();
-  for (const Cell &c : make_public) instances.push_back(c.value);
-  tr.common_scalar(pk->vk_digest);
-  for (const U256 &v : instances) tr.common_scalar(v);
   auto blind_and_upload = [&](unsigned c_lo, unsigned c_hi) -> int {
     for (unsigned c = c_lo; c < c_hi; ++c) {
       U256 *col = as.t.advice[c];
@@ -1313,38 +1312,22 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     for (size_t i = 0; i < items.size(); ++i)
       for (int r = 0; r < items[i].n_rot; ++r) items[i].ev[r] = ev[i * 4 + r];
   }
+  const OpenLayout layout(cfg);
+  if (items.size() != layout.count || idx_H != layout.H) return zk_fail_msg(ctx, ZKFHE_EINVAL, "opening layout mismatch");
   for (size_t i = 0; i < items.size(); ++i) {
     if (i == idx_H) continue;  // implied by the identity, not written
     for (int r = 0; r < items[i].n_rot; ++r) tr.write_scalar(items[i].ev[r]);
   }
-  // ------------------------------------------------------------ SHPLONK (Lagrange form; commitments are basis independent)
+  // ------------------------------------------------------------ SHPLONK (halo2 ProverSHPLONK; Lagrange form, commitments are basis independent)
   const Fr yq = mont(tr.squeeze());
-  struct SetInfo {
-    std::vector<int> rots;
-    std::vector<size_t> members;
-  };
-  std::vector<SetInfo> sets;
-  for (size_t i = 0; i < items.size(); ++i) {
-    std::vector<int> key(items[i].rot, items[i].rot + items[i].n_rot);
-    size_t s = 0;
-    for (; s < sets.size(); ++s)
-      if (sets[s].rots == key) break;
-    if (s == sets.size()) sets.push_back(SetInfo{key, {}});
-    sets[s].members.push_back(i);
-  }
-  const size_t ns = sets.size();
   std::vector<int> all_rots;
-  for (const auto &s : sets)
-    for (int r : s.rots)
-      if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
+  const std::vector<OpenSet> sets = intermediate_sets(layout, open_queries(cfg, layout), all_rots);
+  const size_t ns = sets.size();
   Fr *F = ws->misc.fr() + 12 * n;  // [ns][n]
   if (ns > 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many rotation sets");
   std::vector<zkp::ShSet> shsets(ns);
   {
-    size_t max_m = 0;
-    for (const auto &s : sets) max_m = std::max(max_m, s.members.size());
     // pointer and scalar tables live behind the eval-job table, one slice per set (no host round trip between the sets)
-    (void)max_m;
     char *const ptab = (char *)ws->jobs.p + items.size() * sizeof(zkp::EvalJob);
     char *const stab = ptab + ((items.size() * sizeof(void *) + 31) / 32) * 32;
     size_t tab_off = 0;
@@ -1358,7 +1341,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       for (size_t m = 0; m < mem.size(); ++m) {
         ptrs[m] = items[mem[m]].lagr;
         pw[m] = cur;
-        for (size_t t = 0; t < np; ++t) comb[t] = comb[t] + cur * mont(items[mem[m]].ev[t]);
+        for (size_t t = 0; t < np; ++t) comb[t] = comb[t] + cur * mont(items[mem[m]].ev[layout.eval_slot(mem[m], sets[j].rots[t])]);
         cur = cur * yq;
       }
       struct { void *p; } pd, sd;
@@ -1428,17 +1411,22 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   {
     Fr ztu = Fr::one();
     for (int r : all_rots) ztu = ztu * (uu - pts_rot[r]);
+    // halo2 normalises the final quotient by the difference vanishing polynomial of the first set ("z_0_diff_inv"): every
+    // coefficient below carries that factor, so the kernel is unchanged
+    Fr z0_diff_inv = Fr::one();
     for (size_t j = 0; j < ns; ++j) {
       Fr zdiff = Fr::one();
       for (int r : all_rots)
         if (std::find(sets[j].rots.begin(), sets[j].rots.end(), r) == sets[j].rots.end()) zdiff = zdiff * (uu - pts_rot[r]);
-      shsets[j].coef = shsets[j].vj * zdiff;
+      if (j == 0) z0_diff_inv = fr_inv(zdiff);
+      shsets[j].coef = shsets[j].vj * zdiff * z0_diff_inv;
       Fr ru = shsets[j].rc[3];
       ru = ru * uu + shsets[j].rc[2];
       ru = ru * uu + shsets[j].rc[1];
       ru = ru * uu + shsets[j].rc[0];
       shsets[j].r_u = ru;
     }
+    ztu = ztu * z0_diff_inv;
     CK(up(ctx, ws, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
     zkp::k_sh_den<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(dom->fwd, uu, n, dinv);
     ZK_LAUNCH_CHECK(ctx);
@@ -1483,22 +1471,27 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
   DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow,
                     &pk->lookup_src, &pk->inv_slots, &pk->place_start, &pk->place_len};
   for (DevBuf *b : bufs) b->release();
-  for (auto &kv : pk->workspaces) {
-    for (DevBuf *b : kv.second->all()) b->release();
-    if (kv.second->host_adv) (void)hipHostFree(kv.second->host_adv);
-    if (kv.second->host_blind) (void)hipHostFree(kv.second->host_blind);
-    if (kv.second->host_pool) (void)hipHostFree(kv.second->host_pool);
-    if (kv.second->host_wblind) (void)hipHostFree(kv.second->host_wblind);
-    if (kv.second->host_pts) (void)hipHostFree(kv.second->host_pts);
-    if (kv.second->ring) (void)hipHostFree(kv.second->ring);
-    if (kv.second->ev_pts) (void)hipEventDestroy(kv.second->ev_pts);
-    delete kv.second;
-  }
+  for (auto &kv : pk->workspaces) free_workspace(kv.second);
   delete pk;
   return ZKFHE_OK;
 }
 
-// ---- proving key on disk ("ZKFHEPK1"): configuration, break points, the structure lists of the GPU witness generator,
+// Frees the prover workspace (0.3 GB at k = 13, several GB at k = 19) this key holds for `ctx`.  Call it before destroying a
+// context that proved against a key that lives on; zkfhe_bfv_pk_destroy frees whatever is left.
+int zkfhe_bfv_pk_release_ctx(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, pk != nullptr);
+  zkfhe_sync(ctx);
+  std::lock_guard<std::mutex> lock(pk->mu);
+  auto it = pk->workspaces.find(ctx->uid);
+  if (it != pk->workspaces.end()) {
+    free_workspace(it->second);
+    pk->workspaces.erase(it);
+  }
+  return ZKFHE_OK;
+}
+
+// ---- proving key on disk ("ZKFHEPK2"): configuration, break points, the structure lists of the GPU witness generator,
 // commitments and the fixed / sigma columns in Lagrange form (device limbs as they are).  The extended-coset tables are
 // rebuilt on load.  The key is bound to the SRS it was generated with (its commitments are stored, not recomputed).
 namespace {
@@ -1567,8 +1560,8 @@ int zkfhe_bfv_pk_save(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, const char *path) 
   FILE *f = fopen(path, "wb");
   if (!f) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("cannot write ") + path);
   FileW w{f};
-  w.raw("ZKFHEPK1", 8);
-  const uint32_t hdr[7] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits};
+  w.raw("ZKFHEPK2", 8);
+  const uint32_t hdr[8] = {cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits, cfg.transcript};
   w.raw(hdr, sizeof(hdr));
   w.vec32(cfg.bp_gate0), w.vec32(cfg.bp_gate1), w.vec32(cfg.bp_rlc);
   w.u64(pk->prm.N), w.u64(pk->prm.Q), w.u64(pk->prm.T), w.u64(pk->prm.B);
@@ -1593,9 +1586,9 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
   FileR r{f};
   char magic[8];
   r.raw(magic, 8);
-  if (!r.ok || memcmp(magic, "ZKFHEPK1", 8) != 0) {
+  if (!r.ok || memcmp(magic, "ZKFHEPK2", 8) != 0) {
     fclose(f);
-    return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + " is not a ZKFHEPK1 proving key");
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + " is not a ZKFHEPK2 proving key");
   }
   zkfhe_bfv_pk *pk = new zkfhe_bfv_pk();
   pk->ext_rows = getenv("ZKFHE_CHECK_QUOTIENT") ? 4 : 3;
@@ -1605,11 +1598,12 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
     return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + ": " + why);
   };
   try {
-    uint32_t hdr[7];
+    uint32_t hdr[8];
     r.raw(hdr, sizeof(hdr));
     CircuitConfig &cfg = pk->cfg;
     cfg.k = hdr[0], cfg.n_gate0 = hdr[1], cfg.n_gate1 = hdr[2], cfg.n_lookup = hdr[3], cfg.n_rlc = hdr[4], cfg.unusable_rows = hdr[5], cfg.lookup_bits = hdr[6];
-    if (!r.ok || cfg.k < 3 || cfg.k > 20 || cfg.n_gate0 + cfg.n_gate1 > 4096 || cfg.n_lookup > 4096 || cfg.n_rlc > 4096) return fail("bad header");
+    cfg.transcript = hdr[7];
+    if (!r.ok || cfg.transcript > TR_BLAKE2B || cfg.k < 3 || cfg.k > 20 || cfg.n_gate0 + cfg.n_gate1 > 4096 || cfg.n_lookup > 4096 || cfg.n_rlc > 4096) return fail("bad header");
     if (cfg.k != srs->k) return fail("proving key and SRS have different k");
     cfg.bp_gate0 = r.vec32(1 << 16), cfg.bp_gate1 = r.vec32(1 << 16), cfg.bp_rlc = r.vec32(1 << 16);
     pk->prm.N = r.u64(), pk->prm.Q = r.u64(), pk->prm.T = r.u64(), pk->prm.B = r.u64();
@@ -1690,15 +1684,15 @@ int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t
 int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, size_t *len) {
   if (!pk || !len) return ZKFHE_EINVAL;
   const size_t nf = pk->fixed_commit.size(), ns = pk->sigma_commit.size();
-  const size_t need = 8 + 36 + 32 + 64 * (nf + ns);
+  const size_t need = 8 + 40 + 32 + 64 * (nf + ns);
   *len = need;
   if (!out || cap < need) return out ? ZKFHE_EINVAL : ZKFHE_OK;
-  memcpy(out, "ZKFHEVK1", 8);
-  const uint32_t hdr[9] = {pk->cfg.k, pk->cfg.n_gate0, pk->cfg.n_gate1, pk->cfg.n_lookup, pk->cfg.n_rlc, pk->cfg.unusable_rows,
-                           pk->cfg.lookup_bits, (uint32_t)nf, (uint32_t)ns};
-  memcpy(out + 8, hdr, 36);
-  memcpy(out + 44, pk->vk_digest.l, 32);
-  uint8_t *p = out + 76;
+  memcpy(out, "ZKFHEVK2", 8);
+  const uint32_t hdr[10] = {pk->cfg.k, pk->cfg.n_gate0, pk->cfg.n_gate1, pk->cfg.n_lookup, pk->cfg.n_rlc, pk->cfg.unusable_rows,
+                            pk->cfg.lookup_bits, pk->cfg.transcript, (uint32_t)nf, (uint32_t)ns};
+  memcpy(out + 8, hdr, 40);
+  memcpy(out + 48, pk->vk_digest.l, 32);
+  uint8_t *p = out + 80;
   for (const auto &c : pk->fixed_commit) {
     memcpy(p, c.x.l, 32);
     memcpy(p + 32, c.y.l, 32);
@@ -1733,8 +1727,12 @@ int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk
     memcpy(proof_out, proof.data(), proof.size());
     *proof_len = proof.size();
     if (n_instances) {
-      if (instances_out && *n_instances >= inst.size()) memcpy(instances_out, inst.data(), inst.size() * 32);
+      const size_t have = *n_instances;
       *n_instances = inst.size();
+      if (instances_out) {
+        if (have < inst.size()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "instance buffer too small (the required count is returned in *n_instances)");
+        memcpy(instances_out, inst.data(), inst.size() * 32);
+      }
     }
     return ZKFHE_OK;
   } catch (const std::exception &e) {

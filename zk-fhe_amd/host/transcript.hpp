@@ -1,16 +1,18 @@
 // Blake2b (RFC 7693) and the Fiat-Shamir transcript of the prover.
 //
-// The reference's scaffold uses snark-verifier's PoseidonTranscript; this build uses halo2_proofs' own
-// `Blake2bWrite/Blake2bRead` transcript shape instead (personalisation "Halo2-Transcript", prefix bytes
-// 0 = challenge, 1 = point, 2 = scalar) -- a documented deviation: byte parity with the Rust
-// reference is impossible anyway.  Mirrors oracle/halo2_ref.py `Transcript` / `Rng`.
+// The reference's scaffold proves and verifies with snark-verifier's PoseidonTranscript (examples/bfv.rs:311 ->
+// gen_snark_shplonk); that is the default here (poseidon.hpp).  halo2_proofs' own Blake2b transcript stays selectable
+// (zkfhe_bfv_config.transcript).  Mirrors oracle/halo2_ref.py `TRANSCRIPTS` / `Rng`.
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fe.hpp"
+#include "poseidon.hpp"
 
 namespace zkhost {
 
@@ -148,12 +150,36 @@ struct AffinePoint {  // canonical coordinates; identity = (0,0)
   bool is_identity() const { return x.is_zero() && y.is_zero(); }
 };
 
+enum TranscriptKind : uint32_t {
+  TR_POSEIDON = 0,  // snark-verifier PoseidonTranscript<NativeLoader> -- what the reference's prove / verify use
+  TR_BLAKE2B = 1,   // halo2_proofs Blake2bWrite / Blake2bRead with Challenge255
+};
+
+// Fiat-Shamir transcript, writer and reader side (the reader feeds decoded values through common_*).
+//  * Poseidon: a scalar is absorbed as itself, a point as its affine coordinates mapped Fq -> Fr (value mod r); the
+//    identity cannot be absorbed (snark-verifier: "Cannot write points at infinity to the transcript").
+//  * Blake2b: personalisation "Halo2-Transcript", prefix bytes 0 = challenge, 1 = point, 2 = scalar; a challenge is the
+//    64-byte digest of a copy of the state, reduced mod r.
+// The byte stream is the same for both: 32-byte compressed points (x little-endian, bit 7 of byte 31 = parity of y) and
+// 32-byte little-endian scalars.
 class Transcript {
  public:
-  Transcript() : h(64, "Halo2-Transcript") {}
+  explicit Transcript(uint32_t kind_) : kind(kind_), h(64, "Halo2-Transcript") {
+    if (kind != TR_POSEIDON && kind != TR_BLAKE2B) throw std::runtime_error("unknown transcript kind");
+  }
+  ~Transcript() { join(); }
+  Transcript(const Transcript &) = delete;
+  Transcript &operator=(const Transcript &) = delete;
   std::vector<uint8_t> out;
 
   void common_point(const AffinePoint &p) {
+    join();
+    if (kind == TR_POSEIDON) {
+      if (p.is_identity()) throw std::runtime_error("Cannot write points at infinity to the transcript");
+      sp.update(fq_to_fr(p.x));
+      sp.update(fq_to_fr(p.y));
+      return;
+    }
     uint8_t b[65];
     b[0] = 1;
     memcpy(b + 1, p.x.l, 32);
@@ -161,21 +187,21 @@ class Transcript {
     h.update(b, 65);
   }
   void common_scalar(const U256 &s) {
-    uint8_t b[33];
-    b[0] = 2;
-    memcpy(b + 1, s.l, 32);
-    h.update(b, 33);
+    join();
+    absorb_scalar(s);
+  }
+  // Absorbs a long run of scalars (the public inputs) on a helper thread; every later call waits for it first.
+  void common_scalars_async(std::vector<U256> v) {
+    join();
+    pending = std::move(v);
+    worker = std::thread([this] {
+      for (const U256 &s : pending) absorb_scalar(s);
+    });
   }
   void write_point(const AffinePoint &p) {
     common_point(p);
     uint8_t b[32];
-    if (p.is_identity()) {
-      memset(b, 0, 32);
-      b[31] |= 0x40;
-    } else {
-      memcpy(b, p.x.l, 32);
-      if (p.y.l[0] & 1) b[31] |= 0x80;
-    }
+    compress(p, b);
     out.insert(out.end(), b, b + 32);
   }
   void write_scalar(const U256 &s) {
@@ -184,15 +210,48 @@ class Transcript {
     out.insert(out.end(), b, b + 32);
   }
   U256 squeeze() {
+    join();
+    if (kind == TR_POSEIDON) return sp.squeeze();
     const uint8_t z = 0;
     h.update(&z, 1);
     uint8_t d[64];
     h.digest(d);
     return from_bytes_wide(d);
   }
+  static void compress(const AffinePoint &p, uint8_t b[32]) {
+    if (p.is_identity()) {
+      memset(b, 0, 32);
+      b[31] |= 0x40;
+    } else {
+      memcpy(b, p.x.l, 32);
+      if (p.y.l[0] & 1) b[31] |= 0x80;
+    }
+  }
+  size_t poseidon_permutations() const { return sp.n_perm; }
 
  private:
+  uint32_t kind;
   Blake2b h;
+  pos::Sponge sp;
+  std::thread worker;
+  std::vector<U256> pending;
+  void join() {
+    if (worker.joinable()) worker.join();
+  }
+  void absorb_scalar(const U256 &s) {
+    if (kind == TR_POSEIDON) {
+      sp.update(s);
+      return;
+    }
+    uint8_t b[33];
+    b[0] = 2;
+    memcpy(b + 1, s.l, 32);
+    h.update(b, 33);
+  }
+  static U256 fq_to_fr(U256 v) {  // fe_to_fe::<Fq, Fr>: the integer value mod r (q < 2 r)
+    if (!(v < fe::MOD)) fe::sub_raw(v, v, fe::MOD);
+    return v;
+  }
 };
 
 }  // namespace zkhost

@@ -12,7 +12,9 @@
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
 #include "pairing.hpp"
+#include "shplonk.hpp"
 #include "transcript.hpp"
+#include "vk.hpp"
 
 using namespace zkhost;
 using zk::Fr;
@@ -39,21 +41,9 @@ Fr finv(const Fr &a) { return zk::fp_inv<zk::FrP>(a); }
 struct Reader {
   const uint8_t *p;
   size_t len, pos = 0;
-  Blake2b h;
-  Reader(const uint8_t *d, size_t l) : p(d), len(l), h(64, "Halo2-Transcript") {}
-  void common_point(const AffinePoint &a) {
-    uint8_t b[65];
-    b[0] = 1;
-    memcpy(b + 1, a.x.l, 32);
-    memcpy(b + 33, a.y.l, 32);
-    h.update(b, 65);
-  }
-  void common_scalar(const U256 &s) {
-    uint8_t b[33];
-    b[0] = 2;
-    memcpy(b + 1, s.l, 32);
-    h.update(b, 33);
-  }
+  Transcript tr;
+  Reader(uint32_t kind, const uint8_t *d, size_t l) : p(d), len(l), tr(kind) {}
+  void common_scalar(const U256 &s) { tr.common_scalar(s); }
   AffinePoint read_point() {
     if (pos + 32 > len) throw std::runtime_error("proof truncated");
     uint8_t b[32];
@@ -61,11 +51,15 @@ struct Reader {
     pos += 32;
     AffinePoint a;
     if (b[31] & 0x40) {
+      // the identity has exactly one encoding (halo2curves rejects anything else)
+      for (int i = 0; i < 31; ++i)
+        if (b[i]) throw std::runtime_error("non-canonical encoding of the identity");
+      if (b[31] != 0x40) throw std::runtime_error("non-canonical encoding of the identity");
       a.x = fe::zero();
       a.y = fe::zero();
     } else {
       const unsigned sign = b[31] >> 7;
-      b[31] &= 0x3f;
+      b[31] &= 0x7f;
       memcpy(a.x.l, b, 32);
       static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
       if (!(a.x < QMOD)) throw std::runtime_error("point x not reduced");
@@ -84,7 +78,7 @@ struct Reader {
       yc = zk::fp_from_mont<zk::FqP>(y);
       memcpy(a.y.l, yc.l, 32);
     }
-    common_point(a);
+    tr.common_point(a);   // Poseidon: refuses the identity, as snark-verifier does
     return a;
   }
   U256 read_scalar() {
@@ -93,16 +87,10 @@ struct Reader {
     memcpy(s.l, p + pos, 32);
     pos += 32;
     if (!(s < fe::MOD)) throw std::runtime_error("scalar not reduced");
-    common_scalar(s);
+    tr.common_scalar(s);
     return s;
   }
-  U256 squeeze() {
-    const uint8_t z = 0;
-    h.update(&z, 1);
-    uint8_t d[64];
-    h.digest(d);
-    return from_bytes_wide(d);
-  }
+  U256 squeeze() { return tr.squeeze(); }
 };
 
 // host MSM over G1 (affine canonical in, XYZZ accumulate): small Pippenger, c = 8
@@ -147,12 +135,12 @@ struct Vk {
   U256 digest;
 };
 
-const char VK_MAGIC[8] = {'Z', 'K', 'F', 'H', 'E', 'V', 'K', '1'};
+const char VK_MAGIC[8] = {'Z', 'K', 'F', 'H', 'E', 'V', 'K', '2'};
 
 Vk parse_vk(const uint8_t *d, size_t len) {
-  if (len < 8 + 9 * 4 + 32 || memcmp(d, VK_MAGIC, 8)) throw std::runtime_error("not a zkfhe vk file");
-  uint32_t h[9];
-  memcpy(h, d + 8, 36);
+  if (len < 8 + 10 * 4 + 32 || memcmp(d, VK_MAGIC, 8)) throw std::runtime_error("not a zkfhe vk file (ZKFHEVK2)");
+  uint32_t h[10];
+  memcpy(h, d + 8, 40);
   Vk vk;
   vk.cfg.k = h[0];
   vk.cfg.n_gate0 = h[1];
@@ -161,20 +149,32 @@ Vk parse_vk(const uint8_t *d, size_t len) {
   vk.cfg.n_rlc = h[4];
   vk.cfg.unusable_rows = h[5];
   vk.cfg.lookup_bits = h[6];
-  const size_t nf = h[7], ns = h[8];
-  if (len != 8 + 36 + 32 + 64 * (nf + ns)) throw std::runtime_error("vk file has the wrong size");
+  vk.cfg.transcript = h[7];
+  // bounds first: n(), u() and the root of unity are only defined for these (2-adicity of Fr is 28)
+  if (vk.cfg.k < 3 || vk.cfg.k > 28) throw std::runtime_error("vk: k out of range");
+  if (vk.cfg.unusable_rows < 4 || vk.cfg.unusable_rows >= vk.cfg.n()) throw std::runtime_error("vk: unusable_rows out of range");
+  if (vk.cfg.n_gate0 > 4096 || vk.cfg.n_gate1 > 4096 || vk.cfg.n_lookup > 4096 || vk.cfg.n_rlc > 4096 || vk.cfg.n_gate() == 0)
+    throw std::runtime_error("vk: column counts out of range");
+  if (vk.cfg.lookup_bits == 0 || vk.cfg.lookup_bits > 20 || ((size_t)1 << vk.cfg.lookup_bits) > vk.cfg.max_rows()) throw std::runtime_error("vk: lookup_bits out of range");
+  if (vk.cfg.transcript > TR_BLAKE2B) throw std::runtime_error("vk: unknown transcript kind");
+  const size_t nf = h[8], ns = h[9];
   if (nf != vk.cfg.n_fixed() || ns != vk.cfg.n_perm()) throw std::runtime_error("vk commitment counts do not match its configuration");
-  memcpy(vk.digest.l, d + 44, 32);
-  const uint8_t *p = d + 76;
+  if (len != 8 + 40 + 32 + 64 * (nf + ns)) throw std::runtime_error("vk file has the wrong size");
+  memcpy(vk.digest.l, d + 48, 32);
+  const uint8_t *p = d + 80;
+  static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
   auto rd = [&](std::vector<AffinePoint> &v, size_t cnt) {
     v.resize(cnt);
     for (size_t i = 0; i < cnt; ++i, p += 64) {
       memcpy(v[i].x.l, p, 32);
       memcpy(v[i].y.l, p + 32, 32);
+      if (!(v[i].x < QMOD) || !(v[i].y < QMOD)) throw std::runtime_error("vk: commitment coordinate not reduced");
     }
   };
   rd(vk.fixed_commit, nf);
   rd(vk.sigma_commit, ns);
+  // the digest is what the transcript starts from: it must be the digest OF this configuration and these commitments
+  if (!(vk_digest(vk.cfg, vk.fixed_commit, vk.sigma_commit) == vk.digest)) throw std::runtime_error("vk digest does not match its contents");
   return vk;
 }
 
@@ -205,7 +205,9 @@ bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *pro
   const CircuitConfig &cfg = vk.cfg;
   const size_t n = cfg.n(), u = cfg.u();
   const Fr w = zk_fr_root_of_unity((int)cfg.k);
-  Reader tr(proof, proof_len);
+  // halo2 verify_proof: Error::InstanceTooLarge.  Without it L_{i+n} = L_i would let value move between instance i and i+n.
+  if (inst.size() > u) throw std::runtime_error("more instances than usable rows");
+  Reader tr(cfg.transcript, proof, proof_len);
   tr.common_scalar(vk.digest);
   for (const U256 &v : inst) tr.common_scalar(v);
   std::vector<AffinePoint> adv_commit;
@@ -348,49 +350,43 @@ bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *pro
     fold(lactive * ((ap - sp) * (ap - apm)));
   }
   items[h_slot].evals[0] = acc * finv(zh);
-  // ---- SHPLONK
+  // ---- SHPLONK (halo2 VerifierSHPLONK::verify_proof)
   const Fr yq = M(tr.squeeze()), v = M(tr.squeeze());
-  const AffinePoint hq_commit = tr.read_point();
+  const AffinePoint h1 = tr.read_point();
   const Fr uu = M(tr.squeeze());
-  const AffinePoint w_commit = tr.read_point();
+  const AffinePoint h2 = tr.read_point();
   if (tr.pos != proof_len) throw std::runtime_error("trailing bytes in proof");
-  Fr pts_rot[6];
-  pts_rot[0] = x;
-  pts_rot[1] = x * w;
-  pts_rot[2] = pts_rot[1] * w;
-  pts_rot[3] = pts_rot[2] * w;
-  pts_rot[4] = x * fpow(w, u);
-  pts_rot[5] = x * finv(w);
-  std::vector<std::vector<int>> set_rots;
-  std::vector<std::vector<size_t>> set_members;
-  for (size_t i = 0; i < items.size(); ++i) {
-    size_t s = 0;
-    for (; s < set_rots.size(); ++s)
-      if (set_rots[s] == items[i].rots) break;
-    if (s == set_rots.size()) {
-      set_rots.push_back(items[i].rots);
-      set_members.push_back({});
-    }
-    set_members[s].push_back(i);
-  }
+  Fr pts_rot[N_ROT_IDS];
+  pts_rot[ROT_0] = x;
+  pts_rot[ROT_1] = x * w;
+  pts_rot[ROT_2] = pts_rot[1] * w;
+  pts_rot[ROT_3] = pts_rot[2] * w;
+  pts_rot[ROT_LAST] = x * fpow(w, u);
+  pts_rot[ROT_PREV] = x * finv(w);
+  const OpenLayout layout(cfg);
+  if (items.size() != layout.count || h_slot != layout.H) throw std::logic_error("opening layout mismatch");
   std::vector<int> all_rots;
-  for (const auto &sr : set_rots)
-    for (int r : sr)
-      if (std::find(all_rots.begin(), all_rots.end(), r) == all_rots.end()) all_rots.push_back(r);
-  Fr ztu = Fr::one();
-  for (int r : all_rots) ztu = ztu * (uu - pts_rot[r]);
+  const std::vector<OpenSet> sets = intermediate_sets(layout, open_queries(cfg, layout), all_rots);
   std::vector<Fr> scal;
   std::vector<AffinePoint> pts;
-  Fr e_total = Fr::zero(), vj = Fr::one();
-  for (size_t j = 0; j < set_rots.size(); ++j) {
-    const auto &rots = set_rots[j];
+  Fr r_outer = Fr::zero(), vj = Fr::one(), z_0 = Fr::one(), z_0_diff_inv = Fr::one();
+  for (size_t j = 0; j < sets.size(); ++j) {
+    const auto &rots = sets[j].rots;
     Fr zdiff = Fr::one();
     for (int r : all_rots)
       if (std::find(rots.begin(), rots.end(), r) == rots.end()) zdiff = zdiff * (uu - pts_rot[r]);
+    if (j == 0) {
+      // normalised by the first set: its own vanishing polynomial multiplies h1, everything else is divided by z_diff_0
+      for (int r : rots) z_0 = z_0 * (uu - pts_rot[r]);
+      z_0_diff_inv = finv(zdiff);
+      zdiff = Fr::one();
+    } else {
+      zdiff = zdiff * z_0_diff_inv;
+    }
     const Fr coef = vj * zdiff;
     std::vector<Fr> comb(rots.size(), Fr::zero());
     Fr pw = Fr::one();
-    for (size_t mi : set_members[j]) {
+    for (size_t mi : sets[j].members) {
       const Item &it = items[mi];
       if (it.kind == 1) {
         Fr xp = Fr::one();
@@ -403,7 +399,7 @@ bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *pro
         pts.push_back(it.commit);
         scal.push_back(coef * pw);
       }
-      for (size_t t = 0; t < rots.size(); ++t) comb[t] = comb[t] + pw * it.evals[t];
+      for (size_t t = 0; t < rots.size(); ++t) comb[t] = comb[t] + pw * it.evals[layout.eval_slot(mi, rots[t])];
       pw = pw * yq;
     }
     // r_j(u) by Lagrange interpolation through (points of the set, comb)
@@ -417,20 +413,21 @@ bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *pro
         }
       ru = ru + comb[a] * num * finv(den);
     }
-    e_total = e_total + coef * ru;
+    r_outer = r_outer + coef * ru;
     vj = vj * v;
   }
   AffinePoint gen;
   gen.x = fe::from_u64(1);
   gen.y = fe::from_u64(2);
   pts.push_back(gen);
-  scal.push_back(Fr::zero() - e_total);
-  pts.push_back(hq_commit);
-  scal.push_back(Fr::zero() - ztu);
-  pts.push_back(w_commit);
+  scal.push_back(Fr::zero() - r_outer);
+  pts.push_back(h1);
+  scal.push_back(Fr::zero() - z_0);
+  pts.push_back(h2);
   scal.push_back(uu);
+  const AffinePoint &w_commit = h2;
   const AffinePoint F = msm_host(scal, pts);
-  // e(F + u W', G2) = e(W', s G2)
+  // e(h2, s G2) = e(F, G2)
   const pairing::Pt<pairing::Fq2> &g2 = srs.g2, &sg2 = srs.sg2;
   pairing::G1 Fp{F.x, F.y}, nW;
   nW.x = w_commit.x;
@@ -449,7 +446,7 @@ extern "C" {
 
 int zkfhe_bfv_verify(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof, size_t proof_len,
                      const uint8_t *srs_seed, size_t seed_len, int *accepted, char *err, size_t err_len) {
-  if (!vk_bytes || !proof || !accepted || (!instances && n_instances)) return ZKFHE_EINVAL;
+  if (!vk_bytes || !proof || !accepted || (!instances && n_instances) || (!srs_seed && seed_len)) return ZKFHE_EINVAL;
   *accepted = 0;
   try {
     const Vk vk = parse_vk(vk_bytes, vk_len);
