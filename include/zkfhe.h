@@ -70,7 +70,7 @@ int zkfhe_timer_start(zkfhe_ctx *ctx);
 int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms);   /* waits for the stop event */
 
 /* Per-kernel profiling with HIP events on the context's stream.  While enabled, zkfhe_msm_batch and
- * zkfhe_ntt_batch bracket their dominant kernel (which 0: k_msm_accumulate, 1: k_ntt_tile) with an event pair
+ * zkfhe_ntt_batch bracket their dominant kernel (which 0: k_msm_accumulate, 1: k_ntt_tile, 2: k_msm_direct) with an event pair
  * and wait for it, accumulating duration, launch count and ALGORITHMIC bytes (MSM: 96 B per term, NTT: 64 B per
  * point -- BASELINE.md).  Meant for a separate, untimed pass (it serialises the stream). */
 int zkfhe_prof_enable(zkfhe_ctx *ctx, int on);

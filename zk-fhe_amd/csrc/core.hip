@@ -133,6 +133,7 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
   }
   for (int i = 0; i < 4; ++i)
     if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+  if (ctx->tickets) hipFree(ctx->tickets);
   if (ctx->wait_ev) hipEventDestroy(ctx->wait_ev);
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
@@ -225,7 +226,7 @@ int zkfhe_prof_enable(zkfhe_ctx *ctx, int on) {
 }
 int zkfhe_prof_reset(zkfhe_ctx *ctx) {
   ZK_ENTER(ctx);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 3; ++i) {
     ctx->prof_ms[i] = ctx->prof_bytes[i] = ctx->prof_ops[i] = 0;
     ctx->prof_launches[i] = 0;
   }
@@ -233,7 +234,7 @@ int zkfhe_prof_reset(zkfhe_ctx *ctx) {
 }
 int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launches, double *algorithmic_bytes) {
   ZK_ENTER(ctx);
-  ZK_ARG(ctx, which >= 0 && which < 2);
+  ZK_ARG(ctx, which >= 0 && which < 3);
   if (total_ms) *total_ms = ctx->prof_ms[which];
   if (launches) *launches = ctx->prof_launches[which];
   if (algorithmic_bytes) *algorithmic_bytes = ctx->prof_bytes[which];
@@ -242,7 +243,7 @@ int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launc
 
 int zkfhe_prof_read_ops(zkfhe_ctx *ctx, int which, double *ops) {
   ZK_ENTER(ctx);
-  ZK_ARG(ctx, which >= 0 && which < 2 && ops != nullptr);
+  ZK_ARG(ctx, which >= 0 && which < 3 && ops != nullptr);
   *ops = ctx->prof_ops[which];
   return ZKFHE_OK;
 }

@@ -31,13 +31,14 @@ struct zkfhe_ctx {
   bool prof_on = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: host waits sleep instead of spinning (zk_wait)
-  double prof_ms[2] = {0, 0}, prof_bytes[2] = {0, 0}, prof_ops[2] = {0, 0};
-  uint64_t prof_launches[2] = {0, 0};
+  double prof_ms[3] = {0, 0, 0}, prof_bytes[3] = {0, 0, 0}, prof_ops[3] = {0, 0, 0};   // [2] = k_msm_direct
+  uint64_t prof_launches[3] = {0, 0, 0};
   // pinned bounce buffer for small host<->device transfers (pageable copies go through the runtime's shared staging path)
   void *bounce = nullptr;
   static constexpr size_t BOUNCE_BYTES = (size_t)1 << 20;
   void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[4] = {0, 0, 0, 0};
+  unsigned *tickets = nullptr;   // 256 zeroed counters: "last workgroup done" tickets of the direct-sum MSM (self-resetting)
 };
 
 struct zkfhe_basis {
@@ -45,6 +46,9 @@ struct zkfhe_basis {
   int c = 0;        // window bits
   int windows = 0;  // number of signed windows
   zk::G1Affine *table = nullptr;  // [windows][n] : 2^(c*w) * P_i
+  // digit-multiple table of the direct-sum path (msm.hip "few columns"): mult[(w*n + i)*8 + d-1] = d * 16^w * P_i,
+  // d = 1..8, w < 64 -- 32 KiB per base point; built for n <= 2^16 (256 MiB at n = 2^13, 2 GiB at 2^16)
+  zk::G1Affine *mult = nullptr;
 };
 
 int zk_fail(zkfhe_ctx *ctx, int code, const char *what, hipError_t e, const char *file, int line);

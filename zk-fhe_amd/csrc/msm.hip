@@ -22,6 +22,14 @@
 //     lane-parallel double-and-add over the marginals and a shuffle tree; the result is normalised to affine in the
 //     same kernel (k_msm_marginals, k_msm_weighted; k_msm_reduce is the generic fallback for larger K).
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
+//
+// Calls of a few columns (the random polynomial, the quotient pieces, the two SHPLONK commitments, the phase-0 advice: five
+// of the prover's seven calls) do not fill the chip and their cost is the LENGTH of the dependent chain -- one point
+// operation is ~10 us for a wave whether 1 or 64 lanes are live -- so they take the direct-sum path (k_msm_direct): with
+// the digit-multiple table d * 16^w * P_i (d = 1..8) of the basis resident in HBM an MSM is a plain sum of <= 64 n table
+// points: no sort, no buckets, no weights.  One launch: a few mixed additions per lane, a butterfly, and the last workgroup
+// of a column (ticket counter) folds the per-workgroup partials and normalises.  22 point operations end to end at
+// n = 2^13 instead of ~70 through the bucket pipeline (13 launches).
 #include <vector>
 #include <cstring>
 
@@ -588,6 +596,118 @@ __global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ ma
   }
 }
 
+// ---- direct-sum path for calls of a few columns ------------------------------------------------------------------
+constexpr int DM_WINDOWS = 64, DM_MULTS = 8;   // 4-bit signed digits: windows, multiples per window
+
+// mult[(w*n + i)*8 + d-1] = d * 16^w * P_i.  One thread per base point walks its 64 windows; every point is normalised on
+// its own (a 40 us inversion each: 20 ms per thread, once per basis).
+__global__ void __launch_bounds__(64) k_basis_multiples(const G1Affine *__restrict__ bases, size_t n, G1Affine *__restrict__ mult) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine cur = bases[i];
+  for (int w = 0; w < DM_WINDOWS; ++w) {
+    G1Affine *m = mult + ((size_t)w * n + i) * DM_MULTS;
+    m[0] = cur;
+    if (cur.is_identity()) {
+      for (int d = 1; d < DM_MULTS; ++d) m[d] = cur;
+      continue;
+    }
+    G1X acc = g1x_from_affine_dbl(cur);
+    m[1] = g1x_to_affine(acc);
+    for (int d = 2; d < DM_MULTS; ++d) {
+      g1x_add_affine(acc, cur, false);
+      m[d] = g1x_to_affine(acc);
+    }
+    cur = g1x_to_affine(g1x_dbl(acc));   // 16 * (16^w P_i)
+  }
+}
+
+// sum of 256 XYZZ points held one per thread -> thread 0 (6-step butterfly per wave, then the four wave sums through LDS)
+__device__ __forceinline__ G1X block_sum_256(G1X v, G1X *sh /* [4] */) {
+  for (int m = 1; m < 64; m <<= 1) {
+    const G1X other = g1x_shfl_xor(v, m);
+    g1x_add(v, other);
+  }
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  if (wv == 0) {
+    v = lane < 4 ? sh[lane] : G1X::identity();
+    for (int m = 1; m < 4; m <<= 1) {
+      const G1X other = g1x_shfl_xor(v, m);
+      g1x_add(v, other);
+    }
+  }
+  return v;
+}
+
+// E windows per thread; thread t of a column handles scalar i = t % n, windows (t / n) * E .. + E - 1 (lanes of a wave read
+// consecutive scalars).  Signed digits without a carry chain: with B = 0x88..8, nibble_w(s + B) - 8 is in [-8, 7], the digits
+// sum to s, and the zero nibbles of a short scalar stay zero digits.
+template <int E>
+__global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scalars, size_t n, const G1Affine *__restrict__ mult,
+                                                    unsigned blocks_per_col, G1X *__restrict__ partials /* [n_cols][blocks_per_col] */,
+                                                    unsigned *__restrict__ tickets /* [n_cols], zero on entry and on exit */,
+                                                    G1Affine *__restrict__ out) {
+  __shared__ G1X sh[4];
+  __shared__ unsigned last;
+  const unsigned col = blockIdx.x / blocks_per_col, blk = blockIdx.x % blocks_per_col;
+  const size_t t = (size_t)blk * 256 + threadIdx.x;
+  const size_t i = t % n;
+  const unsigned w0 = (unsigned)(t / n) * E;
+  G1X acc = G1X::identity();
+  if (w0 < (unsigned)DM_WINDOWS) {
+    Fr s = fp_from_mont<FrP>(scalars[(size_t)col * n + i]);
+    const bool neg = fr_gt_half(s);
+    if (neg) s = fp_neg<FrP>(s);
+    // s + 0x8888...8: no overflow (s < 2^253)
+    u32 carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 v = (u64)s.l[k] + 0x88888888u + carry;
+      s.l[k] = (u32)v;
+      carry = (u32)(v >> 32);
+    }
+    // E nibbles starting at window w0 (E is a multiple of 8: whole limbs)
+    const G1Affine *base = mult + ((size_t)w0 * n + i) * DM_MULTS;
+    const size_t wstride = n * DM_MULTS;
+    auto digit = [&](int e) { return (int)((s.l[(w0 + e) >> 3] >> (((w0 + e) & 7) * 4)) & 15u) - 8; };
+    // two-deep software pipeline over the table gathers
+    int d = digit(0);
+    G1Affine p;
+    if (d) p = base[(d < 0 ? -d : d) - 1];
+#pragma unroll 1
+    for (int e = 0; e < E; ++e) {
+      const int dn = e + 1 < E ? digit(e + 1) : 0;
+      G1Affine pn;
+      if (dn) pn = base[(size_t)(e + 1) * wstride + (dn < 0 ? -dn : dn) - 1];
+      if (d) g1x_add_affine(acc, p, neg != (d < 0));
+      d = dn;
+      p = pn;
+    }
+  }
+  acc = block_sum_256(acc, sh);
+  G1X *mine = partials + (size_t)col * blocks_per_col;
+  if (threadIdx.x == 0) {
+    mine[blk] = acc;
+    __threadfence();
+    last = atomicAdd(&tickets[col], 1u) == blocks_per_col - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  // the last workgroup of this column folds all partials and normalises.  The fences are agent-scope release / acquire:
+  // the other workgroups' partials may sit in another XCD's L2
+  __threadfence();
+  G1X v = G1X::identity();
+  for (unsigned b = threadIdx.x; b < blocks_per_col; b += 256) g1x_add(v, mine[b]);
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) {
+    out[col] = g1x_to_affine(v);
+    tickets[col] = 0;
+  }
+}
+
 // table[w][i] = 2^(c*w) * P_i
 __global__ void __launch_bounds__(256) k_basis_table(const G1Affine *__restrict__ bases, size_t n, int c, int windows,
                                                      G1Affine *__restrict__ table) {
@@ -627,6 +747,52 @@ __global__ void __launch_bounds__(256) k_g1_mul(const G1Affine *__restrict__ p, 
   out[i] = g1x_to_affine(acc);
 }
 
+// largest basis that gets a digit-multiple table, and the largest call (columns x n scalars) sent down the direct-sum path
+size_t direct_max_n() {
+  static long v = -1;
+  if (v < 0) {
+    const char *e = getenv("ZKFHE_DIRECT_MAX_LOGN");
+    v = 1L << (e ? atoi(e) : 16);
+    if (e && atoi(e) <= 0) v = 0;
+  }
+  return (size_t)v;
+}
+size_t direct_max_terms() {
+  static long v = -1;
+  if (v < 0) {
+    const char *e = getenv("ZKFHE_DIRECT_MAX_TERMS");
+    v = e ? atol(e) : (1L << 15);
+  }
+  return (size_t)v;
+}
+
+int msm_direct(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t n_cols, G1Affine *out) {
+  const size_t n = basis->n;
+  if (!ctx->tickets) {
+    ZK_HIP(ctx, hipMalloc((void **)&ctx->tickets, 256 * sizeof(unsigned)));
+    ZK_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, 256 * sizeof(unsigned), ctx->stream));
+  }
+  // windows per thread: as few as keep about one wave per SIMD (a lane's chain is E - 1 additions + the 8-step fold)
+  const size_t simds = (size_t)ctx->num_cu * 4;
+  int E = 8;
+  while (E < 64 && n_cols * n * (DM_WINDOWS / E) / 64 > simds + simds / 2) E <<= 1;
+  const unsigned blocks_per_col = (unsigned)((n * (DM_WINDOWS / E) + 255) / 256);
+  void *p0;
+  int rc = zk_scratch(ctx, 0, n_cols * (size_t)blocks_per_col * sizeof(G1X), &p0);
+  if (rc) return rc;
+  const unsigned grid = (unsigned)(n_cols * blocks_per_col);
+  zk_prof_begin(ctx);
+  switch (E) {
+    case 8: k_msm_direct<8><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    case 16: k_msm_direct<16><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    case 32: k_msm_direct<32><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    default: k_msm_direct<64><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+  }
+  ZK_LAUNCH_CHECK(ctx);
+  zk_prof_end(ctx, 2, 96.0 * (double)n * (double)n_cols);
+  return ZKFHE_OK;
+}
+
 int default_window_bits(size_t n) {
   if (n <= 64) return 5;
   if (n <= 1024) return 8;
@@ -662,6 +828,17 @@ int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t
   ZK_HIP(ctx, hipMemcpyAsync(tmp, bases_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
   k_basis_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)tmp, n, c, windows, b->table);
   ZK_LAUNCH_CHECK(ctx);
+  if (window_bits == 0 && n >= 256 && n <= direct_max_n()) {
+    // digit-multiple table for calls of a few columns (k_msm_direct): 32 KiB per base point
+    e = hipMalloc((void **)&b->mult, n * (size_t)DM_WINDOWS * DM_MULTS * sizeof(G1Affine));
+    if (e != hipSuccess) {
+      hipFree(b->table);
+      delete b;
+      return zk_fail(ctx, e == hipErrorOutOfMemory ? ZKFHE_ENOMEM : ZKFHE_EHIP, "hipMalloc(basis multiples)", e, __FILE__, __LINE__);
+    }
+    k_basis_multiples<<<zk_blocks(n, 64), 64, 0, ctx->stream>>>((const G1Affine *)tmp, n, b->mult);
+    ZK_LAUNCH_CHECK(ctx);
+  }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = b;
   return ZKFHE_OK;
@@ -672,6 +849,7 @@ int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis) {
   if (!basis) return ZKFHE_OK;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   hipFree(basis->table);
+  if (basis->mult) hipFree(basis->mult);
   delete basis;
   return ZKFHE_OK;
 }
@@ -684,6 +862,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, scalars_dev != nullptr && out_dev != nullptr);
   const size_t n = basis->n;
+  if (basis->mult && n_cols <= 256 && n_cols * n <= direct_max_terms()) return msm_direct(ctx, basis, (const Fr *)scalars_dev, n_cols, (G1Affine *)out_dev);
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
