@@ -270,9 +270,11 @@ __global__ void __launch_bounds__(128) k_msm_task_colscan(const unsigned *__rest
   }
 }
 // per column: hand out the positions (LDS cursors per length class) and write the task list
+constexpr unsigned MERGE_MEDIUM = 128;  // up to this many partials: eight lanes per bucket; beyond: one wave per bucket
 __global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restrict__ off, unsigned K, unsigned TASK_E, const unsigned *__restrict__ col_base,
                                                        unsigned *__restrict__ bucket_posA, unsigned *__restrict__ bucket_posB /* [n_cols][K] each */,
-                                                       uint2 *__restrict__ tasks) {
+                                                       uint2 *__restrict__ tasks, unsigned *__restrict__ heavy_count /* [0] medium, [1] large */,
+                                                       unsigned *__restrict__ medium_list, unsigned *__restrict__ large_list, unsigned heavy_cap) {
   __shared__ unsigned cur[TASK_BINS];
   const size_t col = blockIdx.x;
   for (unsigned i = threadIdx.x; i < TASK_BINS; i += 256) cur[i] = col_base[col * TASK_BINS + i];
@@ -286,6 +288,11 @@ __global__ void __launch_bounds__(256) k_msm_task_fill(const unsigned *__restric
     const unsigned posB = atomicAdd(&cur[s.a], s.nt - s.r);
     bucket_posA[g] = posA;
     bucket_posB[g] = posB;
+    if (s.nt > (unsigned)MERGE_LIGHT) {   // the merge kernel's block ranges for buckets with many partials
+      const bool large = s.nt > MERGE_MEDIUM;
+      const unsigned slot = atomicAdd(&heavy_count[large ? 1 : 0], 1u);
+      if (slot < heavy_cap) (large ? large_list : medium_list)[slot] = g;
+    }
     for (unsigned j = 0; j < s.r; ++j) tasks[posA + j] = make_uint2(g, j);
     for (unsigned j = s.r; j < s.nt; ++j) tasks[posB + (j - s.r)] = make_uint2(g, j);
   }
@@ -339,37 +346,6 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
   }
 }
 
-// bucket sum = sum of its partials.  Light buckets: one thread.  Heavy ones are listed for k_msm_merge_heavy.
-__global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_posA, const unsigned *__restrict__ bucket_posB,
-                                                   const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, size_t n_cols, G1X *__restrict__ buckets,
-                                                   unsigned *__restrict__ heavy_count, unsigned *__restrict__ heavy_list, unsigned heavy_cap) {
-  const size_t total = (size_t)K * n_cols;
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t col = g / K;
-    const unsigned b = (unsigned)(g - col * K);
-    const unsigned *o = off + col * (K + 1);
-    const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
-    const unsigned nt = s.nt;
-    if (nt > (unsigned)MERGE_LIGHT) {
-      const unsigned slot = atomicAdd(heavy_count, 1u);
-      if (slot < heavy_cap) heavy_list[slot] = (unsigned)g;
-      continue;
-    }
-    G1X acc = G1X::identity();
-    if (nt) {
-      const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
-      acc = partials[partial_pos(s, pa, pb, 0)];
-      G1X nxt = nt > 1 ? partials[partial_pos(s, pa, pb, 1)] : acc;
-      for (unsigned j = 1; j < nt; ++j) {  // the load of partial j+1 is in flight while partial j is added
-        const G1X cur = nxt;
-        if (j + 1 < nt) nxt = partials[partial_pos(s, pa, pb, j + 1)];
-        g1x_add(acc, cur);
-      }
-    }
-    buckets[g] = acc;
-  }
-}
-
 __device__ __forceinline__ G1X g1x_shfl_down(const G1X &p, int delta) {
   G1X r;
 #pragma unroll
@@ -394,60 +370,93 @@ __device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
   return r;
 }
 
-// Buckets with more than MERGE_LIGHT partials.  Up to MERGE_MEDIUM partials (every column has ~2^(254 mod c) such
-// buckets: the narrow top window piles its digits onto them): EIGHT lanes per bucket, lanes stride over the partials,
-// 3-step butterfly.  Beyond (skewed witness columns): one wave per bucket, 6-step shuffle tree.
-constexpr unsigned MERGE_MEDIUM = 128;
-__global__ void __launch_bounds__(256) k_msm_merge_heavy(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_posA, const unsigned *__restrict__ bucket_posB,
-                                                         const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, G1X *__restrict__ buckets,
-                                                         const unsigned *__restrict__ heavy_count, const unsigned *__restrict__ heavy_list,
-                                                         unsigned heavy_cap) {
-  unsigned cnt = *heavy_count;
-  if (cnt > heavy_cap) cnt = heavy_cap;
+// bucket sum = sum of its partials, ONE launch with three block ranges that run side by side (they used to be two
+// kernels and two loops, one after the other: 650 us of dependent chains per call):
+//   large_blocks: skewed witness columns (thousands of 0/1 cells in one bucket): one wave per bucket, 6-step tree;
+//   medium_blocks: buckets with <= MERGE_MEDIUM partials -- every column has ~2^(254 mod c) of them, the narrow top
+//     window piles its digits onto them -- eight lanes per bucket, lanes stride over the partials, 3-step butterfly;
+//   the rest: one thread per bucket with <= MERGE_LIGHT partials (every bucket of a full-width column).
+// The medium / large lists are written by k_msm_task_fill.
+__global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ off, const unsigned *__restrict__ bucket_posA, const unsigned *__restrict__ bucket_posB,
+                                                   const G1X *__restrict__ partials, unsigned K, unsigned TASK_E, size_t n_cols, G1X *__restrict__ buckets,
+                                                   const unsigned *__restrict__ heavy_count, const unsigned *__restrict__ medium_list,
+                                                   const unsigned *__restrict__ large_list, unsigned heavy_cap, unsigned large_blocks, unsigned medium_blocks) {
+  // block order = dispatch order: the long chains (large, then medium) go first, the light range fills the chip behind them
   const unsigned lane = threadIdx.x & 63;
-  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const unsigned n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (unsigned base = wave * 8; base < cnt; base += n_waves * 8) {
-    const unsigned h = base + (lane >> 3), sub = lane & 7;
-    size_t g = 0;
-    unsigned nt = 0, pa = 0, pb = 0;
-    Slices s = {0, 0, 0};
-    if (h < cnt) {
-      g = heavy_list[h];
+  if (blockIdx.x < large_blocks) {
+    unsigned cnt = heavy_count[1];
+    if (cnt > heavy_cap) cnt = heavy_cap;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned n_waves = (large_blocks * blockDim.x) >> 6;
+    for (unsigned h = wave; h < cnt; h += n_waves) {
+      const size_t g = large_list[h];
       const size_t col = g / K;
       const unsigned b = (unsigned)(g - col * K);
       const unsigned *o = off + col * (K + 1);
-      s = slices_of(o[b + 1] - o[b], TASK_E);
-      nt = s.nt;
-      pa = bucket_posA[g];
-      pb = bucket_posB[g];
+      const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
+      const unsigned nt = s.nt;
+      const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
+      G1X acc = G1X::identity();
+      for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
+      for (int d = 32; d > 0; d >>= 1) {
+        const G1X other = g1x_shfl_down(acc, d);
+        if ((int)lane < d) g1x_add(acc, other);
+      }
+      if (lane == 0) buckets[g] = acc;
     }
-    const bool mine = nt && nt <= MERGE_MEDIUM;
-    G1X acc = G1X::identity();
-    if (mine)
-      for (unsigned j = sub; j < nt; j += 8) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
-    for (int m = 1; m < 8; m <<= 1) {
-      const G1X other = g1x_shfl_xor(acc, m);
-      g1x_add(acc, other);
-    }
-    if (mine && sub == 0) buckets[g] = acc;
+    return;
   }
-  for (unsigned h = wave; h < cnt; h += n_waves) {
-    const size_t g = heavy_list[h];
+  if (blockIdx.x < large_blocks + medium_blocks) {
+    unsigned cnt = heavy_count[0];
+    if (cnt > heavy_cap) cnt = heavy_cap;
+    const unsigned wave = ((blockIdx.x - large_blocks) * blockDim.x + threadIdx.x) >> 6;
+    const unsigned n_waves = (medium_blocks * blockDim.x) >> 6;
+    for (unsigned base = wave * 8; base < cnt; base += n_waves * 8) {
+      const unsigned h = base + (lane >> 3), sub = lane & 7;
+      size_t g = 0;
+      unsigned nt = 0, pa = 0, pb = 0;
+      Slices s = {0, 0, 0};
+      if (h < cnt) {
+        g = medium_list[h];
+        const size_t col = g / K;
+        const unsigned b = (unsigned)(g - col * K);
+        const unsigned *o = off + col * (K + 1);
+        s = slices_of(o[b + 1] - o[b], TASK_E);
+        nt = s.nt;
+        pa = bucket_posA[g];
+        pb = bucket_posB[g];
+      }
+      G1X acc = G1X::identity();
+      for (unsigned j = sub; j < nt; j += 8) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
+      for (int m = 1; m < 8; m <<= 1) {
+        const G1X other = g1x_shfl_xor(acc, m);
+        g1x_add(acc, other);
+      }
+      if (nt && sub == 0) buckets[g] = acc;
+    }
+    return;
+  }
+  const unsigned first = large_blocks + medium_blocks, light_blocks = gridDim.x - first;
+  const size_t total = (size_t)K * n_cols;
+  for (size_t g = (blockIdx.x - first) * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)light_blocks * blockDim.x) {
     const size_t col = g / K;
     const unsigned b = (unsigned)(g - col * K);
     const unsigned *o = off + col * (K + 1);
     const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
     const unsigned nt = s.nt;
-    if (nt <= MERGE_MEDIUM) continue;
-    const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
+    if (nt > (unsigned)MERGE_LIGHT) continue;
     G1X acc = G1X::identity();
-    for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
-    for (int d = 32; d > 0; d >>= 1) {
-      const G1X other = g1x_shfl_down(acc, d);
-      if ((int)lane < d) g1x_add(acc, other);
+    if (nt) {
+      const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
+      acc = partials[partial_pos(s, pa, pb, 0)];
+      G1X nxt = nt > 1 ? partials[partial_pos(s, pa, pb, 1)] : acc;
+      for (unsigned j = 1; j < nt; ++j) {  // the load of partial j+1 is in flight while partial j is added
+        const G1X cur = nxt;
+        if (j + 1 < nt) nxt = partials[partial_pos(s, pa, pb, j + 1)];
+        g1x_add(acc, cur);
+      }
     }
-    if (lane == 0) buckets[g] = acc;
+    buckets[g] = acc;
   }
 }
 
@@ -564,7 +573,10 @@ __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ b
   if (live && sub == 0) marg[col * per_col + w] = v;
 }
 
-// one block per MSM: waves 0 .. ceil(A/64)-1 weight the row sums (a * R_a), the last wave the column sums ((b+1) * C_b)
+// one block per MSM: waves 0 .. ceil(A/64)-1 weight the row sums (64 a * R_a), the last wave the column sums ((b+1) * C_b).
+// Every lane runs a double-and-add over exactly the bits its wave needs (log2 A for the rows, 7 for the columns); the row
+// lanes then double six more times (the factor 64) while the column wave is still busy, so that after the butterflies one
+// lane only adds the wave sums and normalises: 30 dependent point operations at K = 4096, 26 at K = 512 (it was 37).
 __global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ marg, unsigned K, G1Affine *__restrict__ out) {
   __shared__ G1X sh[9];
   const unsigned A = K >> 6;
@@ -575,12 +587,18 @@ __global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ ma
   const bool rows = wv < row_waves;
   const unsigned a = wv * 64 + lane;
   const G1X P = rows ? (a < A ? M[a] : G1X::identity()) : M[A + lane];
-  const unsigned k = rows ? a : lane + 1;  // weights a (rows) and b + 1 (columns)
+  const unsigned k = rows ? a : lane + 1;  // weights a (rows, times 64 below) and b + 1 (columns)
+  int nbits = 7;
+  if (rows) {
+    nbits = 0;
+    while ((1u << nbits) < A) ++nbits;
+  }
   G1X W = G1X::identity();
-  for (int bit = 9; bit >= 0; --bit) {
+  for (int bit = nbits - 1; bit >= 0; --bit) {
     W = g1x_dbl(W);
     if ((k >> bit) & 1) g1x_add(W, P);
   }
+  if (rows) W = g1x_mul_pow2(W, 6);
   for (int m = 1; m < 64; m <<= 1) {
     const G1X other = g1x_shfl_xor(W, m);
     g1x_add(W, other);
@@ -589,9 +607,7 @@ __global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ ma
   __syncthreads();
   if (threadIdx.x == 0) {
     G1X t = sh[0];
-    for (unsigned w = 1; w < row_waves; ++w) g1x_add(t, sh[w]);
-    t = g1x_mul_pow2(t, 6);
-    g1x_add(t, sh[row_waves]);
+    for (unsigned w = 1; w <= row_waves; ++w) g1x_add(t, sh[w]);
     out[col] = g1x_to_affine(t);
   }
 }
@@ -871,7 +887,7 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   const size_t heavy_cap = (n_cols * col_entries) / ((size_t)TASK_E * MERGE_LIGHT) + 1;  // buckets with > MERGE_LIGHT partials
   // scratch 1: hist | off | cursor | bucket_posA | bucket_posB | col_hist | col_base | n_tasks | heavy_count | heavy_list | tasks
   // scratch 2: entries     scratch 0: buckets | partials
-  const size_t words = 3 * n_cols * K1 + 2 * (size_t)K * n_cols + 2 * n_cols * TASK_BINS + 16 + heavy_cap + 2 * max_tasks;
+  const size_t words = 3 * n_cols * K1 + 2 * (size_t)K * n_cols + 2 * n_cols * TASK_BINS + 16 + 2 * heavy_cap + 2 * max_tasks;
   void *p1, *p2, *p0;
   int rc = zk_scratch(ctx, 1, words * sizeof(unsigned), &p1);
   if (rc) return rc;
@@ -888,8 +904,9 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   unsigned *col_base = col_hist + n_cols * TASK_BINS;
   unsigned *n_tasks_dev = col_base + n_cols * TASK_BINS;
   unsigned *heavy_count = n_tasks_dev + 4;
-  unsigned *heavy_list = heavy_count + 4;
-  uint2 *tasks = (uint2 *)(((uintptr_t)(heavy_list + heavy_cap) + 7) & ~(uintptr_t)7);
+  unsigned *medium_list = heavy_count + 4;
+  unsigned *large_list = medium_list + heavy_cap;
+  uint2 *tasks = (uint2 *)(((uintptr_t)(large_list + heavy_cap) + 7) & ~(uintptr_t)7);
   unsigned *entries = (unsigned *)p2;
   G1X *buckets = (G1X *)p0;
   G1X *partials = buckets + n_cols * (size_t)K;
@@ -918,7 +935,8 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   ZK_LAUNCH_CHECK(ctx);
   k_msm_task_colscan<<<1, 128, 0, ctx->stream>>>(col_hist, (unsigned)n_cols, col_base, n_tasks_dev);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_base, bucket_posA, bucket_posB, tasks);
+  k_msm_task_fill<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_base, bucket_posA, bucket_posB, tasks, heavy_count, medium_list, large_list,
+                                                             (unsigned)heavy_cap);
   ZK_LAUNCH_CHECK(ctx);
   unsigned gridt = zk_blocks(max_tasks, 256);
   const unsigned capt = (unsigned)ctx->num_cu * 32;
@@ -938,15 +956,19 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
     ZK_HIP(ctx, hipMemcpy2D(tot.data(), sizeof(unsigned), off + K, (size_t)K1 * sizeof(unsigned), sizeof(unsigned), n_cols, hipMemcpyDeviceToHost));
     for (unsigned t : tot) ctx->prof_ops[0] += (double)t;
   }
-  const size_t nb = (size_t)K * n_cols;
-  unsigned gridb = zk_blocks(nb, 256);
-  if (gridb > capt) gridb = capt;
-  k_msm_merge<<<gridb, 256, 0, ctx->stream>>>(off, bucket_posA, bucket_posB, partials, K, TASK_E, n_cols, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
-  ZK_LAUNCH_CHECK(ctx);
-  unsigned gridh = (unsigned)((heavy_cap + 3) / 4);
-  if (gridh > 2048) gridh = 2048;
-  k_msm_merge_heavy<<<gridh, 256, 0, ctx->stream>>>(off, bucket_posA, bucket_posB, partials, K, TASK_E, buckets, heavy_count, heavy_list, (unsigned)heavy_cap);
-  ZK_LAUNCH_CHECK(ctx);
+  {
+    // light buckets: one thread each; medium: a wave per eight buckets; large: a wave per bucket -- three block ranges of one launch
+    const size_t nb = (size_t)K * n_cols;
+    unsigned gridb = zk_blocks(nb, 256);
+    if (gridb > capt) gridb = capt;
+    unsigned gridm = (unsigned)((heavy_cap / 8 + 3) / 4);
+    if (gridm > 512) gridm = 512;
+    unsigned gridl = (unsigned)((heavy_cap + 3) / 4);
+    if (gridl > 512) gridl = 512;
+    k_msm_merge<<<gridl + gridm + gridb, 256, 0, ctx->stream>>>(off, bucket_posA, bucket_posB, partials, K, TASK_E, n_cols, buckets, heavy_count, medium_list,
+                                                                large_list, (unsigned)heavy_cap, gridl, gridm);
+    ZK_LAUNCH_CHECK(ctx);
+  }
   if (K >= 64 && K <= 32768) {
     const unsigned A = K >> 6, per_col = A + 64;
     G1X *marg = partials;  // the accumulation partials are dead once the buckets are merged
@@ -955,12 +977,18 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
     // part would be A / 8 additions deep
     const unsigned Lr = n_cols <= 16 ? 64 : 8;
     const unsigned Lc = (n_cols <= 16 || A > 64) ? 64 : 8;
-    size_t waves = (n_cols * A + 64 / Lr - 1) / (64 / Lr);
-    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lr, 0, A, marg);
-    ZK_LAUNCH_CHECK(ctx);
-    waves = (n_cols * 64 + 64 / Lc - 1) / (64 / Lc);
-    k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lc, A, 64, marg);
-    ZK_LAUNCH_CHECK(ctx);
+    if (Lr == Lc) {   // rows and columns side by side in one launch
+      const size_t waves = (n_cols * (A + 64) + 64 / Lr - 1) / (64 / Lr);
+      k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lr, 0, A + 64, marg);
+      ZK_LAUNCH_CHECK(ctx);
+    } else {
+      size_t waves = (n_cols * A + 64 / Lr - 1) / (64 / Lr);
+      k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lr, 0, A, marg);
+      ZK_LAUNCH_CHECK(ctx);
+      waves = (n_cols * 64 + 64 / Lc - 1) / (64 / Lc);
+      k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lc, A, 64, marg);
+      ZK_LAUNCH_CHECK(ctx);
+    }
     k_msm_weighted<<<(unsigned)n_cols, 64 * ((A + 63) / 64 + 1), 0, ctx->stream>>>(marg, K, (G1Affine *)out_dev);
     ZK_LAUNCH_CHECK(ctx);
     (void)per_col;

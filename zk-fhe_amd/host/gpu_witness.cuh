@@ -236,7 +236,10 @@ struct GadgetArgs {
   u64 p0, p1;        // z, y  |  z  |  q
   Fr bound;          // div_mod bound
 };
-__global__ void __launch_bounds__(256) k_gadget(GadgetArgs g) {
+// blockIdx.y selects one of the gadget calls of a dependency level: calls whose inputs are ready run side by side in one
+// launch (24 calls, 5 levels: see GpuPhase1::launch)
+__global__ void __launch_bounds__(256) k_gadget(const GadgetArgs *__restrict__ calls) {
+  const GadgetArgs g = calls[blockIdx.y];
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= g.count) return;
   DevWriter w{g.stream + g.base + i * g.cpc};

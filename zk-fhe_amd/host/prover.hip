@@ -89,6 +89,12 @@ struct Workspace {
   G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
   hipEvent_t ev_pts = nullptr;
   U256 *host_wblind = nullptr; // pinned staging for the blinding rows of device-generated columns
+  // the random polynomial of the vanishing argument depends on no challenge: it is uploaded and committed at the start of
+  // the proof on an auxiliary context (own stream, scratch and tickets) beside the phase-0 / witness work
+  zkfhe_ctx *aux = nullptr;
+  U256 *host_rand = nullptr;   // pinned [n] coefficients
+  G1Affine *host_rand_pt = nullptr;  // pinned: the commitment
+  hipEvent_t ev_rand = nullptr;
   DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
   std::vector<DevBuf *> all() {
@@ -346,15 +352,22 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->ring, Workspace::RING_BYTES, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming | hipEventBlockingSync));
+  ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_rand, hipEventDisableTiming | hipEventBlockingSync));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_rand, pk->cfg.n() * 32, hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_rand_pt, sizeof(G1Affine), hipHostMallocDefault));
+  if (zkfhe_ctx_create(ctx->device, nullptr, &ws->aux)) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("auxiliary context: ") + zkfhe_last_error(nullptr));
   return ZKFHE_OK;
 }
 
 void free_workspace(Workspace *ws) {
   (void)hipSetDevice(ws->all_l.device);
   for (DevBuf *b : ws->all()) b->release();
-  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_wblind, (void *)ws->host_pts, (void *)ws->ring})
+  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_wblind, (void *)ws->host_pts, (void *)ws->ring,
+                  (void *)ws->host_rand, (void *)ws->host_rand_pt})
     if (h) (void)hipHostFree(h);
   if (ws->ev_pts) (void)hipEventDestroy(ws->ev_pts);
+  if (ws->ev_rand) (void)hipEventDestroy(ws->ev_rand);
+  if (ws->aux) (void)zkfhe_ctx_destroy(ws->aux);
   delete ws;
 }
 
@@ -598,6 +611,9 @@ class GpuPhase1 {
     stream = ws->stream.fr();
     pool_used = 0;
     off = 0;
+    calls.clear();
+    call_level.clear();
+    produced.clear();
     // inputs: one pinned staging block, one DMA
     h_used = 0;
     DevPoly e0 = stage(st.e0), e1 = stage(st.e1), u = stage(st.u), m = stage(st.m);
@@ -653,6 +669,7 @@ class GpuPhase1 {
       CK(equal(c_red, side ? xc1 : xc0));
     }
     if (off != pk->gate1_cells) return zk_fail_msg(ctx, ZKFHE_EINVAL, "GPU witness stream length differs from the keygen circuit shape");
+    CK(launch_levels());
     // deferred 1/x cells of is_zero: one batch inversion over the structural slot list
     if (pk->n_inv_slots) {
       const unsigned g = (unsigned)((pk->n_inv_slots + 255) / 256);
@@ -728,9 +745,51 @@ class GpuPhase1 {
     g.p0 = p0;
     g.p1 = p1;
     g.bound = bound;
-    zkw::k_gadget<<<(unsigned)((a.len + 255) / 256), 256, 0, ctx->stream>>>(g);
-    ZK_LAUNCH_CHECK(ctx);
+    // recorded in program order (the stream offsets follow examples/bfv.rs:171-301), launched level by level: a call's level
+    // is one more than the level of the call that produced its inputs
+    calls.push_back(g);
+    call_level.push_back(level_of(a.d, a.len, b));
+    if (out) produced.push_back({out, out + a.len, call_level.back()});
     off += a.len * cpc;
+    return ZKFHE_OK;
+  }
+  struct Produced {
+    const Fr *lo, *hi;
+    int level;
+  };
+  std::vector<zkw::GadgetArgs> calls;
+  std::vector<int> call_level;
+  std::vector<Produced> produced;
+  int level_of(const Fr *a, size_t len, const Fr *b) const {
+    int lv = 0;
+    for (const Produced &p : produced) {
+      if (a < p.hi && a + len > p.lo) lv = std::max(lv, p.level + 1);
+      if (b && b < p.hi && b + 1 > p.lo) lv = std::max(lv, p.level + 1);   // b: an array aligned with a, or one scalar
+      if (b && b + len > p.lo && b < p.hi) lv = std::max(lv, p.level + 1);
+    }
+    return lv;
+  }
+  int launch_levels() {
+    int max_level = 0;
+    for (int l : call_level) max_level = std::max(max_level, l);
+    std::vector<zkw::GadgetArgs> ordered;
+    std::vector<size_t> first(max_level + 2, 0);
+    for (int l = 0; l <= max_level; ++l) {
+      first[l] = ordered.size();
+      for (size_t i = 0; i < calls.size(); ++i)
+        if (call_level[i] == l) ordered.push_back(calls[i]);
+    }
+    first[max_level + 1] = ordered.size();
+    zkw::GadgetArgs *dev = (zkw::GadgetArgs *)((char *)ws->small.p + 768 * 1024);
+    if (ordered.size() * sizeof(zkw::GadgetArgs) > 128 * 1024) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many gadget calls");
+    CK(up(ctx, ws, dev, ordered.data(), ordered.size() * sizeof(zkw::GadgetArgs)));
+    for (int l = 0; l <= max_level; ++l) {
+      size_t longest = 0;
+      for (size_t i = first[l]; i < first[l + 1]; ++i) longest = std::max(longest, ordered[i].count);
+      if (first[l + 1] == first[l]) continue;
+      zkw::k_gadget<<<dim3((unsigned)((longest + 255) / 256), (unsigned)(first[l + 1] - first[l])), 256, 0, ctx->stream>>>(dev + first[l]);
+      ZK_LAUNCH_CHECK(ctx);
+    }
     return ZKFHE_OK;
   }
   int in_range(const DevPoly &a, uint64_t z, uint64_t y) {
@@ -784,31 +843,50 @@ bool witness_on_host() {
 // circuit shape -- are produced by a helper thread while the witness is being generated; next() hands them out in order.
 class PreRng {
  public:
-  PreRng(const uint8_t seed[32], size_t total) : vals(total), done(0) {
+  // The stream is counter based, so the values do not depend on the order they are computed in: the draws are cut into
+  // HEAD_PARTS ranges plus the `tail` (the random polynomial, needed first), one helper thread each.
+  static constexpr int HEAD_PARTS = 4;
+  PreRng(const uint8_t seed[32], size_t total, size_t tail) : vals(total) {
     memcpy(sd, seed, 32);
-    th = std::thread([this] {
-      Rng r(sd);
-      for (size_t i = 0; i < vals.size(); ++i) {
-        vals[i] = r.next();
-        done.store(i + 1, std::memory_order_release);
-      }
-    });
+    const size_t head = total - tail;
+    for (int p = 0; p <= HEAD_PARTS; ++p) lo[p] = head * p / HEAD_PARTS;
+    lo[HEAD_PARTS + 1] = total;
+    for (int p = 0; p <= HEAD_PARTS; ++p) {
+      done[p].store(lo[p], std::memory_order_relaxed);
+      th[p] = std::thread([this, p] {
+        Rng r(sd);
+        r.ctr = lo[p];
+        for (size_t i = lo[p]; i < lo[p + 1]; ++i) {
+          vals[i] = r.next();
+          if ((i & 63) == 63 || i + 1 == lo[p + 1]) done[p].store(i + 1, std::memory_order_release);
+        }
+      });
+    }
   }
   ~PreRng() {
-    if (th.joinable()) th.join();
+    for (auto &t : th)
+      if (t.joinable()) t.join();
   }
   U256 next() {
     if (idx >= vals.size()) throw std::logic_error("blinding stream exhausted");
-    while (done.load(std::memory_order_acquire) <= idx) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    while (idx >= lo[part + 1]) ++part;
+    while (done[part].load(std::memory_order_acquire) <= idx) std::this_thread::sleep_for(std::chrono::microseconds(10));
     return vals[idx++];
   }
+  const U256 *tail() {   // the last `tail` draws, without consuming them
+    while (done[HEAD_PARTS].load(std::memory_order_acquire) < vals.size()) std::this_thread::sleep_for(std::chrono::microseconds(10));
+    return vals.data() + lo[HEAD_PARTS];
+  }
+  void skip(size_t k) { idx += k; }
 
  private:
   std::vector<U256> vals;
-  std::atomic<size_t> done;
+  size_t lo[HEAD_PARTS + 2];
+  std::atomic<size_t> done[HEAD_PARTS + 1];
   size_t idx = 0;
+  int part = 0;
   uint8_t sd[32];
-  std::thread th;
+  std::thread th[HEAD_PARTS + 1];
 };
 
 struct OpenItem {
@@ -839,7 +917,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const double t_start = now_ms();
   Trace trace;
   PreRng rng(seed, (size_t)cfg.n_advice() * (n - u) + 2 * (size_t)cfg.n_lookup * (n - u) +
-                        ((size_t)cfg.n_chunks() + cfg.n_lookup) * (n - u - 1) + n);
+                        ((size_t)cfg.n_chunks() + cfg.n_lookup) * (n - u - 1) + n, n);
   Transcript tr(cfg.transcript);
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
@@ -858,6 +936,29 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   CK(alloc_witness_buffers(ctx, pk, ws));
   ws->ring_off = 0;
   trace.mark("setup (rng thread, workspace)");
+  // random polynomial, early: coefficients (the tail of the blinding stream) -> auxiliary stream -> commitment, enqueued by a
+  // helper thread as soon as the draws exist.  The main stream is idle here (synchronised above) and only touches this
+  // region again after waiting for ev_rand.
+  struct EarlyRand {
+    std::thread th;
+    int rc = 0;
+    ~EarlyRand() {
+      if (th.joinable()) th.join();
+    }
+  } early;
+  early.th = std::thread([&, n] {
+    zkfhe_ctx *aux = ws->aux;
+    (void)hipSetDevice(aux->device);
+    Fr *rand_dev = ws->misc.fr() + 8 * n;
+    G1Affine *pt_dev = (G1Affine *)ws->points.p + std::max<size_t>(ws->n_all, cfg.n_perm());
+    memcpy(ws->host_rand, rng.tail(), n * 32);
+    int rc = hipMemcpyAsync(rand_dev, ws->host_rand, n * 32, hipMemcpyHostToDevice, aux->stream) == hipSuccess ? 0 : ZKFHE_EHIP;
+    if (!rc) rc = zkfhe_fr_to_mont(aux, (const zkfhe_fr *)rand_dev, (zkfhe_fr *)rand_dev, n);
+    if (!rc) rc = zkfhe_msm_batch(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_affine *)pt_dev);
+    if (!rc && hipMemcpyAsync(ws->host_rand_pt, pt_dev, sizeof(G1Affine), hipMemcpyDeviceToHost, aux->stream) != hipSuccess) rc = ZKFHE_EHIP;
+    if (!rc && hipEventRecord(ws->ev_rand, aux->stream) != hipSuccess) rc = ZKFHE_EHIP;
+    early.rc = rc;
+  });
   const CircuitInput in = CircuitInput::parse_json(input_json);
   trace.mark("parse_json");
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
@@ -890,12 +991,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   trace.mark("blind + upload phase 0");
   const bool host_witness = witness_on_host();
   GpuPhase1 g1(ctx, pk, ws);
+  // the few phase-0 columns go through the full-width basis: zkfhe_msm_batch takes its direct-sum path for them
+  const zkfhe_basis *p0_basis = (size_t)cfg.n_gate0 * n <= ((size_t)1 << 15) ? srs->g_lagrange : small_basis;
   if (host_witness) {
-    CK(commit_cols(ctx, small_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+    CK(commit_cols(ctx, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   } else {
     // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
     CK(alloc_witness_buffers(ctx, pk, ws));
-    CK(zkfhe_msm_batch(ctx, small_basis, (const zkfhe_fr *)ws->adv_l.fr(), cfg.n_gate0, (zkfhe_g1_affine *)ws->points.p));
+    CK(zkfhe_msm_batch(ctx, p0_basis, (const zkfhe_fr *)ws->adv_l.fr(), cfg.n_gate0, (zkfhe_g1_affine *)ws->points.p));
     ZK_HIP(ctx, hipMemcpyAsync(ws->host_pts, ws->points.p, cfg.n_gate0 * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
     CK(g1.launch(st));
@@ -1084,14 +1187,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   for (const auto &p : lz_commit) tr.write_point(p);
   // ------------------------------------------------------------ vanishing: random polynomial (coefficient form)
   Fr *rand_c = ws->misc.fr() + 8 * n, *rand_l = ws->misc.fr() + 9 * n, *H_c = ws->misc.fr() + 10 * n, *H_l = ws->misc.fr() + 11 * n;
-  {
-    std::vector<U256> rc(n);
-    for (auto &v : rc) v = rng.next();
-    CK(upload_canon(ctx, rand_c, rc.data(), n));
-  }
-  std::vector<AffinePoint> rand_commit;
-  CK(commit_cols(ctx, srs->g, rand_c, 1, (G1Affine *)ws->points.p, rand_commit));
-  tr.write_point(rand_commit[0]);
+  // committed at the start of the proof on the auxiliary stream (see below "random polynomial, early"); its n draws are the
+  // last of the blinding stream, consumed here
+  rng.skip(n);
+  early.th.join();
+  if (early.rc) return zk_fail_msg(ctx, early.rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(ws->aux));
+  ZK_HIP(ctx, hipEventSynchronize(ws->ev_rand));
+  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_rand, 0));   // later reads of rand_c on the main stream
+  tr.write_point(point_canon(*ws->host_rand_pt));
   const Fr y = mont(tr.squeeze());
   const double t_commit = now_ms();
   trace.mark("grand products + commits");

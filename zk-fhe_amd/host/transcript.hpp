@@ -108,21 +108,24 @@ class Blake2b {
   }
 };
 
-// 64 little-endian bytes -> value mod r  (Fr::from_bytes_wide)
+// 64 little-endian bytes -> value mod r  (Fr::from_bytes_wide): lo + hi * 2^256, each half reduced first
 inline U256 from_bytes_wide(const uint8_t b[64]) {
-  // value = lo + hi * 2^256, each 256-bit; reduce with Montgomery arithmetic: lo*1 + hi*R  (R = 2^256 mod r)
   U256 lo, hi;
   memcpy(lo.l, b, 32);
   memcpy(hi.l, b + 32, 32);
-  auto reduce = [](U256 v) {
+  auto reduce = [](U256 v) {   // 2^256 < 6 r
     while (!(v < fe::MOD)) fe::sub_raw(v, v, fe::MOD);
     return v;
   };
   lo = reduce(lo);
   hi = reduce(hi);
-  // hi * 2^256 mod r = from_mont^-1 ... : to_mont(hi) = hi * R mod r, as a canonical number
-  const U256 hiR = fe::from_fr_raw(fe::to_mont(hi));
-  return fe::add(lo, hiR);
+  // Montgomery product of hi with R^2 is hi * R mod r = hi * 2^256 mod r
+  pos::F h;
+  memcpy(h.l, hi.l, 32);
+  const pos::F hr = pos::mul(h, pos::R2);
+  U256 hi_r;
+  memcpy(hi_r.l, hr.l, 32);
+  return fe::add(lo, hi_r);
 }
 
 class Rng {  // blinding stream: Blake2b-512(person "zkfhe-rng", seed[32] || counter_le64) mod r
