@@ -92,6 +92,9 @@ int zkfhe_fr_from_mont(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, zkfhe_fr *out_dev,
 int zkfhe_fr_batch_invert(zkfhe_ctx *ctx, zkfhe_fr *a_dev, size_t n);
 /* modmul micro-benchmark: out[i] = a[i]^(2^iters) by repeated squaring (ALU-roofline probe) */
 int zkfhe_fr_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, zkfhe_fr *out_dev, size_t n, int iters);
+/* the same probe for the radix-2^29 product the MSM kernels use (nine 29-bit limbs, Montgomery constant 2^261): a[i] < q as a
+ * packed 256-bit integer, out[i] = a[i]^(2^iters) * (2^-261)^(2^iters - 1) mod q, canonical */
+int zkfhe_fq29_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fq *a_dev, zkfhe_fq *out_dev, size_t n, int iters);
 
 /* ---- NTT ---------------------------------------------------------------------------------- */
 /* n_cols independent transforms of length 2^log_n, column c at cols_dev + c * 2^log_n, in place,

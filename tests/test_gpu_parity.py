@@ -68,6 +68,29 @@ def test_field_random_vs_oracle(ctx):
     assert np.array_equal(ctx.fr_unop("sqr_chain", x, 5), want)
 
 
+def test_radix29_product_on_device(ctx):
+    """fq29.cuh on the GPU (the field arithmetic inside the MSM kernels): k squarings in the radix-2^29 Montgomery form
+    (R' = 2^261) against python integers: x -> x^(2^k) * R'^-(2^k - 1) mod q, for random, tiny and q - 1 inputs."""
+    import ctypes
+    rng = np.random.default_rng(29)
+    Q, n, iters = pyref.Q, 4096, 7
+    xs = [int.from_bytes(rng.bytes(32), "little") % Q for _ in range(n)]
+    xs[:4] = [0, 1, Q - 1, 2]
+    mask = (1 << 64) - 1
+    raw = np.array([[(v >> (64 * j)) & mask for j in range(4)] for v in xs], dtype=np.uint64)
+    d, o = ctx.to_device(raw), ctx.alloc(n * 32)
+    ctx.lib.zkfhe_fq29_sqr_chain.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    ctx._check(ctx.lib.zkfhe_fq29_sqr_chain(ctx.h, d.at(0), o.at(0), n, iters))
+    got = o.download(shape=(n, 4))
+    rinv = pow(pow(2, 261, Q), -1, Q)
+    for v, g in zip(xs, got):
+        w = v
+        for _ in range(iters):
+            w = w * w * rinv % Q
+        assert sum(int(g[j]) << (64 * j) for j in range(4)) == w
+    d.free(), o.free()
+
+
 def test_g1_golden(ctx, vec):
     g = vec["g1"]
     G = orc.points_to_arr([pyref.G1_GEN] * len(g["k"]))

@@ -20,3 +20,18 @@ def test_safegcd_inverse_matches_euclid(tmp_path):
                     os.path.join(HERE, "native", "inverse_check.hip"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "Fr: 0 bad" in out and "Fq: 0 bad" in out, out
+
+
+def test_radix29_field_and_point_arithmetic(tmp_path):
+    """csrc/fq29.cuh (nine 29-bit limbs, Montgomery constant 2^261, lazy reduction -- the arithmetic of the MSM kernels) against
+    the standard 8 x 32-bit arithmetic: products, fused products with operands up to 11 p, weak / canonical reduction, the
+    zero test on differences, pack / unpack, and mixed / full additions and doublings including the doubling-through-addition
+    and cancellation cases.  Host instantiation of the same host+device code (no GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "f29_check")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "zk-fhe_amd", "csrc"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "native", "f29_check.hip"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "fq29: 0 bad" in out, out

@@ -31,6 +31,19 @@ def main():
         ts.append(ctx.timer_stop_ms())
     ms = float(np.median(ts))
     res["modmul_per_s"] = n * iters / (ms * 1e-3)
+    # the radix-2^29 product of the MSM kernels (fq29.cuh), same loop
+    for _ in range(2):
+        ctx._check(ctx.lib.zkfhe_fq29_sqr_chain(ctx.h, d.at(0), o.at(0), n, iters))
+    ts = []
+    for _ in range(5):
+        ctx.timer_start()
+        ctx._check(ctx.lib.zkfhe_fq29_sqr_chain(ctx.h, d.at(0), o.at(0), n, iters))
+        ts.append(ctx.timer_stop_ms())
+    res["modmul29_per_s"] = n * iters / (float(np.median(ts)) * 1e-3)
+    ctx._check(ctx.lib.zkfhe_fq29_sqr_chain(ctx.h, d.at(0), o.at(0), 64, 20000))
+    ctx.timer_start()
+    ctx._check(ctx.lib.zkfhe_fq29_sqr_chain(ctx.h, d.at(0), o.at(0), 64, 20000))
+    res["modmul29_latency_us_single_wave"] = ctx.timer_stop_ms() * 1e3 / 20000
     # single-wave dependent-chain latency of one modmul (64 threads, long chain)
     lat_iters = 20000
     ctx._check(ctx.lib.zkfhe_fr_sqr_chain(ctx.h, d.at(0), o.at(0), 64, lat_iters))

@@ -21,7 +21,7 @@ EXPORTS = [
     "zkfhe_dev_alloc", "zkfhe_dev_free", "zkfhe_upload", "zkfhe_download", "zkfhe_copy_dev", "zkfhe_memset_dev",
     "zkfhe_timer_start", "zkfhe_timer_stop_ms", "zkfhe_prof_enable", "zkfhe_prof_reset", "zkfhe_prof_read", "zkfhe_prof_read_ops",
     "zkfhe_fr_add", "zkfhe_fr_sub", "zkfhe_fr_mul", "zkfhe_fr_scale", "zkfhe_fr_to_mont", "zkfhe_fr_from_mont",
-    "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain",
+    "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain", "zkfhe_fq29_sqr_chain",
     "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
     "zkfhe_g1_add", "zkfhe_g1_mul",

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
+#include "fq29.cuh"
 
 using namespace zk;
 
@@ -294,6 +295,15 @@ __global__ void __launch_bounds__(256) k_fr_sqr_chain(const Fr *__restrict__ a, 
   out[i] = x;
 }
 
+// the same probe for the radix-2^29 product of the MSM kernels (fq29.cuh): packed 256-bit words in, nine limbs in registers
+__global__ void __launch_bounds__(256) k_fq29_sqr_chain(const Fq *__restrict__ a, Fq *__restrict__ out, size_t n, int iters) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F29 x = f29_unpack(a[i]);
+  for (int k = 0; k < iters; ++k) x = f29_sqr(x);
+  out[i] = f29_pack(f29_canonical(x));
+}
+
 // Batch inversion, Montgomery trick per thread over a strided chunk of CHUNK elements:
 // thread t owns elements t, t+T, t+2T, ... (T = total threads) so every load/store is coalesced.
 // prefix products go to `tmp` (n elements).  Zero elements are skipped and stay zero.
@@ -387,6 +397,14 @@ int zkfhe_fr_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fr *a, zkfhe_fr *out, size_t 
   ZK_ENTER(ctx);
   if (!n) return ZKFHE_OK;
   k_fr_sqr_chain<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const Fr *)a, (Fr *)out, n, iters);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+int zkfhe_fq29_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fq *a, zkfhe_fq *out, size_t n, int iters) {
+  ZK_ENTER(ctx);
+  if (!n) return ZKFHE_OK;
+  k_fq29_sqr_chain<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const Fq *)a, (Fq *)out, n, iters);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }

@@ -23,6 +23,11 @@
 //     same kernel (k_msm_marginals, k_msm_weighted; k_msm_reduce is the generic fallback for larger K).
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
 //
+// Field arithmetic of every kernel between the tables and the final normalisation: radix 2^29, nine limbs, Montgomery
+// constant 2^261 (fq29.cuh: 162 carry-free multiply-adds per product instead of 128 multiply-add + carry pairs, lazy
+// reduction in the point formulas).  The tables, partials, buckets and marginals hold packed 256-bit words in that
+// form; k_msm_weighted / k_msm_direct convert the one result per MSM back before normalising it.
+//
 // Calls of a few columns (the random polynomial, the quotient pieces, the two SHPLONK commitments, the phase-0 advice: five
 // of the prover's seven calls) do not fill the chip and their cost is the LENGTH of the dependent chain -- one point
 // operation is ~10 us for a wave whether 1 or 64 lanes are live -- so they take the direct-sum path (k_msm_direct): with
@@ -34,12 +39,12 @@
 #include <cstring>
 
 #include "ctx.hpp"
+#include "fq29.cuh"
 
 using namespace zk;
 
 namespace {
 
-constexpr int RED_THREADS = 256;   // threads of the bucket-reduction kernel
 
 // (r-1)/2 as canonical limbs: scalars above it are negated
 __device__ __forceinline__ bool fr_gt_half(const Fr &s) {
@@ -323,7 +328,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
     // cycles of the plain loop waiting on this dependent load chain).  The entry indices themselves come in 16-byte
     // loads into an 8-entry shift window: with one 4-byte load per entry and lanes 4*E bytes apart, every lane pulled
     // its own cache line through L1 once per entry.
-    G1X acc = G1X::identity();
+    G1X29 acc = G1X29::identity();
     const unsigned *ep = e + lo;
     uint4 w0 = ld_entries(ep), w1 = ld_entries(ep + 4);
     unsigned valid = 8;
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
       const unsigned en = w0.x, en1 = w0.y;
       G1Affine pn = p;
       if (i + 1 < cnt_e) pn = table[en1 & 0x7fffffffu];
-      g1x_add_affine(acc, p, (en >> 31) != 0);
+      g1x29_add_affine(acc, g1a29_load(p), (en >> 31) != 0);
       p = pn;
       w0.x = w0.y, w0.y = w0.z, w0.z = w0.w, w0.w = w1.x;
       w1.x = w1.y, w1.y = w1.z, w1.z = w1.w;
@@ -342,14 +347,14 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const uint2 *__restrict_
         valid = 8;
       }
     }
-    partials[t] = acc;
+    partials[t] = g1x29_store(acc);
   }
 }
 
-__device__ __forceinline__ G1X g1x_shfl_down(const G1X &p, int delta) {
-  G1X r;
+__device__ __forceinline__ G1X29 g1x_shfl_down(const G1X29 &p, int delta) {
+  G1X29 r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 9; ++i) {
     r.x.l[i] = __shfl_down(p.x.l[i], delta);
     r.y.l[i] = __shfl_down(p.y.l[i], delta);
     r.zz.l[i] = __shfl_down(p.zz.l[i], delta);
@@ -358,10 +363,10 @@ __device__ __forceinline__ G1X g1x_shfl_down(const G1X &p, int delta) {
   return r;
 }
 
-__device__ __forceinline__ G1X g1x_shfl_xor(const G1X &p, int mask) {
-  G1X r;
+__device__ __forceinline__ G1X29 g1x_shfl_xor(const G1X29 &p, int mask) {
+  G1X29 r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 9; ++i) {
     r.x.l[i] = __shfl_xor(p.x.l[i], mask);
     r.y.l[i] = __shfl_xor(p.y.l[i], mask);
     r.zz.l[i] = __shfl_xor(p.zz.l[i], mask);
@@ -396,13 +401,13 @@ __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ 
       const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
       const unsigned nt = s.nt;
       const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
-      G1X acc = G1X::identity();
-      for (unsigned j = lane; j < nt; j += 64) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
+      G1X29 acc = G1X29::identity();
+      for (unsigned j = lane; j < nt; j += 64) g1x29_add(acc, g1x29_load(partials[partial_pos(s, pa, pb, j)]));
       for (int d = 32; d > 0; d >>= 1) {
-        const G1X other = g1x_shfl_down(acc, d);
-        if ((int)lane < d) g1x_add(acc, other);
+        const G1X29 other = g1x_shfl_down(acc, d);
+        if ((int)lane < d) g1x29_add(acc, other);
       }
-      if (lane == 0) buckets[g] = acc;
+      if (lane == 0) buckets[g] = g1x29_store(acc);
     }
     return;
   }
@@ -426,13 +431,13 @@ __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ 
         pa = bucket_posA[g];
         pb = bucket_posB[g];
       }
-      G1X acc = G1X::identity();
-      for (unsigned j = sub; j < nt; j += 8) g1x_add(acc, partials[partial_pos(s, pa, pb, j)]);
+      G1X29 acc = G1X29::identity();
+      for (unsigned j = sub; j < nt; j += 8) g1x29_add(acc, g1x29_load(partials[partial_pos(s, pa, pb, j)]));
       for (int m = 1; m < 8; m <<= 1) {
-        const G1X other = g1x_shfl_xor(acc, m);
-        g1x_add(acc, other);
+        const G1X29 other = g1x_shfl_xor(acc, m);
+        g1x29_add(acc, other);
       }
-      if (nt && sub == 0) buckets[g] = acc;
+      if (nt && sub == 0) buckets[g] = g1x29_store(acc);
     }
     return;
   }
@@ -445,18 +450,22 @@ __global__ void __launch_bounds__(256) k_msm_merge(const unsigned *__restrict__ 
     const Slices s = slices_of(o[b + 1] - o[b], TASK_E);
     const unsigned nt = s.nt;
     if (nt > (unsigned)MERGE_LIGHT) continue;
-    G1X acc = G1X::identity();
+    G1X first = G1X::identity();
     if (nt) {
       const unsigned pa = bucket_posA[g], pb = bucket_posB[g];
-      acc = partials[partial_pos(s, pa, pb, 0)];
-      G1X nxt = nt > 1 ? partials[partial_pos(s, pa, pb, 1)] : acc;
-      for (unsigned j = 1; j < nt; ++j) {  // the load of partial j+1 is in flight while partial j is added
-        const G1X cur = nxt;
-        if (j + 1 < nt) nxt = partials[partial_pos(s, pa, pb, j + 1)];
-        g1x_add(acc, cur);
+      first = partials[partial_pos(s, pa, pb, 0)];
+      if (nt > 1) {
+        G1X29 acc = g1x29_load(first);
+        G1X nxt = partials[partial_pos(s, pa, pb, 1)];
+        for (unsigned j = 1; j < nt; ++j) {  // the load of partial j+1 is in flight while partial j is added
+          const G1X cur = nxt;
+          if (j + 1 < nt) nxt = partials[partial_pos(s, pa, pb, j + 1)];
+          g1x29_add(acc, g1x29_load(cur));
+        }
+        first = g1x29_store(acc);
       }
     }
-    buckets[g] = acc;
+    buckets[g] = first;
   }
 }
 
@@ -464,70 +473,9 @@ __device__ __forceinline__ G1X g1x_mul_pow2(G1X p, int k) {
   for (int i = 0; i < k; ++i) p = g1x_dbl(p);
   return p;
 }
-
-// sum_{j=1..K} j * B_j for one MSM per block (RED_THREADS threads), result -> affine.
-// Level 1: thread q owns buckets q*g+1 .. q*g+g (g = K/RED_THREADS, >= 1): S_q = sum B, T_q = sum s*B_{qg+s}.
-//   total = sum_q T_q + g * sum_q q*S_q.
-// Level 2: weighted tree over q in LDS: node = (S, W = sum (q - lo) S_q, T);  merge(L, Rn) of width m:
-//   S = SL + SR, W = WL + WR + m*SR, T = TL + TR.
-__global__ void __launch_bounds__(RED_THREADS) k_msm_reduce(const G1X *__restrict__ buckets, unsigned K, G1Affine *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char red_lds[];
-  G1X *shS = (G1X *)red_lds;
-  G1X *shW = shS + RED_THREADS;
-  const size_t col = blockIdx.x;
-  const G1X *B = buckets + col * K;
-  const unsigned q = threadIdx.x;
-  unsigned g = K / RED_THREADS;
-  unsigned nthr = RED_THREADS;
-  if (g == 0) {
-    g = 1;
-    nthr = K;
-  }
-  G1X S = G1X::identity(), T = G1X::identity();
-  if (q < nthr) {
-    for (int s = (int)g - 1; s >= 0; --s) {
-      g1x_add(S, B[(size_t)q * g + s]);
-      g1x_add(T, S);
-    }
-  }
-  // tree over S with weights q, and plain sum of T.  T is summed through shW in a first sweep.
-  shW[q] = T;
-  __syncthreads();
-  for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
-    if ((int)q < s) {
-      G1X a = shW[q];
-      g1x_add(a, shW[q + s]);
-      shW[q] = a;
-    }
-    __syncthreads();
-  }
-  G1X Tsum = shW[0];
-  __syncthreads();
-  shS[q] = S;
-  shW[q] = G1X::identity();
-  __syncthreads();
-  int logm = 0;
-  for (int m = 1; m < RED_THREADS; m <<= 1, ++logm) {
-    // nodes of width m at positions multiple of m; merge pairs (2m*t, 2m*t + m)
-    if ((q & (2 * m - 1)) == 0) {
-      G1X SL = shS[q], WL = shW[q];
-      const G1X SR = shS[q + m], WR = shW[q + m];
-      g1x_add(WL, WR);
-      g1x_add(WL, g1x_mul_pow2(SR, logm));
-      g1x_add(SL, SR);
-      shS[q] = SL;
-      shW[q] = WL;
-    }
-    __syncthreads();
-  }
-  if (q == 0) {
-    G1X W = shW[0];
-    int logg = 0;
-    while ((1u << logg) < g) ++logg;
-    W = g1x_mul_pow2(W, logg);
-    g1x_add(W, Tsum);
-    out[col] = g1x_to_affine(W);
-  }
+__device__ __forceinline__ G1X29 g1x29_mul_pow2(G1X29 p, int k) {
+  for (int i = 0; i < k; ++i) p = g1x29_dbl(p);
+  return p;
 }
 
 // ---- fast bucket reduction for 64 <= K <= 32768 -------------------------------------------------------
@@ -564,13 +512,13 @@ __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ b
     cnt = A > sub ? (A - sub + L - 1) / L : 0;
   }
   if (!live) cnt = 0;
-  G1X v = G1X::identity();
-  for (unsigned i = 0; i < cnt; ++i) g1x_add(v, B[base + i * stride]);
+  G1X29 v = G1X29::identity();
+  for (unsigned i = 0; i < cnt; ++i) g1x29_add(v, g1x29_load(B[base + i * stride]));
   for (int m = (int)G; m < 64; m <<= 1) {
-    const G1X other = g1x_shfl_xor(v, m);
-    g1x_add(v, other);
+    const G1X29 other = g1x_shfl_xor(v, m);
+    g1x29_add(v, other);
   }
-  if (live && sub == 0) marg[col * per_col + w] = v;
+  if (live && sub == 0) marg[col * per_col + w] = g1x29_store(v);
 }
 
 // one block per MSM: waves 0 .. ceil(A/64)-1 weight the row sums (64 a * R_a), the last wave the column sums ((b+1) * C_b).
@@ -586,30 +534,48 @@ __global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ ma
   const G1X *M = marg + col * (A + 64);
   const bool rows = wv < row_waves;
   const unsigned a = wv * 64 + lane;
-  const G1X P = rows ? (a < A ? M[a] : G1X::identity()) : M[A + lane];
+  const G1X29 P = g1x29_load(rows ? (a < A ? M[a] : G1X::identity()) : M[A + lane]);
   const unsigned k = rows ? a : lane + 1;  // weights a (rows, times 64 below) and b + 1 (columns)
   int nbits = 7;
   if (rows) {
     nbits = 0;
     while ((1u << nbits) < A) ++nbits;
   }
-  G1X W = G1X::identity();
+  G1X29 W = G1X29::identity();
   for (int bit = nbits - 1; bit >= 0; --bit) {
-    W = g1x_dbl(W);
-    if ((k >> bit) & 1) g1x_add(W, P);
+    W = g1x29_dbl(W);
+    if ((k >> bit) & 1) g1x29_add(W, P);
   }
-  if (rows) W = g1x_mul_pow2(W, 6);
+  if (rows) W = g1x29_mul_pow2(W, 6);
   for (int m = 1; m < 64; m <<= 1) {
-    const G1X other = g1x_shfl_xor(W, m);
-    g1x_add(W, other);
+    const G1X29 other = g1x_shfl_xor(W, m);
+    g1x29_add(W, other);
   }
-  if (lane == 0) sh[wv] = W;
+  if (lane == 0) sh[wv] = g1x29_store(W);
   __syncthreads();
   if (threadIdx.x == 0) {
-    G1X t = sh[0];
-    for (unsigned w = 1; w <= row_waves; ++w) g1x_add(t, sh[w]);
-    out[col] = g1x_to_affine(t);
+    G1X29 t = g1x29_load(sh[0]);
+    for (unsigned w = 1; w <= row_waves; ++w) g1x29_add(t, g1x29_load(sh[w]));
+    out[col] = g1x_to_affine(g1x29_to_std(t));   // back to the standard Montgomery form, then one inversion
   }
+}
+
+// K < 64 buckets (window_bits < 7: tiny bases and tests): one wave per MSM, lane b weights bucket b by b + 1
+__global__ void __launch_bounds__(64) k_msm_small(const G1X *__restrict__ buckets, unsigned K, G1Affine *__restrict__ out) {
+  const size_t col = blockIdx.x;
+  const unsigned lane = threadIdx.x;
+  const G1X29 P = g1x29_load(lane < K ? buckets[col * K + lane] : G1X::identity());
+  const unsigned k = lane + 1;
+  G1X29 W = G1X29::identity();
+  for (int bit = 6; bit >= 0; --bit) {
+    W = g1x29_dbl(W);
+    if ((k >> bit) & 1) g1x29_add(W, P);
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    const G1X29 other = g1x_shfl_xor(W, m);
+    g1x29_add(W, other);
+  }
+  if (lane == 0) out[col] = g1x_to_affine(g1x29_to_std(W));
 }
 
 // ---- direct-sum path for calls of a few columns ------------------------------------------------------------------
@@ -623,36 +589,36 @@ __global__ void __launch_bounds__(64) k_basis_multiples(const G1Affine *__restri
   G1Affine cur = bases[i];
   for (int w = 0; w < DM_WINDOWS; ++w) {
     G1Affine *m = mult + ((size_t)w * n + i) * DM_MULTS;
-    m[0] = cur;
+    m[0] = g1_affine_to_29(cur);   // stored in the 2^261 Montgomery form of the MSM kernels
     if (cur.is_identity()) {
       for (int d = 1; d < DM_MULTS; ++d) m[d] = cur;
       continue;
     }
     G1X acc = g1x_from_affine_dbl(cur);
-    m[1] = g1x_to_affine(acc);
+    m[1] = g1_affine_to_29(g1x_to_affine(acc));
     for (int d = 2; d < DM_MULTS; ++d) {
       g1x_add_affine(acc, cur, false);
-      m[d] = g1x_to_affine(acc);
+      m[d] = g1_affine_to_29(g1x_to_affine(acc));
     }
     cur = g1x_to_affine(g1x_dbl(acc));   // 16 * (16^w P_i)
   }
 }
 
 // sum of 256 XYZZ points held one per thread -> thread 0 (6-step butterfly per wave, then the four wave sums through LDS)
-__device__ __forceinline__ G1X block_sum_256(G1X v, G1X *sh /* [4] */) {
+__device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [4] */) {
   for (int m = 1; m < 64; m <<= 1) {
-    const G1X other = g1x_shfl_xor(v, m);
-    g1x_add(v, other);
+    const G1X29 other = g1x_shfl_xor(v, m);
+    g1x29_add(v, other);
   }
   const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __syncthreads();
-  if (lane == 0) sh[wv] = v;
+  if (lane == 0) sh[wv] = g1x29_store(v);
   __syncthreads();
   if (wv == 0) {
-    v = lane < 4 ? sh[lane] : G1X::identity();
+    v = g1x29_load(lane < 4 ? sh[lane] : G1X::identity());
     for (int m = 1; m < 4; m <<= 1) {
-      const G1X other = g1x_shfl_xor(v, m);
-      g1x_add(v, other);
+      const G1X29 other = g1x_shfl_xor(v, m);
+      g1x29_add(v, other);
     }
   }
   return v;
@@ -672,7 +638,7 @@ __global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scala
   const size_t t = (size_t)blk * 256 + threadIdx.x;
   const size_t i = t % n;
   const unsigned w0 = (unsigned)(t / n) * E;
-  G1X acc = G1X::identity();
+  G1X29 acc = G1X29::identity();
   if (w0 < (unsigned)DM_WINDOWS) {
     Fr s = fp_from_mont<FrP>(scalars[(size_t)col * n + i]);
     const bool neg = fr_gt_half(s);
@@ -698,7 +664,7 @@ __global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scala
       const int dn = e + 1 < E ? digit(e + 1) : 0;
       G1Affine pn;
       if (dn) pn = base[(size_t)(e + 1) * wstride + (dn < 0 ? -dn : dn) - 1];
-      if (d) g1x_add_affine(acc, p, neg != (d < 0));
+      if (d) g1x29_add_affine(acc, g1a29_load(p), neg != (d < 0));
       d = dn;
       p = pn;
     }
@@ -706,7 +672,7 @@ __global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scala
   acc = block_sum_256(acc, sh);
   G1X *mine = partials + (size_t)col * blocks_per_col;
   if (threadIdx.x == 0) {
-    mine[blk] = acc;
+    mine[blk] = g1x29_store(acc);
     __threadfence();
     last = atomicAdd(&tickets[col], 1u) == blocks_per_col - 1 ? 1u : 0u;
   }
@@ -715,11 +681,11 @@ __global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scala
   // the last workgroup of this column folds all partials and normalises.  The fences are agent-scope release / acquire:
   // the other workgroups' partials may sit in another XCD's L2
   __threadfence();
-  G1X v = G1X::identity();
-  for (unsigned b = threadIdx.x; b < blocks_per_col; b += 256) g1x_add(v, mine[b]);
+  G1X29 v = G1X29::identity();
+  for (unsigned b = threadIdx.x; b < blocks_per_col; b += 256) g1x29_add(v, g1x29_load(mine[b]));
   v = block_sum_256(v, sh);
   if (threadIdx.x == 0) {
-    out[col] = g1x_to_affine(v);
+    out[col] = g1x_to_affine(g1x29_to_std(v));
     tickets[col] = 0;
   }
 }
@@ -730,12 +696,12 @@ __global__ void __launch_bounds__(256) k_basis_table(const G1Affine *__restrict_
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Affine p = bases[i];
-  table[i] = p;
+  table[i] = g1_affine_to_29(p);   // the tables hold the 2^261 Montgomery form of the MSM kernels (fq29.cuh)
   G1X cur = g1x_from_affine(p);
   for (int w = 1; w < windows; ++w) {
     cur = g1x_mul_pow2(cur, c);
     G1Affine a = g1x_to_affine(cur);
-    table[(size_t)w * n + i] = a;
+    table[(size_t)w * n + i] = g1_affine_to_29(a);
     cur = g1x_from_affine(a);
   }
 }
@@ -994,15 +960,12 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
     (void)per_col;
     return ZKFHE_OK;
   }
-  static bool red_attr = false;
-  const int red_lds = 2 * RED_THREADS * (int)sizeof(G1X);
-  if (!red_attr) {
-    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, red_lds));
-    red_attr = true;
+  if (K < 64) {
+    k_msm_small<<<(unsigned)n_cols, 64, 0, ctx->stream>>>(buckets, K, (G1Affine *)out_dev);
+    ZK_LAUNCH_CHECK(ctx);
+    return ZKFHE_OK;
   }
-  k_msm_reduce<<<(unsigned)n_cols, RED_THREADS, red_lds, ctx->stream>>>(buckets, K, (G1Affine *)out_dev);
-  ZK_LAUNCH_CHECK(ctx);
-  return ZKFHE_OK;
+  return zk_fail_msg(ctx, ZKFHE_EINVAL, "MSM basis with more than 32768 buckets (window_bits > 16) is not supported");
 }
 
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {
