@@ -131,6 +131,8 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
   for (auto &kv : ctx->domains) {
     hipFree(kv.second.fwd);
     hipFree(kv.second.inv);
+    hipFree(kv.second.fwd29);
+    hipFree(kv.second.inv29);
   }
   for (int i = 0; i < 4; ++i)
     if (ctx->scratch[i]) hipFree(ctx->scratch[i]);

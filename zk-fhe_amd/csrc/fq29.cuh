@@ -24,7 +24,7 @@ struct F29 {
 
 namespace q29 {
 constexpr u32 MASK = (1u << 29) - 1;
-constexpr u32 INV = 0x04866389u;  // -p^-1 mod 2^29
+constexpr u32 INV = 0x04866389u;  // -q^-1 mod 2^29
 #define ZK_Q29_P \
   { 0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu }
 #define ZK_Q29_2P \
@@ -128,120 +128,17 @@ ZK_HD F29 f29_neg(const F29 &b, const u32 (&kp)[9]) {  // kp - b
 }
 ZK_HD F29 f29_dbl(const F29 &a) { return f29_add(a, a); }
 
-// value < 16 p  ->  the same residue below 2 p (in fact below 1.03 p): q = floor(v / 2^245) * 169 >> 16 underestimates v / p by
-// less than one (169 = floor(2^261 / p))
-ZK_HD F29 f29_weak_reduce(const F29 &a) {
-  const u32 P[9] = ZK_Q29_P;
-  const u32 q = ((a.l[8] >> 13) * 169u) >> 16;
-  F29 r;
-  long long c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const long long v = (long long)a.l[i] - (long long)((u64)q * P[i]) + c;
-    r.l[i] = (u32)v & q29::MASK;
-    c = v >> 29;
-  }
-  r.l[8] = (u32)((long long)a.l[8] - (long long)((u64)q * P[8]) + c);
-  return r;
-}
-// value < 4 p -> canonical (< p)
-ZK_HD F29 f29_canonical(const F29 &a) {
-  const u32 P[9] = ZK_Q29_P;
-  F29 r = f29_weak_reduce(a);  // < 2 p
-  int t[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) t[i] = (int)r.l[i] - (int)P[i];
-  // r - p: negative iff the propagated top limb is negative
-  int c = 0;
-  u32 o[9];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int v = t[i] + c;
-    o[i] = (u32)v & q29::MASK;
-    c = v >> 29;
-  }
-  const int top = t[8] + c;
-  o[8] = (u32)top;
-  if (top >= 0) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = o[i];
-  }
-  return r;
-}
-// value in (0, 4 p): is it 0 mod p?  (differences u2 - u1 + 2p of two representatives below 2 p)
-ZK_HD bool f29_is_zero_mod_p(const F29 &a) {
-  const u32 P1[9] = ZK_Q29_P, P2[9] = ZK_Q29_2P, P3[9] = ZK_Q29_3P;
-  if (a.l[0] != P1[0] && a.l[0] != P2[0] && a.l[0] != P3[0]) return false;  // almost always
-  return f29_eq(a, P1) || f29_eq(a, P2) || f29_eq(a, P3);
-}
-
-// Montgomery product a b / 2^261 mod p.  Needs a * b < 2^261 p (e.g. both below 11 p); gives a value below 2 p.
-ZK_HD F29 f29_mul(const F29 &a, const F29 &b) {
-  const u32 P[9] = ZK_Q29_P;
-  u32 m[9];
-  F29 r;
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int j = 0; j < k; ++j) {
-      acc += (u64)a.l[j] * b.l[k - j];
-      acc += (u64)m[j] * P[k - j];
-    }
-    acc += (u64)a.l[k] * b.l[0];
-    m[k] = ((u32)acc * q29::INV) & q29::MASK;
-    acc += (u64)m[k] * P[0];
-    acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int j = k - 8; j < 9; ++j) {
-      acc += (u64)a.l[j] * b.l[k - j];
-      acc += (u64)m[j] * P[k - j];
-    }
-    r.l[k - 9] = (u32)acc & q29::MASK;
-    acc >>= 29;
-  }
-  r.l[8] = (u32)acc;
-  return r;
-}
-ZK_HD F29 f29_sqr(const F29 &a) { return f29_mul(a, a); }
-
-// (a b + c d) / 2^261 mod p with one reduction.  Needs a b + c d < 2^261 p; gives a value below 2 p.
-ZK_HD F29 f29_mul2(const F29 &a, const F29 &b, const F29 &c, const F29 &d) {
-  const u32 P[9] = ZK_Q29_P;
-  u32 m[9];
-  F29 r;
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-#pragma unroll
-    for (int j = 0; j < k; ++j) {
-      acc += (u64)a.l[j] * b.l[k - j];
-      acc += (u64)c.l[j] * d.l[k - j];
-      acc += (u64)m[j] * P[k - j];
-    }
-    acc += (u64)a.l[k] * b.l[0];
-    acc += (u64)c.l[k] * d.l[0];
-    m[k] = ((u32)acc * q29::INV) & q29::MASK;
-    acc += (u64)m[k] * P[0];
-    acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; ++k) {
-#pragma unroll
-    for (int j = k - 8; j < 9; ++j) {
-      acc += (u64)a.l[j] * b.l[k - j];
-      acc += (u64)c.l[j] * d.l[k - j];
-      acc += (u64)m[j] * P[k - j];
-    }
-    r.l[k - 9] = (u32)acc & q29::MASK;
-    acc >>= 29;
-  }
-  r.l[8] = (u32)acc;
-  return r;
-}
+#define F29_FN(name) f29_##name
+#define F29_P ZK_Q29_P
+#define F29_2P ZK_Q29_2P
+#define F29_3P ZK_Q29_3P
+#define F29_INV q29::INV
+#include "f29_field.inc"
+#undef F29_FN
+#undef F29_P
+#undef F29_2P
+#undef F29_3P
+#undef F29_INV
 
 // ---- G1 in XYZZ coordinates over F29.  Stored coordinates are below 2 p; identity: zz = zzz = literal 0 --------------
 struct G1A29 {  // affine, canonical coordinates (table entries); identity (0, 0)

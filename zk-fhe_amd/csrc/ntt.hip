@@ -22,6 +22,7 @@
 
 #include "ctx.hpp"
 #include "ntt_tile.cuh"
+#include "fr29.cuh"
 
 using namespace zk;
 
@@ -42,7 +43,7 @@ namespace {
 // one radix-2 DIF stage over vectors of length n (all columns): pairs (j, j+half) inside blocks of 2*half
 //   a' = a + b ; b' = (a - b) * omega_n^(j * n/(2*half)),  j = index inside the half
 __global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t n_cols, int log_n, int log_half,
-                                                   const Fr *__restrict__ tw_n /* omega_n^j, j < n/2 */) {
+                                                   const Fr *__restrict__ tw_n /* omega_n^j, j < n/2, 2^261 form */) {
   const size_t half = (size_t)1 << log_half;
   const size_t per_col = (size_t)1 << (log_n - 1);
   const size_t total = n_cols * per_col;
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t
     Fr s = x + y, d = x - y;
     const size_t e = j << (log_n - 1 - log_half);
     p[0] = s;
-    p[half] = e ? d * tw_n[e] : d;
+    p[half] = e ? fr29_mul_const(d, tw_n[e]) : d;
   }
 }
 
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) k_dif_fused(Fr *__restrict__ data, size_t
         x[m] = a + b;
         const Fr d = a - b;
         const size_t e = j << sh;
-        x[m + h] = e ? d * tw_n[e] : d;
+        x[m + h] = e ? fr29_mul_const(d, tw_n[e]) : d;
       }
     }
 #pragma unroll
@@ -138,14 +139,14 @@ __global__ void __launch_bounds__(256) k_coset_prescale(const Fr *__restrict__ i
   const size_t total = n_cols * ne;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t c = g / ne, r = g - c * ne, i = r & (n - 1);
-    out[g] = in[c * n + i] * pre[r];
+    out[g] = fr29_mul_const(in[c * n + i], pre[r]);   // pre: 2^261 form
   }
 }
 
 template <int LEF>
 __global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows, Fr *__restrict__ out, size_t n_cols, int log_n,
                                                      const Fr *__restrict__ tw_ext_inv /* w_ext^-j, j < n*E */,
-                                                     const Fr *__restrict__ scale /* 2^-lef g^-j, j < n*E */) {
+                                                     const Fr *__restrict__ scale /* 2^-lef g^-j, j < n*E */) {   // both tables in the 2^261 form
   constexpr int E = 1 << LEF;
   const size_t n = (size_t)1 << log_n;
   const size_t total = n_cols * n;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows
 #pragma unroll
     for (int k1 = 0; k1 < E; ++k1) {
       Fr x = src[(size_t)k1 * n + i2];
-      v[k1] = k1 ? x * tw_ext_inv[(size_t)k1 * i2] : x;
+      v[k1] = k1 ? fr29_mul_const(x, tw_ext_inv[(size_t)k1 * i2]) : x;
     }
     // DFT_E with root w_E^-1 = w_ext^-(n)
     Fr o[E];
@@ -166,13 +167,13 @@ __global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows
 #pragma unroll
       for (int k1 = 1; k1 < E; ++k1) {
         const int e = (k1 * i1) & (E - 1);
-        acc = acc + (e ? v[k1] * tw_ext_inv[(size_t)e * n] : v[k1]);
+        acc = acc + (e ? fr29_mul_const(v[k1], tw_ext_inv[(size_t)e * n]) : v[k1]);
       }
       o[i1] = acc;
     }
     Fr *dst = out + c * n * E;
 #pragma unroll
-    for (int i1 = 0; i1 < E; ++i1) dst[(size_t)i1 * n + i2] = o[i1] * scale[(size_t)i1 * n + i2];
+    for (int i1 = 0; i1 < E; ++i1) dst[(size_t)i1 * n + i2] = fr29_mul_const(o[i1], scale[(size_t)i1 * n + i2]);
   }
 }
 
@@ -212,6 +213,14 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
     ZK_LAUNCH_CHECK(ctx);
     k_pow_table<<<grid, 256, 0, ctx->stream>>>(d.omega_inv, d.inv, n);
     ZK_LAUNCH_CHECK(ctx);
+    const Fr c32 = zk_fr_to_29(Fr::one());   // 32 in the standard Montgomery form
+    d.n_inv29 = d.n_inv * c32;
+    ZK_HIP(ctx, hipMalloc((void **)&d.fwd29, n * sizeof(Fr)));
+    ZK_HIP(ctx, hipMalloc((void **)&d.inv29, n * sizeof(Fr)));
+    k_pow_table_scaled<<<grid, 256, 0, ctx->stream>>>(c32, d.omega, d.fwd29, n);
+    ZK_LAUNCH_CHECK(ctx);
+    k_pow_table_scaled<<<grid, 256, 0, ctx->stream>>>(c32, d.omega_inv, d.inv29, n);
+    ZK_LAUNCH_CHECK(ctx);
     it = ctx->domains.emplace(log_n, d).first;
   }
   *out = &it->second;
@@ -240,12 +249,12 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
     rc = zk_scratch(ctx, 3, 64, &p);
     if (rc) return rc;
     ninv_dev = (Fr *)p;
-    ZK_HIP(ctx, hipMemcpyAsync(ninv_dev, &dom->n_inv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(ninv_dev, &dom->n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
   }
   if (log_n < 3) {
     // tiny transforms: DIF stages then a bit-reversed gather is overkill; do log_n DIF stages and fix order on 2/4 points
     // n = 2: one stage is the whole transform (bitrev of 1 bit is identity).  n = 4: outputs 1 and 2 swapped.
-    const Fr *tw = inverse ? dom->inv : dom->fwd;
+    const Fr *tw = inverse ? dom->inv29 : dom->fwd29;
     for (int s = log_n - 1; s >= 0; --s) {
       k_dif_stage<<<zk_blocks(n_cols * (n / 2), 256), 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
       ZK_LAUNCH_CHECK(ctx);
@@ -277,7 +286,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
     a.out = data;
     a.in_tile_stride = n;
     a.col_stride_in = a.col_stride_out = n;
-    a.tw = inverse ? dom->inv : dom->fwd;
+    a.tw = inverse ? dom->inv29 : dom->fwd29;
     a.pre = nullptr;
     a.post = ninv_dev;
     a.log_tiles = 0;
@@ -287,7 +296,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   }
   // large: DIF stages down to 2^13 blocks, then tile NTT per block with bit-reversed strided scatter
   const int log_tiles = log_n - MAX_TILE_LOG;
-  const Fr *tw = inverse ? dom->inv : dom->fwd;
+  const Fr *tw = inverse ? dom->inv29 : dom->fwd29;
   for (int s = log_n - 1; s >= MAX_TILE_LOG;) {
     const int left = s - MAX_TILE_LOG + 1;
     const int S = left >= 3 ? 3 : left;       // fuse up to three stages per pass over memory
@@ -312,7 +321,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   a.out = (Fr *)p;
   a.in_tile_stride = (size_t)1 << MAX_TILE_LOG;
   a.col_stride_in = a.col_stride_out = n;
-  a.tw = inverse ? tdom->inv : tdom->fwd;
+  a.tw = inverse ? tdom->inv29 : tdom->fwd29;
   a.post = ninv_dev;
   a.log_tiles = log_tiles;
   a.in_len = 1 << MAX_TILE_LOG;
@@ -341,8 +350,9 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   if (rc) return rc;
   Fr *pre = (Fr *)p;
   Fr shift = g;
-  for (int k1 = 0; k1 < rows; ++k1) {
-    k_pow_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(shift, pre + (size_t)k1 * n, n);
+  const Fr c32 = zk_fr_to_29(Fr::one());
+  for (int k1 = 0; k1 < rows; ++k1) {   // (g w_ext^k1)^i as constant operands of the nine-limb multiply (2^261 form)
+    k_pow_table_scaled<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(c32, shift, pre + (size_t)k1 * n, n);
     ZK_LAUNCH_CHECK(ctx);
     shift = shift * edom->omega;
   }
@@ -360,7 +370,7 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   a.in_tile_stride = 0;
   a.col_stride_in = n;
   a.col_stride_out = nr;
-  a.tw = dom->fwd;
+  a.tw = dom->fwd29;
   a.pre = pre;
   a.pre_tile_stride = n;
   a.post = nullptr;
@@ -394,8 +404,9 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     if (rc) return rc;
     Fr *pre = (Fr *)p;
     Fr shift = g;
+    const Fr c32 = zk_fr_to_29(Fr::one());
     for (int k1 = 0; k1 < E; ++k1) {
-      k_pow_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(shift, pre + (size_t)k1 * n, n);
+      k_pow_table_scaled<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(c32, shift, pre + (size_t)k1 * n, n);
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * edom->omega;
     }
@@ -414,7 +425,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     a.in_tile_stride = 0;  // every coset row of a column starts from the same n coefficients
     a.col_stride_in = n;
     a.col_stride_out = ne;
-    a.tw = dom->fwd;
+    a.tw = dom->fwd29;
     a.pre = pre;
     a.pre_tile_stride = n;
     a.post = nullptr;
@@ -441,12 +452,12 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     Fr *scale2 = (Fr *)p;
     const Fr einv2 = fp_inv<FrP>(zk_fr_from_u64((uint64_t)E));
     const Fr ginv2 = fp_inv<FrP>(g);
-    k_pow_table_scaled<<<zk_blocks(ne, 256), 256, 0, ctx->stream>>>(einv2, ginv2, scale2, ne);
+    k_pow_table_scaled<<<zk_blocks(ne, 256), 256, 0, ctx->stream>>>(zk_fr_to_29(einv2), ginv2, scale2, ne);
     ZK_LAUNCH_CHECK(ctx);
     unsigned grid2 = zk_blocks(n_cols * n, 256);
-    if (lef == 1) k_ext_combine<1><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv, scale2);
-    else if (lef == 2) k_ext_combine<2><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv, scale2);
-    else k_ext_combine<3><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv, scale2);
+    if (lef == 1) k_ext_combine<1><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv29, scale2);
+    else if (lef == 2) k_ext_combine<2><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv29, scale2);
+    else k_ext_combine<3><<<grid2, 256, 0, ctx->stream>>>(rows2, (Fr *)out_dev, n_cols, log_n, edom->inv29, scale2);
     ZK_LAUNCH_CHECK(ctx);
     return ZKFHE_OK;
   }
@@ -456,14 +467,14 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
   void *q;
   rc = zk_scratch(ctx, 3, 64, &q);
   if (rc) return rc;
-  ZK_HIP(ctx, hipMemcpyAsync(q, &dom->n_inv, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipMemcpyAsync(q, &dom->n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
   TileArgs a{};
   a.in = (const Fr *)in_dev;
   a.out = rows;
   a.in_tile_stride = n;
   a.col_stride_in = ne;
   a.col_stride_out = ne;
-  a.tw = dom->inv;
+  a.tw = dom->inv29;
   a.post = (const Fr *)q;
   a.log_tiles = lef;
   a.in_len = (int)n;
@@ -476,12 +487,12 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
   Fr *scale = (Fr *)p;
   Fr einv = fp_inv<FrP>(zk_fr_from_u64((uint64_t)E));
   Fr ginv = fp_inv<FrP>(g);
-  k_pow_table_scaled<<<zk_blocks(ne, 256), 256, 0, ctx->stream>>>(einv, ginv, scale, ne);
+  k_pow_table_scaled<<<zk_blocks(ne, 256), 256, 0, ctx->stream>>>(zk_fr_to_29(einv), ginv, scale, ne);
   ZK_LAUNCH_CHECK(ctx);
   unsigned grid = zk_blocks(n_cols * n, 256);
-  if (lef == 1) k_ext_combine<1><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv, scale);
-  else if (lef == 2) k_ext_combine<2><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv, scale);
-  else k_ext_combine<3><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv, scale);
+  if (lef == 1) k_ext_combine<1><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv29, scale);
+  else if (lef == 2) k_ext_combine<2><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv29, scale);
+  else k_ext_combine<3><<<grid, 256, 0, ctx->stream>>>(rows, (Fr *)out_dev, n_cols, log_n, edom->inv29, scale);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
