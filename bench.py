@@ -25,9 +25,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-MODMUL_PEAK_G = 125.0        # G Montgomery products / s, all 256 CUs busy: measured, tools/microbench.py fr_mul (profiles/r1_microbench.md)
+# Issue-rate bound of the field product the MSM kernels use (radix 2^29, 162 v_mad_u64_u32 per product, csrc/fq29.cuh):
+# 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (5.3 cycles per multiply-add issue x 162) = 183 G products / s, counting the
+# multiply-adds only (the 5.3 cycles are profiles/r1_microbench.md's probe).  The same product in a bare squaring loop reaches
+# 168 G/s (tools/microbench.py modmul29_per_s, profiles/r2_microbench.md); the 8 x 32-bit product it replaced 125 G/s.
+MODMUL_PEAK_G = 183.0
 MODMUL_PER_MIXED_ADD = 10.0  # XYZZ += affine: 8 M + 2 S (the first addition into an empty accumulator is free and still counted; the fused Y3 makes it 9.5 reductions)
 Q, T, B, N = 536870909, 7, 19, 1024
+# --config: BASELINE.json configs[1] (the headline), configs[3] and configs[4]
+CONFIGS = {"k13": dict(k=13, N=1024, Q=536870909), "k16": dict(k=16, N=4096, Q=(1 << 60) - 93), "k19": dict(k=19, N=16384, Q=(1 << 60) - 93)}
 
 
 def synth_bfv_input(seed):
@@ -62,7 +68,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=12, help="concurrent proofs per GPU (one HIP stream + workspace each)")
+    ap.add_argument("--streams", type=int, default=0, help="concurrent proofs per GPU (one HIP stream + workspace each); 0 = 16 at k13, 2 at k16, 1 at k19")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="k13", help="k13 = the headline (BASELINE configs[1]); k16 / k19 = configs[3] / [4], single GPU")
+    ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra, separately reported steady-state pass (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
                     help="Fiat-Shamir hash: poseidon = snark-verifier PoseidonTranscript (the reference's, examples/bfv.rs:311); blake2b = halo2's own")
@@ -87,12 +95,26 @@ def main():
     import zk_fhe_amd as zk
 
     ctx = zk.Context(local_rank)
+    conf = CONFIGS[args.config]
+    big = args.config != "k13"
+    if not args.streams:
+        args.streams = {"k13": 16, "k16": 2, "k19": 1}[args.config]
     cfgj = json.load(open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv_config.json")))
-    zcfg = zk.BfvConfig.from_pinning(cfgj, transcript=args.transcript)
-    empty = json.dumps({k: ["0"] * (N + 1 if k == "cyclo" else N) for k in ("pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo")})
-    srs = zk.Srs(ctx, 13)
-    pk = zk.BfvProvingKey(ctx, srs, empty, (N, Q, T, B), zcfg, replay=True)
-    inputs = [synth_bfv_input(20240613 + 1000 * rank + i).encode() for i in range(4)]   # the JSON text the C ABI takes
+    if not big:
+        zcfg = zk.BfvConfig.from_pinning(cfgj, transcript=args.transcript)
+        n_ring, q_mod = N, Q
+        empty = json.dumps({k: ["0"] * (N + 1 if k == "cyclo" else N) for k in ("pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo")})
+        # the reference's own data/bfv/bfv.in verbatim (tests/golden/bfv is a byte-identical copy), then seeded synthetic encryptions
+        inputs = [open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv.in"), "rb").read()]
+        inputs += [synth_bfv_input(20240613 + 1000 * rank + i).encode() for i in range(3)]   # the JSON text the C ABI takes
+    else:
+        from zk_fhe_amd import inputs as gen
+        n_ring, q_mod = conf["N"], conf["Q"]
+        inputs = [json.dumps(gen.generate(n_ring, q_mod, T, B, seed=20240613 + 1000 * rank + i)).encode() for i in range(2)]
+        empty = json.dumps(gen.empty(n_ring))
+        zcfg = zk.bfv_auto_config(inputs[0], (n_ring, q_mod, T, B), conf["k"], transcript=args.transcript)   # halo2-base auto-configuration
+    srs = zk.Srs(ctx, conf["k"])
+    pk = zk.BfvProvingKey(ctx, srs, empty, (n_ring, q_mod, T, B), zcfg, replay=not big)
     seeds = [b"bench-%d-%d" % (rank, i) for i in range(args.steps + args.warmup + 4)]
 
     def barrier():
@@ -105,21 +127,21 @@ def main():
     import zk_fhe_amd.batch as batch
     n_streams = max(1, min(args.streams, args.steps))
     ctxs = [ctx] + [zk.Context(local_rank) for _ in range(n_streams - 1)]
-    stage = np.zeros(5)
+    acc = np.zeros(5)
     proof_len = [0]
     lock = threading.Lock()
 
     def one_proof(c, j):
-        proof, inst, tm = pk.prove(inputs[j % 4], seeds[j % len(seeds)], ctx=c)
+        proof, inst, tm = pk.prove(inputs[j % len(inputs)], seeds[j % len(seeds)], ctx=c)
         with lock:
-            stage[:] += np.array(tm)
+            acc[:] += np.array(tm)
             proof_len[0] = len(proof)
         return proof
 
     # warm-up: every stream proves once (allocates its workspace), then W more proofs
     batch.run_concurrent(list(range(n_streams)), ctxs, one_proof)
     batch.run_concurrent(list(range(n_streams, n_streams + args.warmup)), ctxs, one_proof)
-    stage[:] = 0
+    acc[:] = 0
     si = n_streams + args.warmup
     barrier()
     t0 = time.perf_counter()
@@ -132,26 +154,38 @@ def main():
     host_cpu_ms = (time.process_time() - cpu0) * 1e3 / max(1, args.steps)   # all threads of this rank
     si += args.steps
     dt = batch.max_over_ranks(dt, device="cuda" if (world > 1 and backend == "nccl") else None)
-    stage /= max(1, args.steps)
+    stage = acc / max(1, args.steps)    # a copy: the passes below keep adding to acc
+    # steady state, reported separately (never the headline): the driver's --steps may be a single wave of concurrent proofs,
+    # whose rate is (proofs) / (latency of the slowest); this pass keeps every stream busy for >= steady_seconds
+    steady = None
+    if args.steady_seconds > 0:
+        n_more = max(4 * n_streams, int(args.steady_seconds * world * args.steps / dt))
+        ts = time.perf_counter()
+        batch.run_concurrent(list(range(si, si + n_more)), ctxs, one_proof)
+        for c in ctxs:
+            c.sync()
+        steady = n_more / (time.perf_counter() - ts)
+        si += n_more
 
     # dominant kernel (k_msm_accumulate) timed live with HIP events on the library's stream, in a separate untimed pass
     ctx.prof_enable(True)
     for _ in range(2):
-        pk.prove(inputs[si % 4], seeds[si % len(seeds)])
+        pk.prove(inputs[si % len(inputs)], seeds[si % len(seeds)])
     msm = ctx.prof_read(0)
     ntt = ctx.prof_read(1)
+    direct = ctx.prof_read(2)
     ctx.prof_enable(False)
 
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, rocprofv3 --pmc)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["bytes_per_launch"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["bytes_per_launch"] if not big else None
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
         ach = msm["algorithmic_bytes"] / (msm["total_ms"] * 1e-3) / 1e9
         ntt_ach = ntt["algorithmic_bytes"] / (ntt["total_ms"] * 1e-3) / 1e9 if ntt["launches"] else None
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not big:
             # the oracle prover (Python orchestration + OpenMP C kernels) on ONE proof of the same workload
             from oracle import binding as orc
             from oracle import circuit_ref as C
@@ -168,23 +202,27 @@ def main():
                    "sample": "1 full k=13 proof by the oracle prover (oracle/halo2_ref.py: Python + OpenMP C); same bytes as the GPU proof: %s"
                              % (gpu_proof == proof_o)}
         out = {
-            "metric": "BFV proofs/sec (k=13)", "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
+            "metric": "BFV proofs/sec (k=%d)" % conf["k"], "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if world == 1 else None,
+            "scaling": "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if (world == 1 and not big) else None,
             "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
-            "config": {"workload": "one proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout",
+            "config": {"workload": ("one proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout; "
+                                    "inputs: the reference's data/bfv/bfv.in + 3 seeded synthetic encryptions") if not big else
+                                   "one proof per step, k=%d, N=%d, Q=2^60-93 (BASELINE configs[%d]); columns by halo2-base auto-configuration"
+                                   % (conf["k"], conf["N"], 3 if args.config == "k16" else 4),
                        "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
+                       "steady_state_proofs_per_s": steady,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
                          "launches_per_proof": msm["launches"] / 2,
                          # the bound that actually binds this kernel (SURVEY.md 8(d) "secondary, honest bound"): 256-bit modular
-                         # multiplications.  11 per mixed XYZZ addition; peak = the v_mad_u64_u32 Montgomery product rate
-                         # measured on this chip with tools/microbench.py (profiles/r1_microbench.md)
+                         # multiplications, 10 per mixed XYZZ addition, against the multiply-add issue bound (MODMUL_PEAK_G above)
                          "int_alu": {"achieved": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9, "peak": MODMUL_PEAK_G,
                                      "unit": "G modmul/s", "frac": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G,
                                      "mixed_additions_per_proof": msm["ops"] / 2},
+                         "msm_direct": {"avg_launch_ms": direct["total_ms"] / max(1, direct["launches"]), "launches_per_proof": direct["launches"] / 2},
                          "ntt_tile": {"achieved": ntt_ach, "int_alu_frac": (ntt["ops"] / (ntt["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G) if ntt["launches"] else None, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
             "cpu_baseline": cpu,
         }

@@ -123,6 +123,32 @@ size_t zkfhe_basis_len(const zkfhe_basis *basis);
 int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols,
                     zkfhe_g1_affine *out_dev);
 
+/* ---- intra-proof multi-GPU: commitments sharded by point range (replaces nothing in the reference,
+ * whose prover is single-process -- the seam is again best_multiexp inside ParamsKZG::{commit, commit_lagrange}) ----------
+ * One process per GPU.  Rank r of W owns the bases [n r / W, n (r+1) / W) of each SRS half and the same rows of every
+ * column; zkfhe_msm_batch_sharded computes its partial sums, all-gathers the 64-byte affine partials as raw bytes
+ * (ncclAllGather of ncclUint8 over RCCL / xGMI, on the context's stream) and adds them on every rank, so all ranks hold the
+ * same commitments, the same transcript and the same proof bytes as a single GPU.  An SRS made with
+ * zkfhe_srs_create_sharded carries the communicator: zkfhe_bfv_keygen / zkfhe_bfv_prove then shard every commitment with
+ * no further change (every rank calls them with the same inputs and seed).
+ * zkfhe_comm_create needs librccl.so at run time (dlopen; nothing is linked).  zkfhe_comm_create_with_transport takes a host
+ * all-gather callback instead (MPI, gloo, a test shim): recv = the `world` send buffers of `bytes` bytes each, rank-major;
+ * return 0 on success. */
+typedef struct zkfhe_comm zkfhe_comm;
+typedef int (*zkfhe_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
+int zkfhe_comm_unique_id(uint8_t id_out[128]);   /* rank 0: ncclGetUniqueId, to be passed to the other ranks out of band */
+int zkfhe_comm_create(zkfhe_ctx *ctx, int rank, int world, const uint8_t unique_id[128], zkfhe_comm **out);
+int zkfhe_comm_create_with_transport(zkfhe_ctx *ctx, int rank, int world, zkfhe_allgather_fn allgather, void *user, zkfhe_comm **out);
+int zkfhe_comm_destroy(zkfhe_ctx *ctx, zkfhe_comm *comm);
+int zkfhe_comm_rank(const zkfhe_comm *comm);
+int zkfhe_comm_world(const zkfhe_comm *comm);
+void zkfhe_comm_point_range(const zkfhe_comm *comm, size_t n, size_t *lo, size_t *hi);
+int zkfhe_comm_all_gather(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes);
+/* basis_slice: a basis made of this rank's point range; column c's scalars for that range at scalars_dev + c * col_stride
+ * (col_stride = the full column length when scalars_dev points at row lo of column 0).  out_dev[c]: the full MSM, on every rank. */
+int zkfhe_msm_batch_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev,
+                            size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev);
+
 /* ---- G1 helpers (device, used by tests and by the SRS builder) ------------------------------ */
 /* out[i] = a[i] + b[i] (affine in, affine out; handles doubling / inverse / identity) */
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a_dev, const zkfhe_g1_affine *b_dev,
@@ -213,6 +239,9 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
  * caller): 2^k points g[i] = s^i G and g_lagrange[i] = L_i(s) G, host memory, affine, Montgomery limbs (halo2curves'
  * in-memory G1Affine).  The library only builds its MSM tables from them; nothing is checked about the ceremony. */
 int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_host, const zkfhe_g1_affine *g_lagrange_host, zkfhe_srs **out);
+/* The same seeded setup, but only this rank's point range of both halves (1 / world of the table memory); keygen and prove
+ * called with it shard every commitment over `comm` (see "intra-proof multi-GPU").  comm must outlive the SRS. */
+int zkfhe_srs_create_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out);
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs);
 
 /* keygen (README.md:28-38): circuit structure from the (empty) input, fixed + sigma polynomials, their
@@ -238,6 +267,13 @@ int zkfhe_bfv_pk_export_vk(const zkfhe_bfv_pk *pk, uint8_t *out, size_t cap, siz
  * gamma.  cells_out == NULL only returns the cell count. */
 int zkfhe_bfv_witness_stream(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, const char *input_json, const uint8_t gamma_le[32], uint8_t *cells_out,
                              size_t cap_cells, size_t *n_cells);
+/* Lookup argument, step 1 (halo2 lookup::prover `permute_expression_pair`) for the 8-bit table
+ * {0..255} over `usable_rows` rows: column c (Montgomery Fr, n rows) -> A' = the inputs sorted, S' = the table permuted so
+ * that S'[i] = A'[i] wherever A'[i] differs from A'[i-1], the unused table values filling the other rows in ascending
+ * order.  Rows >= usable_rows of the outputs are left untouched (the prover blinds them).  *not_in_table = 1 if an input
+ * exceeds 255.  One workgroup per column. */
+int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols, size_t n, uint32_t usable_rows, zkfhe_fr *a_dev,
+                         zkfhe_fr *s_dev, int *not_in_table);
 /* Proving key on disk (the reference's keygen writes data/<name>.pk, README.md:38): configuration, break points, commitments
  * and the fixed / permutation columns; the extended-domain tables are rebuilt on load.  A key is bound to the SRS it was
  * generated with. */

@@ -309,3 +309,41 @@ def test_msm_point_range_sharding(ctx):
     full = zk.Basis(ctx, bases)
     assert np.array_equal(B.ShardedMsm(ctx, full, 0, 1).msm(S), want)
     full.destroy()
+
+
+def test_lookup_permute_matches_halo2_semantics(ctx):
+    """SURVEY.md 8a row P4 in isolation: k_lookup_permute against the oracle's restatement of halo2's
+    permute_expression_pair (oracle/halo2_ref.py permute_lookup) -- sorted inputs, table aligned at every first occurrence,
+    leftover table values in ascending order -- on uniform, constant, two-valued and saturated columns; an input above 255
+    raises the flag."""
+    import ctypes
+    from oracle import halo2_ref as H
+    rng = np.random.default_rng(4)
+    n, u = 8192, 8192 - 107
+    cfg = H.Config(13, 1, 1, 1, 1, 109)
+    assert cfg.u == u
+    table = list(range(256)) + [0] * (n - 256)
+    cols = [[int(v) for v in rng.integers(0, 256, u)],
+            [7] * u,
+            [int(v) for v in rng.choice([0, 255], u)],
+            [i % 256 for i in range(u)],
+            [0] * (u - 1) + [255]]
+    S = np.stack([orc.ints_to_mont(c + [123456789] * (n - u)) for c in cols])   # rows >= u hold junk: they must be ignored
+    d = ctx.to_device(S)
+    a, s = ctx.alloc(len(cols) * n * 32), ctx.alloc(len(cols) * n * 32)
+    vp = ctypes.c_void_p
+    ctx.lib.zkfhe_lookup_permute.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, vp, vp, ctypes.POINTER(ctypes.c_int)]
+    flag = ctypes.c_int(-1)
+    ctx._check(ctx.lib.zkfhe_lookup_permute(ctx.h, d.at(0), len(cols), n, u, a.at(0), s.at(0), ctypes.byref(flag)))
+    assert flag.value == 0
+    ga, gs = a.download(shape=(len(cols), n, 4)), s.download(shape=(len(cols), n, 4))
+    for i, c in enumerate(cols):
+        wa, ws = H.permute_lookup(cfg, c, table)
+        assert orc.mont_to_ints(ga[i][:u]) == wa and orc.mont_to_ints(gs[i][:u]) == ws, "column %d" % i
+    bad = list(cols[0])
+    bad[100] = 256
+    d2 = ctx.to_device(orc.ints_to_mont(bad + [0] * (n - u))[None])
+    ctx._check(ctx.lib.zkfhe_lookup_permute(ctx.h, d2.at(0), 1, n, u, a.at(0), s.at(0), ctypes.byref(flag)))
+    assert flag.value == 1
+    for b in (d, d2, a, s):
+        b.free()

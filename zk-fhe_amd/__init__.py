@@ -25,12 +25,14 @@ EXPORTS = [
     "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
     "zkfhe_g1_add", "zkfhe_g1_mul",
+    "zkfhe_comm_unique_id", "zkfhe_comm_create", "zkfhe_comm_create_with_transport", "zkfhe_comm_destroy", "zkfhe_comm_rank", "zkfhe_comm_world",
+    "zkfhe_comm_point_range", "zkfhe_comm_all_gather", "zkfhe_msm_batch_sharded", "zkfhe_srs_create_sharded",
     "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",
     "zkfhe_bfv_build_tables", "zkfhe_bfv_auto_config", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points", "zkfhe_bfv_mock_check", "zkfhe_bfv_tables_poke_advice",
     "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info",
-    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
     "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
     "zkfhe_poseidon_permute", "zkfhe_poseidon_constants",
@@ -576,14 +578,74 @@ def bfv_mock(input_json_text, params, config, gamma=7, pokes=()):
 
 
 # ----------------------------------------------------------------------------- SRS / keygen / prove (GPU)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class Comm:
+    """zkfhe_comm: the ranks that shard the commitments of one proof (one process per GPU).
+    unique_id (128 bytes from Comm.unique_id() on rank 0, shared out of band): RCCL over xGMI, ncclAllGather on the context's
+    stream.  all_gather (callable: bytes -> list of `world` byte strings, e.g. zk_fhe_amd.batch.all_gather_bytes over gloo):
+    a host transport instead, for tests and for hosts with their own."""
+
+    def __init__(self, ctx, rank, world, unique_id=None, all_gather=None):
+        lib = ctx.lib
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = ctypes.c_void_p()
+        lib.zkfhe_comm_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if all_gather is not None or world == 1:
+            def cb(_user, send, nbytes, recv):
+                try:
+                    parts = all_gather(ctypes.string_at(send, nbytes))
+                    data = b"".join(parts)
+                    if len(data) != nbytes * world:
+                        return 1
+                    ctypes.memmove(recv, data, len(data))
+                    return 0
+                except Exception:  # noqa: BLE001  (must not propagate into C)
+                    return 1
+            self._cb = ALLGATHER_FN(cb)   # kept alive for the lifetime of the communicator
+            lib.zkfhe_comm_create_with_transport.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ALLGATHER_FN, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+            ctx._check(lib.zkfhe_comm_create_with_transport(ctx.h, rank, world, self._cb, None, ctypes.byref(self.h)))
+        else:
+            lib.zkfhe_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+            ctx._check(lib.zkfhe_comm_create(ctx.h, rank, world, bytes(unique_id), ctypes.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = ctypes.create_string_buffer(128)
+        rc = lib.zkfhe_comm_unique_id(buf)
+        if rc != 0:
+            raise ZkfheError("zkfhe_comm_unique_id failed (%d): is librccl.so available?" % rc)
+        return buf.raw
+
+    def point_range(self, n):
+        lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+        self.ctx.lib.zkfhe_comm_point_range.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+        self.ctx.lib.zkfhe_comm_point_range.restype = None
+        self.ctx.lib.zkfhe_comm_point_range(self.h, n, ctypes.byref(lo), ctypes.byref(hi))
+        return lo.value, hi.value
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.zkfhe_comm_destroy(self.ctx.h, self.h)
+            self.h = ctypes.c_void_p()
+
+
 class Srs:
-    def __init__(self, ctx, k, seed=b"zkfhe-unsafe-srs"):
+    def __init__(self, ctx, k, seed=b"zkfhe-unsafe-srs", comm=None):
+        """comm: a Comm -> only this rank's point range of both halves is built and every commitment of keygen / prove is
+        sharded over the communicator (zkfhe_srs_create_sharded)."""
         lib = ctx.lib
         lib.zkfhe_srs_create.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        lib.zkfhe_srs_create_sharded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
         lib.zkfhe_srs_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        self.ctx, self.k = ctx, k
+        self.ctx, self.k, self.comm = ctx, k, comm
         h = ctypes.c_void_p()
-        ctx._check(lib.zkfhe_srs_create(ctx.h, k, bytes(seed), len(seed), ctypes.byref(h)))
+        if comm is None:
+            ctx._check(lib.zkfhe_srs_create(ctx.h, k, bytes(seed), len(seed), ctypes.byref(h)))
+        else:
+            ctx._check(lib.zkfhe_srs_create_sharded(ctx.h, comm.h, k, bytes(seed), len(seed), ctypes.byref(h)))
         self.h = h
 
     @classmethod

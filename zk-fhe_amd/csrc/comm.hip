@@ -1,0 +1,201 @@
+// Intra-proof multi-GPU: one process per GPU, the big commitments of ONE proof sharded by point range over the ranks
+// (BASELINE config 5 "windows split across 8 GPUs + ncclAllGather").
+//
+// Rank r owns the bases [lo_r, hi_r) of an SRS half (its own per-window table, 1/W of the memory) and reads the same rows of
+// every column: its partial MSM is a group element, sum_r partial_r is the commitment.  EC addition is not an RCCL reduction
+// op, so the 64-byte affine partials are all-gathered as raw bytes (n_cols * 64 B per rank -- latency-bound on xGMI, one
+// collective per commitment batch) and every rank adds the W partials of each column itself: all ranks end with the same
+// points, hence the same transcript and the same proof bytes as a single GPU.
+//
+// Transport: RCCL (librccl.so, resolved with dlopen at zkfhe_comm_create so that single-GPU users do not need it) --
+// ncclAllGather of ncclUint8 on the context's stream, device buffers, no host round trip.  For tests and for hosts that
+// bring their own transport (MPI, gloo, a Rust channel) zkfhe_comm_create_with_transport takes a host all-gather callback
+// instead; the partials then go through pinned host memory.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctx.hpp"
+
+using namespace zk;
+
+namespace {
+
+// the slice of the RCCL API that is used (rccl.h is not needed at build time)
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+enum { NCCL_UINT8 = 1 };   // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = std::string("librccl.so not found: ") + dlerror();
+      return false;
+    }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather) {
+      err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+      return false;
+    }
+    return true;
+  }
+};
+Rccl &rccl() {
+  static Rccl r;
+  return r;
+}
+
+// out[c] = sum_r parts[r * n_cols + c]   (affine in, affine out; one thread per column, W - 1 additions and one inversion)
+__global__ void __launch_bounds__(64) k_sum_partials(const G1Affine *__restrict__ parts, unsigned world, size_t n_cols, G1Affine *__restrict__ out) {
+  const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  G1X acc = g1x_from_affine(parts[c]);
+  for (unsigned r = 1; r < world; ++r) g1x_add_affine(acc, parts[(size_t)r * n_cols + c], false);
+  out[c] = g1x_to_affine(acc);
+}
+
+}  // namespace
+
+struct zkfhe_comm {
+  int rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  zkfhe_allgather_fn transport = nullptr;   // host callback instead of RCCL
+  void *transport_user = nullptr;
+  uint8_t *host_send = nullptr, *host_recv = nullptr;   // pinned staging of the callback transport
+  size_t host_cap = 0;
+};
+
+extern "C" {
+
+int zkfhe_comm_unique_id(uint8_t id_out[128]) {
+  if (!id_out) return ZKFHE_EINVAL;
+  if (!rccl().load()) return ZKFHE_ENODEV;
+  ncclUniqueId id;
+  if (rccl().GetUniqueId(&id) != 0) return ZKFHE_EHIP;
+  memcpy(id_out, id.internal, 128);
+  return ZKFHE_OK;
+}
+
+int zkfhe_comm_create(zkfhe_ctx *ctx, int rank, int world, const uint8_t unique_id[128], zkfhe_comm **out) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, out != nullptr && world >= 1 && rank >= 0 && rank < world);
+  *out = nullptr;
+  zkfhe_comm *c = new zkfhe_comm();
+  c->rank = rank;
+  c->world = world;
+  if (world > 1) {
+    ZK_ARG(ctx, unique_id != nullptr);
+    if (!rccl().load()) {
+      delete c;
+      return zk_fail_msg(ctx, ZKFHE_ENODEV, rccl().err);
+    }
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id, 128);
+    const ncclResult_t rc = rccl().CommInitRank(&c->nccl, world, id, rank);
+    if (rc != 0) {
+      delete c;
+      return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("ncclCommInitRank failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
+    }
+  }
+  *out = c;
+  return ZKFHE_OK;
+}
+
+int zkfhe_comm_create_with_transport(zkfhe_ctx *ctx, int rank, int world, zkfhe_allgather_fn allgather, void *user, zkfhe_comm **out) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, out != nullptr && world >= 1 && rank >= 0 && rank < world && (world == 1 || allgather != nullptr));
+  zkfhe_comm *c = new zkfhe_comm();
+  c->rank = rank;
+  c->world = world;
+  c->transport = allgather;
+  c->transport_user = user;
+  *out = c;
+  return ZKFHE_OK;
+}
+
+int zkfhe_comm_destroy(zkfhe_ctx *ctx, zkfhe_comm *comm) {
+  ZK_ENTER(ctx);
+  if (!comm) return ZKFHE_OK;
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  if (comm->nccl) rccl().CommDestroy(comm->nccl);
+  if (comm->host_send) (void)hipHostFree(comm->host_send);
+  if (comm->host_recv) (void)hipHostFree(comm->host_recv);
+  delete comm;
+  return ZKFHE_OK;
+}
+
+int zkfhe_comm_rank(const zkfhe_comm *comm) { return comm ? comm->rank : 0; }
+int zkfhe_comm_world(const zkfhe_comm *comm) { return comm ? comm->world : 1; }
+
+void zkfhe_comm_point_range(const zkfhe_comm *comm, size_t n, size_t *lo, size_t *hi) {
+  const size_t w = comm ? (size_t)comm->world : 1, r = comm ? (size_t)comm->rank : 0;
+  if (lo) *lo = n * r / w;
+  if (hi) *hi = n * (r + 1) / w;
+}
+
+// every rank: send_dev (bytes) -> recv_dev (world * bytes, rank-major), on the context's stream
+int zkfhe_comm_all_gather(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, comm != nullptr && send_dev != nullptr && recv_dev != nullptr);
+  if (comm->world == 1) return zk_copy_d2d(ctx, recv_dev, send_dev, bytes);
+  if (comm->nccl) {
+    const ncclResult_t rc = rccl().AllGather(send_dev, recv_dev, bytes, NCCL_UINT8, comm->nccl, ctx->stream);
+    if (rc != 0) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("ncclAllGather failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
+    return ZKFHE_OK;
+  }
+  // callback transport: through pinned host memory
+  if (comm->host_cap < bytes * (size_t)comm->world) {
+    if (comm->host_send) (void)hipHostFree(comm->host_send);
+    if (comm->host_recv) (void)hipHostFree(comm->host_recv);
+    comm->host_cap = bytes * (size_t)comm->world;
+    ZK_HIP(ctx, hipHostMalloc((void **)&comm->host_send, comm->host_cap, hipHostMallocDefault));
+    ZK_HIP(ctx, hipHostMalloc((void **)&comm->host_recv, comm->host_cap, hipHostMallocDefault));
+  }
+  ZK_HIP(ctx, hipMemcpyAsync(comm->host_send, send_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, zk_wait(ctx));
+  if (comm->transport(comm->transport_user, comm->host_send, bytes, comm->host_recv) != 0) return zk_fail_msg(ctx, ZKFHE_EINVAL, "all-gather transport callback failed");
+  ZK_HIP(ctx, hipMemcpyAsync(recv_dev, comm->host_recv, bytes * (size_t)comm->world, hipMemcpyHostToDevice, ctx->stream));
+  return ZKFHE_OK;
+}
+
+int zkfhe_msm_batch_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev, size_t col_stride,
+                            size_t n_cols, zkfhe_g1_affine *out_dev) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, comm != nullptr && basis_slice != nullptr);
+  if (!n_cols) return ZKFHE_OK;
+  if (comm->world == 1) return zk_msm_batch_strided(ctx, basis_slice, scalars_dev, col_stride, n_cols, out_dev);
+  // scratch slot 3: [my partials | everyone's partials]  (slots 0..2 belong to the MSM itself)
+  void *p;
+  int rc = zk_scratch(ctx, 3, (size_t)(comm->world + 1) * n_cols * sizeof(G1Affine) + 64, &p);
+  if (rc) return rc;
+  G1Affine *mine = (G1Affine *)((char *)p + 64), *all = mine + n_cols;
+  rc = zk_msm_batch_strided(ctx, basis_slice, scalars_dev, col_stride, n_cols, (zkfhe_g1_affine *)mine);
+  if (rc) return rc;
+  rc = zkfhe_comm_all_gather(ctx, comm, mine, all, n_cols * sizeof(G1Affine));
+  if (rc) return rc;
+  k_sum_partials<<<zk_blocks(n_cols, 64), 64, 0, ctx->stream>>>(all, (unsigned)comm->world, n_cols, (G1Affine *)out_dev);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+}  // extern "C"

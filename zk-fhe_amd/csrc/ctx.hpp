@@ -103,6 +103,8 @@ inline hipError_t zk_wait(zkfhe_ctx *ctx) {
   return hipEventSynchronize(ctx->wait_ev);
 }
 
+// zkfhe_msm_batch with a column stride (msm.hip)
+int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev);
 // returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse
 int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
 // stream-ordered device-to-device copy (own kernel for large blocks)

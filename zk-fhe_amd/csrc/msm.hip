@@ -95,7 +95,7 @@ __device__ __forceinline__ void for_each_digit(const Fr &mont, int c, int window
 constexpr unsigned SORT_CHUNK = 2048;   // scalars per workgroup
 constexpr unsigned SORT_THREADS = 512;
 
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_hist(const Fr *__restrict__ scalars, size_t n, unsigned chunks_per_col, int c, int windows,
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_hist(const Fr *__restrict__ scalars, size_t col_stride, size_t n, unsigned chunks_per_col, int c, int windows,
                                                           unsigned *__restrict__ hist /* [n_cols][K+1] */, unsigned K1) {
   extern __shared__ unsigned lh[];
   const size_t col = blockIdx.x / chunks_per_col;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_hist(const Fr *__restrict_
   __syncthreads();
   const size_t i0 = (size_t)chunk * SORT_CHUNK, i1 = min(n, i0 + SORT_CHUNK);
   for (size_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS)
-    for_each_digit(scalars[col * n + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[b], 1u); });
+    for_each_digit(scalars[col * col_stride + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[b], 1u); });
   __syncthreads();
   unsigned *h = hist + col * K1;
   for (unsigned b = threadIdx.x; b < K1; b += SORT_THREADS) {
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_msm_scan(const unsigned *__restrict__ h
 // scatter: count in LDS again, reserve one contiguous range per (workgroup, bucket) with a single global atomic,
 // then rank the entries inside the range with LDS atomics: entries of a bucket coming from one workgroup land next
 // to each other (fewer partial-line stores), and global atomics drop from one per entry to one per non-empty bin.
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restrict__ scalars, size_t n, unsigned chunks_per_col, int c, int windows,
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restrict__ scalars, size_t col_stride, size_t n, unsigned chunks_per_col, int c, int windows,
                                                              unsigned *__restrict__ cursor, unsigned K1, unsigned *__restrict__ entries,
                                                              size_t col_entries) {
   extern __shared__ unsigned lh[];  // [K1] counts, then running positions
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
   __syncthreads();
   const size_t i0 = (size_t)chunk * SORT_CHUNK, i1 = min(n, i0 + SORT_CHUNK);
   for (size_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS)
-    for_each_digit(scalars[col * n + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[b], 1u); });
+    for_each_digit(scalars[col * col_stride + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[b], 1u); });
   __syncthreads();
   unsigned *cu = cursor + col * K1;
   for (unsigned b = threadIdx.x; b < K1; b += SORT_THREADS) {
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
   __syncthreads();
   unsigned *e = entries + col * col_entries;
   for (size_t i = i0 + threadIdx.x; i < i1; i += SORT_THREADS)
-    for_each_digit(scalars[col * n + i], c, windows, [&](int w, u32 b, bool neg) {
+    for_each_digit(scalars[col * col_stride + i], c, windows, [&](int w, u32 b, bool neg) {
       const unsigned pos = atomicAdd(&lh[b], 1u);
       e[pos] = ((unsigned)w * (unsigned)n + (unsigned)i) | (neg ? 0x80000000u : 0u);
     });
@@ -628,7 +628,7 @@ __device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [4] */) {
 // consecutive scalars).  Signed digits without a carry chain: with B = 0x88..8, nibble_w(s + B) - 8 is in [-8, 7], the digits
 // sum to s, and the zero nibbles of a short scalar stay zero digits.
 template <int E>
-__global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scalars, size_t n, const G1Affine *__restrict__ mult,
+__global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scalars, size_t col_stride, size_t n, const G1Affine *__restrict__ mult,
                                                     unsigned blocks_per_col, G1X *__restrict__ partials /* [n_cols][blocks_per_col] */,
                                                     unsigned *__restrict__ tickets /* [n_cols], zero on entry and on exit */,
                                                     G1Affine *__restrict__ out) {
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scala
   const unsigned w0 = (unsigned)(t / n) * E;
   G1X29 acc = G1X29::identity();
   if (w0 < (unsigned)DM_WINDOWS) {
-    Fr s = fp_from_mont<FrP>(scalars[(size_t)col * n + i]);
+    Fr s = fp_from_mont<FrP>(scalars[(size_t)col * col_stride + i]);
     const bool neg = fr_gt_half(s);
     if (neg) s = fp_neg<FrP>(s);
     // s + 0x8888...8: no overflow (s < 2^253)
@@ -748,7 +748,7 @@ size_t direct_max_terms() {
   return (size_t)v;
 }
 
-int msm_direct(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t n_cols, G1Affine *out) {
+int msm_direct(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t col_stride, size_t n_cols, G1Affine *out) {
   const size_t n = basis->n;
   if (!ctx->tickets) {
     ZK_HIP(ctx, hipMalloc((void **)&ctx->tickets, 256 * sizeof(unsigned)));
@@ -765,10 +765,10 @@ int msm_direct(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size
   const unsigned grid = (unsigned)(n_cols * blocks_per_col);
   zk_prof_begin(ctx);
   switch (E) {
-    case 8: k_msm_direct<8><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-    case 16: k_msm_direct<16><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-    case 32: k_msm_direct<32><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-    default: k_msm_direct<64><<<grid, 256, 0, ctx->stream>>>(scalars, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    case 8: k_msm_direct<8><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    case 16: k_msm_direct<16><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    case 32: k_msm_direct<32><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
+    default: k_msm_direct<64><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
   }
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 2, 96.0 * (double)n * (double)n_cols);
@@ -839,12 +839,21 @@ int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis) {
 size_t zkfhe_basis_len(const zkfhe_basis *basis) { return basis ? basis->n : 0; }
 
 int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols, zkfhe_g1_affine *out_dev) {
+  return zk_msm_batch_strided(ctx, basis, scalars_dev, basis ? basis->n : 0, n_cols, out_dev);
+}
+
+}  // extern "C"
+
+// Column c of the call holds its basis->n scalars at scalars_dev + c * col_stride: col_stride > n selects a row range of longer
+// columns (the point-range shard of one rank, comm.hip) without copying it out.
+int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, basis != nullptr);
   if (!n_cols) return ZKFHE_OK;
-  ZK_ARG(ctx, scalars_dev != nullptr && out_dev != nullptr);
+  ZK_ARG(ctx, scalars_dev != nullptr && out_dev != nullptr && col_stride >= basis->n);
   const size_t n = basis->n;
-  if (basis->mult && n_cols <= 256 && n_cols * n <= direct_max_terms()) return msm_direct(ctx, basis, (const Fr *)scalars_dev, n_cols, (G1Affine *)out_dev);
+  if (basis->mult && n_cols <= 256 && n_cols * n <= direct_max_terms())
+    return msm_direct(ctx, basis, (const Fr *)scalars_dev, col_stride, n_cols, (G1Affine *)out_dev);
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
@@ -891,11 +900,11 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
     ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     sort_attr = true;
   }
-  k_msm_hist<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, n, chunks_per_col, c, W, hist, K1);
+  k_msm_hist<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, hist, K1);
   ZK_LAUNCH_CHECK(ctx);
   k_msm_scan<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(hist, off, cursor, K1);
   ZK_LAUNCH_CHECK(ctx);
-  k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
+  k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
   ZK_LAUNCH_CHECK(ctx);
   k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_hist);
   ZK_LAUNCH_CHECK(ctx);
@@ -967,6 +976,8 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   }
   return zk_fail_msg(ctx, ZKFHE_EINVAL, "MSM basis with more than 32768 buckets (window_bits > 16) is not supported");
 }
+
+extern "C" {
 
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {
   ZK_ENTER(ctx);

@@ -47,7 +47,18 @@ struct zkfhe_srs {
   // the same Lagrange points with narrower windows, for columns of small values (advice, permuted lookups): their cost is
   // the per-bucket work (merge, marginals), not the additions, so 8x fewer buckets beats 30 % more windows
   zkfhe_basis *g_lagrange_small = nullptr;
+  // point-range shard (zkfhe_srs_create_sharded): the bases above hold points [lo, hi) only and every commitment goes through
+  // zkfhe_msm_batch_sharded over `comm`
+  zkfhe_comm *comm = nullptr;
+  size_t lo = 0, hi = 0;
+  bool sharded() const { return comm != nullptr && zkfhe_comm_world(comm) > 1; }
 };
+
+// commitment MSM of `n_cols` full columns (stride n): the whole basis, or this rank's rows + all-gather + sum
+static int srs_msm(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out) {
+  if (!srs->sharded()) return zkfhe_msm_batch(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_affine *)dev_out);
+  return zkfhe_msm_batch_sharded(ctx, srs->comm, basis, (const zkfhe_fr *)(cols + srs->lo), (size_t)1 << srs->k, n_cols, (zkfhe_g1_affine *)dev_out);
+}
 
 struct DevBuf {
   int device = 0;  // not the context: a workspace outlives the zkfhe_ctx it was made for if the caller destroys that first
@@ -147,8 +158,8 @@ int upload_canon(zkfhe_ctx *ctx, Fr *dst, const U256 *src, size_t count) {
 int up(zkfhe_ctx *ctx, Workspace *ws, void *dst, const void *src, size_t bytes);
 
 // commit `n_cols` columns (device, Montgomery) and return canonical affine points
-int commit_cols(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
-  CK(zkfhe_msm_batch(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_affine *)dev_out));
+int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
+  CK(srs_msm(ctx, srs, basis, cols, n_cols, dev_out));
   std::vector<G1Affine> h(n_cols);
   CK(zkfhe_download(ctx, h.data(), dev_out, n_cols * sizeof(G1Affine)));
   out.resize(n_cols);
@@ -186,10 +197,14 @@ struct zkfhe_bfv_pk {
 
 extern "C" {
 
-int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
+static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
   ZK_ENTER(ctx);
-  ZK_ARG(ctx, out != nullptr && k >= 3 && k <= 20);
+  ZK_ARG(ctx, out != nullptr && k >= 3 && k <= 20 && (seed != nullptr || seed_len == 0));
   const size_t n = (size_t)1 << k;
+  size_t lo = 0, hi = n;
+  if (comm) zkfhe_comm_point_range(comm, n, &lo, &hi);   // this rank's bases
+  const size_t nl = hi - lo;
+  ZK_ARG(ctx, nl > 0);
   Blake2b h(64, "zkfhe-srs");
   h.update(seed, seed_len);
   uint8_t d[64];
@@ -198,38 +213,41 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
   DevBuf sc, pts;
-  CK(sc.alloc(ctx, n * 32));
-  CK(pts.alloc(ctx, n * 64));
+  CK(sc.alloc(ctx, nl * 32));
+  CK(pts.alloc(ctx, nl * 64));
   G1Affine gen;
   gen.x = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 1; return t; }());
   gen.y = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 2; return t; }());
-  std::vector<G1Affine> host(n);
+  std::vector<G1Affine> host(nl);
   zkfhe_srs *srs = new zkfhe_srs();
   srs->k = k;
-  const unsigned gr = (unsigned)((n + 255) / 256);
+  srs->comm = comm;
+  srs->lo = lo;
+  srs->hi = hi;
+  const unsigned gr = (unsigned)((nl + 255) / 256);
   for (int which = 0; which < 2; ++which) {
     if (which == 0) {
-      zkp::k_powers<<<gr, 256, 0, ctx->stream>>>(Fr::one(), s, sc.fr(), n);
+      zkp::k_powers<<<gr, 256, 0, ctx->stream>>>(fr_pow(s, lo), s, sc.fr(), nl);   // s^(lo + i)
       ZK_LAUNCH_CHECK(ctx);
     } else {
-      zkp::k_srs_den<<<gr, 256, 0, ctx->stream>>>(dom->fwd, s, mont_u64(n), sc.fr(), n);
+      zkp::k_srs_den<<<gr, 256, 0, ctx->stream>>>(dom->fwd + lo, s, mont_u64(n), sc.fr(), nl);
       ZK_LAUNCH_CHECK(ctx);
-      CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)sc.p, n));
-      zkp::k_srs_li<<<gr, 256, 0, ctx->stream>>>(dom->fwd, fr_pow(s, n) - Fr::one(), sc.fr(), n);
+      CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)sc.p, nl));
+      zkp::k_srs_li<<<gr, 256, 0, ctx->stream>>>(dom->fwd + lo, fr_pow(s, n) - Fr::one(), sc.fr(), nl);
       ZK_LAUNCH_CHECK(ctx);
     }
-    zkp::k_fill_point<<<gr, 256, 0, ctx->stream>>>(gen, (G1Affine *)pts.p, n);
+    zkp::k_fill_point<<<gr, 256, 0, ctx->stream>>>(gen, (G1Affine *)pts.p, nl);
     ZK_LAUNCH_CHECK(ctx);
-    CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, n));
-    CK(zkfhe_download(ctx, host.data(), pts.p, n * 64));
-    CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), n, 0, which == 0 ? &srs->g : &srs->g_lagrange));
+    CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, nl));
+    CK(zkfhe_download(ctx, host.data(), pts.p, nl * 64));
+    CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, 0, which == 0 ? &srs->g : &srs->g_lagrange));
     if (which == 1) {
       static int small_c = -1;
       if (small_c < 0) {
         const char *e = getenv("ZKFHE_SMALL_C");
         small_c = e ? atoi(e) : 10;
       }
-      if (small_c > 0 && k >= 12 && k <= 14) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), n, small_c, &srs->g_lagrange_small));
+      if (small_c > 0 && k >= 12 && k <= 14) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, small_c, &srs->g_lagrange_small));
     }
   }
   sc.release();
@@ -238,12 +256,22 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
   return ZKFHE_OK;
 }
 
+int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
+  return srs_create_impl(ctx, nullptr, k, seed, seed_len, out);
+}
+
+int zkfhe_srs_create_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
+  if (!comm) return zk_fail_msg(ctx, ZKFHE_EINVAL, "comm is NULL");
+  return srs_create_impl(ctx, comm, k, seed, seed_len, out);
+}
+
 int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_host, const zkfhe_g1_affine *g_lagrange_host, zkfhe_srs **out) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, out != nullptr && g_host != nullptr && g_lagrange_host != nullptr && k >= 3 && k <= 20);
   const size_t n = (size_t)1 << k;
   zkfhe_srs *srs = new zkfhe_srs();
   srs->k = k;
+  srs->hi = n;
   int rc = zkfhe_basis_create(ctx, g_host, n, 0, &srs->g);
   if (!rc) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 0, &srs->g_lagrange);
   if (!rc && k >= 12 && k <= 14) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
@@ -547,8 +575,8 @@ int keygen_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *input_json, co
   // ---- commitments
   Workspace *ws;
   CK(get_workspace(ctx, pk, &ws));
-  CK(commit_cols(ctx, srs->g_lagrange, pk->fixed_l.fr(), cfg.n_fixed(), (G1Affine *)ws->points.p, pk->fixed_commit));
-  CK(commit_cols(ctx, srs->g_lagrange, pk->sigma_l.fr(), cfg.n_perm(), (G1Affine *)ws->points.p, pk->sigma_commit));
+  CK(commit_cols(ctx, srs, srs->g_lagrange, pk->fixed_l.fr(), cfg.n_fixed(), (G1Affine *)ws->points.p, pk->fixed_commit));
+  CK(commit_cols(ctx, srs, srs->g_lagrange, pk->sigma_l.fr(), cfg.n_perm(), (G1Affine *)ws->points.p, pk->sigma_commit));
   CK(build_resident_tables(ctx, pk, ws));
   CK(zkfhe_sync(ctx));
   tgt.release();
@@ -946,7 +974,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       if (th.joinable()) th.join();
     }
   } early;
-  early.th = std::thread([&, n] {
+  const bool early_rand = !srs->sharded();   // a sharded commitment is a collective: it stays on the main stream, in protocol order
+  if (early_rand) early.th = std::thread([&, n] {
     zkfhe_ctx *aux = ws->aux;
     (void)hipSetDevice(aux->device);
     Fr *rand_dev = ws->misc.fr() + 8 * n;
@@ -994,11 +1023,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // the few phase-0 columns go through the full-width basis: zkfhe_msm_batch takes its direct-sum path for them
   const zkfhe_basis *p0_basis = (size_t)cfg.n_gate0 * n <= ((size_t)1 << 15) ? srs->g_lagrange : small_basis;
   if (host_witness) {
-    CK(commit_cols(ctx, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+    CK(commit_cols(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   } else {
     // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
     CK(alloc_witness_buffers(ctx, pk, ws));
-    CK(zkfhe_msm_batch(ctx, p0_basis, (const zkfhe_fr *)ws->adv_l.fr(), cfg.n_gate0, (zkfhe_g1_affine *)ws->points.p));
+    CK(srs_msm(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p));
     ZK_HIP(ctx, hipMemcpyAsync(ws->host_pts, ws->points.p, cfg.n_gate0 * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
     CK(g1.launch(st));
@@ -1064,7 +1093,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(upload_canon(ctx, dst, hst, 2 * (size_t)cfg.n_lookup * nbl));
     ZK_HIP(ctx, hipMemcpy2DAsync(ws->la_l.fr() + u, n * 32, dst, nbl * 32, nbl * 32, 2 * cfg.n_lookup, hipMemcpyDeviceToDevice, ctx->stream));
     const size_t n_adv1 = cfg.n_advice() - cfg.n_gate0;
-    CK(commit_cols(ctx, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_adv1 + 2 * cfg.n_lookup, (G1Affine *)ws->points.p, pts));
+    CK(commit_cols(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_adv1 + 2 * cfg.n_lookup, (G1Affine *)ws->points.p, pts));
     int e = 0;
     CK(zkfhe_download(ctx, &e, lookup_err, 4));
     if (e) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
@@ -1072,7 +1101,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ls_commit.assign(pts.begin() + n_adv1 + cfg.n_lookup, pts.end());
     pts.resize(n_adv1);
   } else {
-    CK(commit_cols(ctx, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+    CK(commit_cols(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   }
   trace.mark("commit phase 1 (GPU)");
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
@@ -1092,7 +1121,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       }
       ZK_HIP(ctx, hipMemcpyAsync(ws->la_l.p, ws->host_blind, 2 * (size_t)cfg.n_lookup * n * 32, hipMemcpyHostToDevice, ctx->stream));
       CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
-      CK(commit_cols(ctx, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
+      CK(commit_cols(ctx, srs, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
       ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
       la_commit.resize(cfg.n_lookup);
     }
@@ -1180,7 +1209,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_HIP(ctx, hipMemcpy2DAsync(ws->lz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nl, hipMemcpyDeviceToDevice, ctx->stream));
   }
   std::vector<AffinePoint> pz_commit, lz_commit;
-  CK(commit_cols(ctx, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, (G1Affine *)ws->points.p, pz_commit));  // pz | lz contiguous
+  CK(commit_cols(ctx, srs, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, (G1Affine *)ws->points.p, pz_commit));  // pz | lz contiguous
   lz_commit.assign(pz_commit.begin() + nch, pz_commit.end());
   pz_commit.resize(nch);
   for (const auto &p : pz_commit) tr.write_point(p);
@@ -1189,12 +1218,20 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Fr *rand_c = ws->misc.fr() + 8 * n, *rand_l = ws->misc.fr() + 9 * n, *H_c = ws->misc.fr() + 10 * n, *H_l = ws->misc.fr() + 11 * n;
   // committed at the start of the proof on the auxiliary stream (see below "random polynomial, early"); its n draws are the
   // last of the blinding stream, consumed here
-  rng.skip(n);
-  early.th.join();
-  if (early.rc) return zk_fail_msg(ctx, early.rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(ws->aux));
-  ZK_HIP(ctx, hipEventSynchronize(ws->ev_rand));
-  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_rand, 0));   // later reads of rand_c on the main stream
-  tr.write_point(point_canon(*ws->host_rand_pt));
+  if (early_rand) {
+    rng.skip(n);
+    early.th.join();
+    if (early.rc) return zk_fail_msg(ctx, early.rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(ws->aux));
+    ZK_HIP(ctx, hipEventSynchronize(ws->ev_rand));
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_rand, 0));   // later reads of rand_c on the main stream
+    tr.write_point(point_canon(*ws->host_rand_pt));
+  } else {
+    for (size_t i = 0; i < n; ++i) ws->host_rand[i] = rng.next();
+    CK(upload_canon(ctx, rand_c, ws->host_rand, n));
+    std::vector<AffinePoint> rand_commit;
+    CK(commit_cols(ctx, srs, srs->g, rand_c, 1, (G1Affine *)ws->points.p, rand_commit));
+    tr.write_point(rand_commit[0]);
+  }
   const Fr y = mont(tr.squeeze());
   const double t_commit = now_ms();
   trace.mark("grand products + commits");
@@ -1310,7 +1347,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     }
   }
   std::vector<AffinePoint> h_commit;
-  CK(commit_cols(ctx, srs->g, ws->h_c.fr(), 3, (G1Affine *)ws->points.p, h_commit));
+  CK(commit_cols(ctx, srs, srs->g, ws->h_c.fr(), 3, (G1Affine *)ws->points.p, h_commit));
   if (q_rows == 4) {
     // the quotient must have degree < 3n: a non-zero top quarter means a violated constraint
     std::vector<U256> top(8);
@@ -1508,7 +1545,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   zkp::k_sh_h<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, zs, dom->fwd, n, hq);
   ZK_LAUNCH_CHECK(ctx);
   std::vector<AffinePoint> hq_commit, w_commit;
-  CK(commit_cols(ctx, srs->g_lagrange, hq, 1, (G1Affine *)ws->points.p, hq_commit));
+  CK(commit_cols(ctx, srs, srs->g_lagrange, hq, 1, (G1Affine *)ws->points.p, hq_commit));
   tr.write_point(hq_commit[0]);
   const Fr uu = mont(tr.squeeze());
   {
@@ -1537,7 +1574,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     zkp::k_sh_w<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, hq, ztu, dinv, n, Wq);
     ZK_LAUNCH_CHECK(ctx);
   }
-  CK(commit_cols(ctx, srs->g_lagrange, Wq, 1, (G1Affine *)ws->points.p, w_commit));
+  CK(commit_cols(ctx, srs, srs->g_lagrange, Wq, 1, (G1Affine *)ws->points.p, w_commit));
   tr.write_point(w_commit[0]);
   proof = tr.out;
   const double t_end = now_ms();
@@ -1841,6 +1878,19 @@ int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk
   } catch (const std::exception &e) {
     return zk_fail_msg(ctx, ZKFHE_EINVAL, e.what());
   }
+}
+
+// halo2's permute_expression_pair for the 8-bit range table, as the prover runs it (gpu_witness.cuh k_lookup_permute): the
+// parity hook of SURVEY.md section 8a row P4.
+int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols, size_t n, uint32_t usable_rows, zkfhe_fr *a_dev, zkfhe_fr *s_dev, int *not_in_table) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, cols_dev && a_dev && s_dev && not_in_table && n_cols > 0 && n_cols < 65536 && usable_rows <= n && usable_rows >= 256);
+  void *flag;
+  CK(zk_scratch(ctx, 3, 64, &flag));
+  ZK_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+  zkw::k_lookup_permute<<<(unsigned)n_cols, 1024, 0, ctx->stream>>>((const Fr *)cols_dev, n, usable_rows, (Fr *)a_dev, (Fr *)s_dev, (int *)flag);
+  ZK_LAUNCH_CHECK(ctx);
+  return zkfhe_download(ctx, not_in_table, flag, 4);
 }
 
 // The phase-1 gate stream exactly as the GPU witness generator produces it (gpu_witness.cuh), for a caller-chosen
