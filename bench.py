@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-# Issue-rate bound of the field product the MSM kernels use (radix 2^29, 162 v_mad_u64_u32 per product, csrc/fq29.cuh):
+# Issue-rate bound of the field product the MSM kernels use (radix 2^29, 162 v_mad_u64_u32 per product, csrc/fq29.hip.hpp):
 # 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / (5.3 cycles per multiply-add issue x 162) = 183 G products / s, counting the
 # multiply-adds only (the 5.3 cycles are profiles/r1_microbench.md's probe).  The same product in a bare squaring loop reaches
 # 168 G/s (tools/microbench.py modmul29_per_s, profiles/r2_microbench.md); the 8 x 32-bit product it replaced 125 G/s.
@@ -98,7 +98,9 @@ def main():
     conf = CONFIGS[args.config]
     big = args.config != "k13"
     if not args.streams:
-        args.streams = {"k13": 16, "k16": 2, "k19": 1}[args.config]
+        # k13: 16 proofs in flight; a short run (the driver's --steps 20) goes out as ONE wave of concurrent proofs -- 16 + 4
+        # would leave the chip to four proofs for the second half of the timed region
+        args.streams = {"k13": args.steps if args.steps <= 32 else 16, "k16": 2, "k19": 1}[args.config]
     cfgj = json.load(open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv_config.json")))
     if not big:
         zcfg = zk.BfvConfig.from_pinning(cfgj, transcript=args.transcript)

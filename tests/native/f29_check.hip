@@ -1,6 +1,6 @@
-// Host-side check of csrc/fq29.cuh (the radix-2^29 field and point arithmetic of the MSM kernels) against the standard
-// 8 x 32-bit arithmetic of bn254.cuh, which tests/test_oracle_vectors.py / test_gpu_parity.py pin to the big-integer oracle.
-#include "fq29.cuh"
+// Host-side check of csrc/fq29.hip.hpp (the radix-2^29 field and point arithmetic of the MSM kernels) against the standard
+// 8 x 32-bit arithmetic of bn254.hip.hpp, which tests/test_oracle_vectors.py / test_gpu_parity.py pin to the big-integer oracle.
+#include "fq29.hip.hpp"
 #include <cstdio>
 #include <random>
 using namespace zk;

@@ -1,4 +1,4 @@
-#include "bn254.cuh"
+#include "bn254.hip.hpp"
 #include <cstdio>
 #include <random>
 using namespace zk;

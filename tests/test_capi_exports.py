@@ -40,7 +40,7 @@ def test_product_does_not_reference_oracle():
         if "_build" in base:
             continue
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".inc")):
                 txt = open(os.path.join(base, f), errors="ignore").read()
                 if re.search(r"(from|import)\s+oracle|oracle/[a-z_]+\.(h|c)\"|liboracle", txt):
                     bad.append(f)

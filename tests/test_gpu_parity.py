@@ -69,7 +69,7 @@ def test_field_random_vs_oracle(ctx):
 
 
 def test_radix29_product_on_device(ctx):
-    """fq29.cuh on the GPU (the field arithmetic inside the MSM kernels): k squarings in the radix-2^29 Montgomery form
+    """fq29.hip.hpp on the GPU (the field arithmetic inside the MSM kernels): k squarings in the radix-2^29 Montgomery form
     (R' = 2^261) against python integers: x -> x^(2^k) * R'^-(2^k - 1) mod q, for random, tiny and q - 1 inputs."""
     import ctypes
     rng = np.random.default_rng(29)

@@ -1,4 +1,4 @@
-"""fp_inv (safegcd division steps, zk-fhe_amd/csrc/bn254.cuh) against the binary-Euclid inversion and against
+"""fp_inv (safegcd division steps, zk-fhe_amd/csrc/bn254.hip.hpp) against the binary-Euclid inversion and against
 a * a^-1 == 1, for Fr and Fq: 200 k random values plus powers of two, p - 1, p - 2 and short values.  The field code is
 host+device; this runs its host instantiation (no GPU)."""
 import os
@@ -23,7 +23,7 @@ def test_safegcd_inverse_matches_euclid(tmp_path):
 
 
 def test_radix29_field_and_point_arithmetic(tmp_path):
-    """csrc/fq29.cuh (nine 29-bit limbs, Montgomery constant 2^261, lazy reduction -- the arithmetic of the MSM kernels) against
+    """csrc/fq29.hip.hpp (nine 29-bit limbs, Montgomery constant 2^261, lazy reduction -- the arithmetic of the MSM kernels) against
     the standard 8 x 32-bit arithmetic: products, fused products with operands up to 11 p, weak / canonical reduction, the
     zero test on differences, pack / unpack, and mixed / full additions and doublings including the doubling-through-addition
     and cancellation cases.  Host instantiation of the same host+device code (no GPU)."""

@@ -1,5 +1,5 @@
 // Prototype: carry-free Montgomery product in radix 2^29 (9 limbs, R = 2^261) against the 8x32 FIPS product.
-#include "../../zk-fhe_amd/csrc/bn254.cuh"
+#include "../../zk-fhe_amd/csrc/bn254.hip.hpp"
 #include <cstdio>
 #include <vector>
 using namespace zk;

@@ -31,7 +31,7 @@ def main():
         ts.append(ctx.timer_stop_ms())
     ms = float(np.median(ts))
     res["modmul_per_s"] = n * iters / (ms * 1e-3)
-    # the radix-2^29 product of the MSM kernels (fq29.cuh), same loop
+    # the radix-2^29 product of the MSM kernels (fq29.hip.hpp), same loop
     for _ in range(2):
         ctx._check(ctx.lib.zkfhe_fq29_sqr_chain(ctx.h, d.at(0), o.at(0), n, iters))
     ts = []

@@ -49,7 +49,7 @@ def newest_header(host):
     dirs = (CSRC, os.path.join(HERE, "..", "include")) + ((os.path.join(HERE, "host"),) if host else ())
     for d in dirs:
         for f in os.listdir(d):
-            if f.endswith((".cuh", ".hpp", ".h")):
+            if f.endswith((".hpp", ".h", ".inc")):
                 t = max(t, os.path.getmtime(os.path.join(d, f)))
     return t
 

@@ -4,7 +4,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
-#include "fq29.cuh"
+#include "fq29.hip.hpp"
 
 using namespace zk;
 
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) k_fr_sqr_chain(const Fr *__restrict__ a, 
   out[i] = x;
 }
 
-// the same probe for the radix-2^29 product of the MSM kernels (fq29.cuh): packed 256-bit words in, nine limbs in registers
+// the same probe for the radix-2^29 product of the MSM kernels (fq29.hip.hpp): packed 256-bit words in, nine limbs in registers
 __global__ void __launch_bounds__(256) k_fq29_sqr_chain(const Fq *__restrict__ a, Fq *__restrict__ out, size_t n, int iters) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;

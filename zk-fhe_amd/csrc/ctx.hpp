@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "../../include/zkfhe.h"
-#include "bn254.cuh"
+#include "bn254.hip.hpp"
 
 struct NttDomain {
   int log_n = 0;
@@ -15,7 +15,7 @@ struct NttDomain {
   zk::Fr *inv = nullptr;  // omega^-j, j < n
   zk::Fr n_inv;           // (2^log_n)^-1
   zk::Fr omega, omega_inv;
-  // the same tables as constant operands of the nine-limb multiply (fr29.cuh: value * 2^261, i.e. 32 times the standard
+  // the same tables as constant operands of the nine-limb multiply (fr29.hip.hpp: value * 2^261, i.e. 32 times the standard
   // Montgomery form): what the NTT kernels read
   zk::Fr *fwd29 = nullptr, *inv29 = nullptr;
   zk::Fr n_inv29;

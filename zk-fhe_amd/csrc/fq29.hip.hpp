@@ -1,6 +1,6 @@
 // BN254 Fq in radix 2^29 (nine u32 limbs, Montgomery with R' = 2^261) for the EC kernels of the MSM.
 //
-// Why: the 8 x 32-bit product-scanning multiply (bn254.cuh fp_mul) spends half of its issue slots on carries -- every
+// Why: the 8 x 32-bit product-scanning multiply (bn254.hip.hpp fp_mul) spends half of its issue slots on carries -- every
 // v_mad_u64_u32 is followed by s_nop + v_addc_co_u32 (9.9 cycles per pair against 5.3 for the multiply-add alone,
 // profiles/r1_microbench.md).  With 29-bit limbs a column of a*b + m*p is at most 18 (27 for the fused two-product form)
 // terms below 2^58: they add up in ONE 64-bit accumulator with no carry-out, so a product is 162 plain multiply-adds and
@@ -14,7 +14,7 @@
 // Invariants: every F29 has limbs < 2^29 (the top limb holds whatever is left: values stay < 2^261); the comment of each
 // function states the bound on its VALUE (as a multiple of p) it needs and gives.
 #pragma once
-#include "bn254.cuh"
+#include "bn254.hip.hpp"
 
 namespace zk {
 

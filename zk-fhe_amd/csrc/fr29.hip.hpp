@@ -1,4 +1,4 @@
-// BN254 Fr in radix 2^29 (nine limbs, Montgomery constant 2^261): the scalar-field twin of fq29.cuh, used where a kernel
+// BN254 Fr in radix 2^29 (nine limbs, Montgomery constant 2^261): the scalar-field twin of fq29.hip.hpp, used where a kernel
 // multiplies data by table constants (the NTT twiddles, coset shifts, n^-1).
 //
 // A column value stays in the library's standard form x * 2^256 in memory; the CONSTANT is stored as w * 2^261, so that
@@ -6,7 +6,7 @@
 // with no conversion of the data beyond regrouping its bits into 29-bit limbs (27 shift/mask operations).
 // zk_fr_to_29() turns a standard constant into that form (times 32).
 #pragma once
-#include "fq29.cuh"
+#include "fq29.hip.hpp"
 
 namespace zk {
 namespace r29 {

@@ -24,7 +24,7 @@
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
 //
 // Field arithmetic of every kernel between the tables and the final normalisation: radix 2^29, nine limbs, Montgomery
-// constant 2^261 (fq29.cuh: 162 carry-free multiply-adds per product instead of 128 multiply-add + carry pairs, lazy
+// constant 2^261 (fq29.hip.hpp: 162 carry-free multiply-adds per product instead of 128 multiply-add + carry pairs, lazy
 // reduction in the point formulas).  The tables, partials, buckets and marginals hold packed 256-bit words in that
 // form; k_msm_weighted / k_msm_direct convert the one result per MSM back before normalising it.
 //
@@ -39,7 +39,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
-#include "fq29.cuh"
+#include "fq29.hip.hpp"
 
 using namespace zk;
 
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(256) k_basis_table(const G1Affine *__restrict_
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Affine p = bases[i];
-  table[i] = g1_affine_to_29(p);   // the tables hold the 2^261 Montgomery form of the MSM kernels (fq29.cuh)
+  table[i] = g1_affine_to_29(p);   // the tables hold the 2^261 Montgomery form of the MSM kernels (fq29.hip.hpp)
   G1X cur = g1x_from_affine(p);
   for (int w = 1; w < windows; ++w) {
     cur = g1x_mul_pow2(cur, c);

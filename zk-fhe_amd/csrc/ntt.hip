@@ -21,8 +21,8 @@
 #include <cstring>
 
 #include "ctx.hpp"
-#include "ntt_tile.cuh"
-#include "fr29.cuh"
+#include "ntt_tile.hip.hpp"
+#include "fr29.hip.hpp"
 
 using namespace zk;
 

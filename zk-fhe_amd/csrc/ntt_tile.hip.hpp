@@ -3,7 +3,7 @@
 // sizes build in parallel.
 #pragma once
 #include "ctx.hpp"
-#include "fr29.cuh"
+#include "fr29.hip.hpp"
 
 namespace zk {
 
@@ -15,7 +15,7 @@ __device__ __forceinline__ void set_hi(Fr &a, uint4 v) { a.l[4] = v.x; a.l[5] = 
 // padded LDS slot of logical position pos (one 16-byte slot per position, +1 slot every 8)
 __device__ __forceinline__ int pidx(int pos) { return pos + (pos >> 3); }
 
-// Arithmetic: radix 2^29, nine limbs per coefficient in registers (fr29.cuh).  A coefficient is the standard value
+// Arithmetic: radix 2^29, nine limbs per coefficient in registers (fr29.hip.hpp).  A coefficient is the standard value
 // x 2^256 (any representative below 2 r between passes), a twiddle is stored as w 2^261, so the nine-limb Montgomery
 // product of the two is the standard x w again.  Butterflies do not reduce: the comments give the bound of each value as a
 // multiple of r; a product needs operands below 11 r and returns less than 2 r, a pass ends in one weak reduction (< 16 r

@@ -1,5 +1,5 @@
 // One tile size of the NTT kernel per translation unit: compile with -DZK_TILE_LOGN=k (3..13).
-#include "ntt_tile.cuh"
+#include "ntt_tile.hip.hpp"
 
 #ifndef ZK_TILE_LOGN
 #error "define ZK_TILE_LOGN"

@@ -5,7 +5,7 @@
 #include <cstdint>
 #include <cstring>
 
-#include "../csrc/bn254.cuh"
+#include "../csrc/bn254.hip.hpp"
 #include "bigint.hpp"
 
 namespace zkhost {

@@ -17,8 +17,8 @@
 
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
-#include "gpu_witness.cuh"
-#include "prover_kernels.cuh"
+#include "gpu_witness.hip.hpp"
+#include "prover_kernels.hip.hpp"
 #include "shplonk.hpp"
 #include "transcript.hpp"
 #include "vk.hpp"
@@ -1316,7 +1316,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     if (q_rows == 4) {
       CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)ws->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));
     } else {
-      // three size-n inverse transforms, then the 3x3 Vandermonde solve per coefficient (prover_kernels.cuh: k_ext3_combine)
+      // three size-n inverse transforms, then the 3x3 Vandermonde solve per coefficient (prover_kernels.hip.hpp: k_ext3_combine)
       Fr *rows3 = ws->partials.fr();            // the partials are dead after the combine; 3n values
       Fr *pw = rows3 + 4 * n;                    // 3n values
       CK(zk_copy_d2d(ctx, rows3, ws->h_ext.p, 3 * n * 32));
@@ -1880,7 +1880,7 @@ int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk
   }
 }
 
-// halo2's permute_expression_pair for the 8-bit range table, as the prover runs it (gpu_witness.cuh k_lookup_permute): the
+// halo2's permute_expression_pair for the 8-bit range table, as the prover runs it (gpu_witness.hip.hpp k_lookup_permute): the
 // parity hook of SURVEY.md section 8a row P4.
 int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols, size_t n, uint32_t usable_rows, zkfhe_fr *a_dev, zkfhe_fr *s_dev, int *not_in_table) {
   ZK_ENTER(ctx);
@@ -1893,7 +1893,7 @@ int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols
   return zkfhe_download(ctx, not_in_table, flag, 4);
 }
 
-// The phase-1 gate stream exactly as the GPU witness generator produces it (gpu_witness.cuh), for a caller-chosen
+// The phase-1 gate stream exactly as the GPU witness generator produces it (gpu_witness.hip.hpp), for a caller-chosen
 // challenge: the cells of examples/bfv.rs:171-301 in halo2-base order, canonical values.  This is the parity hook of
 // tests compare it cell for cell with the oracle's restatement of src/poly_chip.rs.
 int zkfhe_bfv_witness_stream(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk_c, const char *input_json, const uint8_t gamma_le[32], uint8_t *cells_out,

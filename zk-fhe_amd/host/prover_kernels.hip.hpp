@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
   auto at = [&](const Fr *base, unsigned col, unsigned rot) -> Fr { return base[(size_t)col * ne + row0 + ((k2 + rot) & (n - 1))]; };
   const Fr one = Fr::one();
   Fr acc = Fr::zero();
-  // acc * y + u * v with one Montgomery reduction (bn254.cuh fp_mul2): the Horner step of every expression
+  // acc * y + u * v with one Montgomery reduction (bn254.hip.hpp fp_mul2): the Horner step of every expression
   auto horner = [&](const Fr &u, const Fr &v) { acc = zk::fp_mul2<zk::FrP>(acc, a.y, u, v); };
   switch (g.type) {
     case QG_GATE:
