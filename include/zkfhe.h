@@ -123,6 +123,14 @@ size_t zkfhe_basis_len(const zkfhe_basis *basis);
 int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols,
                     zkfhe_g1_affine *out_dev);
 
+/* A few non-zero scalars against a basis (one with a digit-multiple table: zkfhe_basis_has_multiples; n <= 2^16, default
+ * window bits): out_dev[slot] = sum of scalar * P_row over the terms of that slot, slot < n_slots.  scalar: Montgomery Fr.
+ * One wave per slot -- the right tool when a column is all zero except a handful of cells. */
+typedef struct { zkfhe_fr scalar; uint32_t row; uint32_t slot; } zkfhe_sparse_term;
+int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots,
+                     zkfhe_g1_affine *out_dev);
+int zkfhe_basis_has_multiples(const zkfhe_basis *basis);
+
 /* ---- intra-proof multi-GPU: commitments sharded by point range (replaces nothing in the reference,
  * whose prover is single-process -- the seam is again best_multiexp inside ParamsKZG::{commit, commit_lagrange}) ----------
  * One process per GPU.  Rank r of W owns the bases [n r / W, n (r+1) / W) of each SRS half and the same rows of every

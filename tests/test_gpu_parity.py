@@ -219,7 +219,7 @@ def test_msm_direct_sum_path(ctx, n, n_cols):
     for _ in range(2):
         assert np.array_equal(ctx.msm(B, S), want)
     # the same columns inside a call too wide for the direct path: the bucket pipeline must agree
-    reps = (1 << 15) // n // n_cols + 1
+    reps = (1 << 16) // n // n_cols + 1
     if n * n_cols * (reps + 1) <= (1 << 22):
         wide = np.concatenate([S] * (reps + 1))
         got = ctx.msm(B, wide)
@@ -347,3 +347,39 @@ def test_lookup_permute_matches_halo2_semantics(ctx):
     assert flag.value == 1
     for b in (d, d2, a, s):
         b.free()
+
+
+def test_msm_sparse_terms(ctx):
+    """zkfhe_msm_sparse (one wave per output over the digit-multiple table) against the oracle MSM of the same cells as full
+    columns: random rows, zero / one / r - 1 scalars, several cells per slot, an empty slot."""
+    import ctypes
+    import zk_fhe_amd as zk
+    rng = np.random.default_rng(77)
+    n, n_slots = 4096, 5
+    bases = _bases(n, seed=3)
+    B = zk.Basis(ctx, bases)
+    cells = [(int(rng.integers(0, n)), int(rng.integers(0, 4)), int.from_bytes(rng.bytes(32), "little") % pyref.R) for _ in range(14)]
+    cells += [(7, 0, 0), (8, 1, 1), (9, 2, pyref.R - 1), (7, 3, 5)]      # slot 4 stays empty
+    cols = [[0] * n for _ in range(n_slots)]
+    for row, slot, v in cells:
+        cols[slot][row] = (cols[slot][row] + v) % pyref.R
+    want = orc.msm(np.stack([orc.ints_to_mont(c) for c in cols]), bases)
+
+    class Term(ctypes.Structure):
+        _fields_ = [("scalar", ctypes.c_uint64 * 4), ("row", ctypes.c_uint32), ("slot", ctypes.c_uint32)]
+    arr = (Term * len(cells))()
+    mont = orc.ints_to_mont([v for _, _, v in cells])
+    for i, (row, slot, _) in enumerate(cells):
+        for j in range(4):
+            arr[i].scalar[j] = int(mont[i][j])
+        arr[i].row, arr[i].slot = row, slot
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    d = ctx.to_device(raw)
+    out = ctx.alloc(n_slots * 64)
+    vp = ctypes.c_void_p
+    ctx.lib.zkfhe_msm_sparse.argtypes = [vp, vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
+    assert ctx.lib.zkfhe_basis_has_multiples(B.h) == 1
+    ctx._check(ctx.lib.zkfhe_msm_sparse(ctx.h, B.h, d.at(0), len(cells), n_slots, out.at(0)))
+    assert np.array_equal(out.download(shape=(n_slots, 8)), want)
+    d.free(), out.free()
+    B.destroy()

@@ -24,7 +24,7 @@ EXPORTS = [
     "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain", "zkfhe_fq29_sqr_chain",
     "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
-    "zkfhe_g1_add", "zkfhe_g1_mul",
+    "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_basis_has_multiples",
     "zkfhe_comm_unique_id", "zkfhe_comm_create", "zkfhe_comm_create_with_transport", "zkfhe_comm_destroy", "zkfhe_comm_rank", "zkfhe_comm_world",
     "zkfhe_comm_point_range", "zkfhe_comm_all_gather", "zkfhe_msm_batch_sharded", "zkfhe_srs_create_sharded",
     "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",

@@ -729,6 +729,44 @@ __global__ void __launch_bounds__(256) k_g1_mul(const G1Affine *__restrict__ p, 
   out[i] = g1x_to_affine(acc);
 }
 
+// A handful of non-zero scalars against a basis with a digit-multiple table: out[slot] = sum over the cells of that slot of
+// scalar * P_row.  One wave per slot, lanes over (cell, window) pairs, a butterfly, one normalisation.  (The prover's early
+// phase-1 commitment: the 16 challenge-dependent gate cells of the constrain_mul gates, as corrections to <= 4 columns.)
+__global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__restrict__ terms, unsigned n_terms, size_t n, const G1Affine *__restrict__ mult,
+                                                   G1Affine *__restrict__ out) {
+  const unsigned slot = blockIdx.x, lane = threadIdx.x;
+  G1X29 acc = G1X29::identity();
+  for (unsigned t = 0; t < n_terms; ++t) {
+    if (terms[t].slot != slot) continue;
+    Fr s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s.l[2 * i] = (u32)terms[t].scalar.l[i];
+      s.l[2 * i + 1] = (u32)(terms[t].scalar.l[i] >> 32);
+    }
+    s = fp_from_mont<FrP>(s);
+    const bool neg = fr_gt_half(s);
+    if (neg) s = fp_neg<FrP>(s);
+    u32 carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u64 v = (u64)s.l[k] + 0x88888888u + carry;
+      s.l[k] = (u32)v;
+      carry = (u32)(v >> 32);
+    }
+    const int d = (int)((s.l[lane >> 3] >> ((lane & 7) * 4)) & 15u) - 8;   // window = lane
+    if (d) {
+      const G1Affine p = mult[((size_t)lane * n + terms[t].row) * DM_MULTS + (d < 0 ? -d : d) - 1];
+      g1x29_add_affine(acc, g1a29_load(p), neg != (d < 0));
+    }
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    const G1X29 other = g1x_shfl_xor(acc, m);
+    g1x29_add(acc, other);
+  }
+  if (lane == 0) out[slot] = g1x_to_affine(g1x29_to_std(acc));
+}
+
 // largest basis that gets a digit-multiple table, and the largest call (columns x n scalars) sent down the direct-sum path
 size_t direct_max_n() {
   static long v = -1;
@@ -743,7 +781,7 @@ size_t direct_max_terms() {
   static long v = -1;
   if (v < 0) {
     const char *e = getenv("ZKFHE_DIRECT_MAX_TERMS");
-    v = e ? atol(e) : (1L << 15);
+    v = e ? atol(e) : (1L << 16);
   }
   return (size_t)v;
 }
@@ -978,6 +1016,16 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
 }
 
 extern "C" {
+
+int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots, zkfhe_g1_affine *out_dev) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, basis != nullptr && basis->mult != nullptr && terms_dev != nullptr && out_dev != nullptr && n_slots > 0 && n_slots <= 65535 && n_terms <= 4096);
+  k_msm_sparse<<<(unsigned)n_slots, 64, 0, ctx->stream>>>(terms_dev, (unsigned)n_terms, basis->n, basis->mult, (G1Affine *)out_dev);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+int zkfhe_basis_has_multiples(const zkfhe_basis *basis) { return basis && basis->mult ? 1 : 0; }
 
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {
   ZK_ENTER(ctx);

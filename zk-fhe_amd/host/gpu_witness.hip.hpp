@@ -277,6 +277,19 @@ __global__ void __launch_bounds__(256) k_place(const Fr *__restrict__ stream, co
     cols[g] = r < col_len[c] ? stream[col_start[c] + r] : Fr::zero();
   }
 }
+// the four gate cells of every constrain_mul depend on the phase-1 challenge: they are written after the rest of the column was
+// committed (prover.hip "early phase-1 commitment") -- into the advice columns and into the sparse correction columns
+struct PatchCell {
+  Fr *dst_adv, *dst_patch;
+  unsigned value;   // index into the values array
+};
+__global__ void __launch_bounds__(64) k_patch_cells(const PatchCell *__restrict__ cells, unsigned count, const Fr *__restrict__ values) {
+  const unsigned i = threadIdx.x;
+  if (i >= count) return;
+  const Fr v = values[cells[i].value];
+  *cells[i].dst_adv = v;
+  *cells[i].dst_patch = v;
+}
 // lookup advice columns: the k-th looked-up cell goes to column k / max_rows, row k % max_rows
 __global__ void __launch_bounds__(256) k_place_lookups(const Fr *__restrict__ stream, const unsigned *__restrict__ src_off, size_t n_lookups,
                                                        unsigned max_rows, size_t n, unsigned n_lookup_cols, Fr *__restrict__ cols) {

@@ -99,13 +99,15 @@ struct Workspace {
   static constexpr size_t RING_BYTES = (size_t)4 << 20;
   G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
   hipEvent_t ev_pts = nullptr;
-  U256 *host_wblind = nullptr; // pinned staging for the blinding rows of device-generated columns
   // the random polynomial of the vanishing argument depends on no challenge: it is uploaded and committed at the start of
   // the proof on an auxiliary context (own stream, scratch and tickets) beside the phase-0 / witness work
   zkfhe_ctx *aux = nullptr;
-  U256 *host_rand = nullptr;   // pinned [n] coefficients
   G1Affine *host_rand_pt = nullptr;  // pinned: the commitment
   hipEvent_t ev_rand = nullptr;
+  // early phase-1 commitment (everything that does not depend on the phase-1 challenge): points + lookup error flag, pinned
+  G1Affine *host_early = nullptr;
+  int *host_early_err = nullptr;
+  hipEvent_t ev_early = nullptr;
   DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
   std::vector<DevBuf *> all() {
@@ -372,16 +374,14 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   CK(ws->pool.alloc(ctx, 40 * (2 * N + 8) * 32));
   CK(ws->invtmp.alloc(ctx, (pk->n_inv_slots + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pool, 24 * (2 * N + 8) * 32, hipHostMallocDefault));
-  // blinding rows of the device-generated advice columns, then those of the permuted lookup columns (staged back to back:
-  // both are in flight when the merged commitment is launched)
-  const size_t nblind = ((size_t)pk->cfg.n_gate1 + 3 * pk->cfg.n_lookup + 1) * (pk->cfg.n() - pk->cfg.u());
-  CK(ws->wblind.alloc(ctx, (nblind + 8) * 32));
-  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_wblind, (nblind + 8) * 32, hipHostMallocDefault));
+  CK(ws->wblind.alloc(ctx, 256));   // the lookup-permutation error flag
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->ring, Workspace::RING_BYTES, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming | hipEventBlockingSync));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_rand, hipEventDisableTiming | hipEventBlockingSync));
-  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_rand, pk->cfg.n() * 32, hipHostMallocDefault));
+  ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_early, hipEventDisableTiming | hipEventBlockingSync));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_early, ((size_t)pk->cfg.n_advice() + 2 * pk->cfg.n_lookup + 16) * sizeof(G1Affine), hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_early_err, 64, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_rand_pt, sizeof(G1Affine), hipHostMallocDefault));
   if (zkfhe_ctx_create(ctx->device, nullptr, &ws->aux)) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("auxiliary context: ") + zkfhe_last_error(nullptr));
   return ZKFHE_OK;
@@ -390,11 +390,12 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
 void free_workspace(Workspace *ws) {
   (void)hipSetDevice(ws->all_l.device);
   for (DevBuf *b : ws->all()) b->release();
-  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_wblind, (void *)ws->host_pts, (void *)ws->ring,
-                  (void *)ws->host_rand, (void *)ws->host_rand_pt})
+  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_pts, (void *)ws->ring, (void *)ws->host_rand_pt,
+                  (void *)ws->host_early, (void *)ws->host_early_err})
     if (h) (void)hipHostFree(h);
   if (ws->ev_pts) (void)hipEventDestroy(ws->ev_pts);
   if (ws->ev_rand) (void)hipEventDestroy(ws->ev_rand);
+  if (ws->ev_early) (void)hipEventDestroy(ws->ev_early);
   if (ws->aux) (void)zkfhe_ctx_destroy(ws->aux);
   delete ws;
 }
@@ -710,6 +711,88 @@ class GpuPhase1 {
     return ZKFHE_OK;
   }
 
+  // Everything of phase 1 except the cells that depend on the challenge: the reserved constrain_mul cells stay zero in the
+  // stream, then stream -> gate columns (break points) and lookup columns.  The columns can be committed from here on;
+  // patch() supplies the missing cells and the correction columns.
+  int place_early() {
+    for (unsigned i = 0; i < n_mg; ++i) ZK_HIP(ctx, hipMemsetAsync(stream + mg_off[i], 0, 4 * 32, ctx->stream));
+    return place();
+  }
+  // (gate column, row) of every reserved cell -- twice for a cell on a break point, whose value is repeated at the top of the
+  // next column.  columns: the distinct affected gate columns, in ascending order.
+  struct PatchPlan {
+    std::vector<unsigned> columns;
+    struct Cell {
+      unsigned col_slot, row, value;
+    };
+    std::vector<Cell> cells;
+  };
+  PatchPlan patch_plan() const {
+    PatchPlan p;
+    const CircuitConfig &cfg = pk->cfg;
+    std::vector<size_t> start(cfg.n_gate1, 0), len(cfg.n_gate1, 0);
+    size_t s = 0;
+    for (unsigned c = 0; c < cfg.n_gate1 && s < pk->gate1_cells; ++c) {
+      start[c] = s;
+      if (c < cfg.bp_gate1.size()) {
+        len[c] = (size_t)cfg.bp_gate1[c] + 1;
+        s += cfg.bp_gate1[c];
+      } else {
+        len[c] = pk->gate1_cells - s;
+        s = pk->gate1_cells;
+      }
+    }
+    for (unsigned i = 0; i < n_mg; ++i)
+      for (unsigned j = 0; j < 4; ++j) {
+        const size_t o = mg_off[i] + j;
+        for (unsigned c = 0; c < cfg.n_gate1; ++c)
+          if (len[c] && o >= start[c] && o < start[c] + len[c]) {
+            size_t slot = std::find(p.columns.begin(), p.columns.end(), c) - p.columns.begin();
+            if (slot == p.columns.size()) p.columns.push_back(c);
+            p.cells.push_back({(unsigned)slot, (unsigned)(o - start[c]), 4 * i + j});
+          }
+      }
+    return p;
+  }
+  // evals as in finish(): writes the reserved cells into the advice columns and into patch_cols[slot][row] (zeroed here);
+  // terms (optional): the same cells as sparse MSM terms (row, slot, scalar)
+  int patch(const U256 evals[12], const PatchPlan &plan, Fr *patch_cols, std::vector<zkfhe_sparse_term> *terms = nullptr) {
+    const CircuitConfig &cfg = pk->cfg;
+    const size_t n = cfg.n();
+    Fr mg[16];
+    for (int i = 0; i < 4; ++i) {
+      mg[4 * i] = Fr::zero();
+      for (int j = 0; j < 3; ++j) mg[4 * i + 1 + j] = mont(evals[3 * i + j]);
+    }
+    if (terms) {
+      terms->clear();
+      for (const auto &c : plan.cells) {
+        if ((c.value & 3) == 0) continue;   // the first cell of a gate is the constant 0
+        zkfhe_sparse_term t;
+        memcpy(&t.scalar, &mg[c.value], 32);
+        t.row = c.row;
+        t.slot = c.col_slot;
+        terms->push_back(t);
+      }
+    }
+    std::vector<zkw::PatchCell> cells(plan.cells.size());
+    for (size_t t = 0; t < cells.size(); ++t) {
+      const auto &c = plan.cells[t];
+      cells[t].dst_adv = ws->adv_l.fr() + ((size_t)cfg.n_gate0 + plan.columns[c.col_slot]) * n + c.row;
+      cells[t].dst_patch = patch_cols + (size_t)c.col_slot * n + c.row;
+      cells[t].value = c.value;
+    }
+    if (cells.size() > 64) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many challenge-dependent gate cells");
+    Fr *vals_dev = ws->pool.fr() + mg_slot;
+    zkw::PatchCell *cells_dev = (zkw::PatchCell *)((char *)ws->small.p + 900 * 1024);
+    CK(up(ctx, ws, vals_dev, mg, sizeof(mg)));
+    CK(up(ctx, ws, cells_dev, cells.data(), cells.size() * sizeof(zkw::PatchCell)));
+    ZK_HIP(ctx, hipMemsetAsync(patch_cols, 0, plan.columns.size() * n * 32, ctx->stream));
+    zkw::k_patch_cells<<<1, 64, 0, ctx->stream>>>(cells_dev, (unsigned)cells.size(), vals_dev);
+    ZK_LAUNCH_CHECK(ctx);
+    return ZKFHE_OK;
+  }
+
   // evals[3 i .. 3 i + 2] = a(gamma), b(gamma), c(gamma) of the i-th constrain_mul: fill the reserved gate cells, then
   // stream -> gate columns (break points) and lookup columns
   int finish(const U256 evals[12]) {
@@ -721,6 +804,11 @@ class GpuPhase1 {
     ZK_HIP(ctx, hipMemcpyAsync(ws->pool.fr() + mg_slot, mg_host, 16 * 32, hipMemcpyHostToDevice, ctx->stream));
     for (unsigned i = 0; i < n_mg; ++i)
       ZK_HIP(ctx, hipMemcpyAsync(stream + mg_off[i], ws->pool.fr() + mg_slot + 4 * i, 4 * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    return place();
+  }
+
+ private:
+  int place() {
     const CircuitConfig &cfg = pk->cfg;
     const size_t n = cfg.n();
     zkw::k_place<<<grid_for(ctx, (size_t)cfg.n_gate1 * n), 256, 0, ctx->stream>>>(stream, (const unsigned *)pk->place_start.p, (const unsigned *)pk->place_len.p,
@@ -736,7 +824,6 @@ class GpuPhase1 {
     return ZKFHE_OK;
   }
 
- private:
   zkfhe_ctx *ctx;
   const zkfhe_bfv_pk *pk;
   Workspace *ws;
@@ -867,56 +954,6 @@ bool witness_on_host() {
   return e && strcmp(e, "host") == 0;
 }
 
-// The blinding stream is counter based (Blake2b(seed || i)), so all draws of a proof -- their number is fixed by the
-// circuit shape -- are produced by a helper thread while the witness is being generated; next() hands them out in order.
-class PreRng {
- public:
-  // The stream is counter based, so the values do not depend on the order they are computed in: the draws are cut into
-  // HEAD_PARTS ranges plus the `tail` (the random polynomial, needed first), one helper thread each.
-  static constexpr int HEAD_PARTS = 4;
-  PreRng(const uint8_t seed[32], size_t total, size_t tail) : vals(total) {
-    memcpy(sd, seed, 32);
-    const size_t head = total - tail;
-    for (int p = 0; p <= HEAD_PARTS; ++p) lo[p] = head * p / HEAD_PARTS;
-    lo[HEAD_PARTS + 1] = total;
-    for (int p = 0; p <= HEAD_PARTS; ++p) {
-      done[p].store(lo[p], std::memory_order_relaxed);
-      th[p] = std::thread([this, p] {
-        Rng r(sd);
-        r.ctr = lo[p];
-        for (size_t i = lo[p]; i < lo[p + 1]; ++i) {
-          vals[i] = r.next();
-          if ((i & 63) == 63 || i + 1 == lo[p + 1]) done[p].store(i + 1, std::memory_order_release);
-        }
-      });
-    }
-  }
-  ~PreRng() {
-    for (auto &t : th)
-      if (t.joinable()) t.join();
-  }
-  U256 next() {
-    if (idx >= vals.size()) throw std::logic_error("blinding stream exhausted");
-    while (idx >= lo[part + 1]) ++part;
-    while (done[part].load(std::memory_order_acquire) <= idx) std::this_thread::sleep_for(std::chrono::microseconds(10));
-    return vals[idx++];
-  }
-  const U256 *tail() {   // the last `tail` draws, without consuming them
-    while (done[HEAD_PARTS].load(std::memory_order_acquire) < vals.size()) std::this_thread::sleep_for(std::chrono::microseconds(10));
-    return vals.data() + lo[HEAD_PARTS];
-  }
-  void skip(size_t k) { idx += k; }
-
- private:
-  std::vector<U256> vals;
-  size_t lo[HEAD_PARTS + 2];
-  std::atomic<size_t> done[HEAD_PARTS + 1];
-  size_t idx = 0;
-  int part = 0;
-  uint8_t sd[32];
-  std::thread th[HEAD_PARTS + 1];
-};
-
 struct OpenItem {
   const Fr *lagr;        // device pointer, Lagrange form
   int n_rot;
@@ -944,8 +981,21 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const unsigned k = cfg.k;
   const double t_start = now_ms();
   Trace trace;
-  PreRng rng(seed, (size_t)cfg.n_advice() * (n - u) + 2 * (size_t)cfg.n_lookup * (n - u) +
-                        ((size_t)cfg.n_chunks() + cfg.n_lookup) * (n - u - 1) + n, n);
+  // The blinding stream (draw i = Blake2b(seed || i) mod r) is evaluated on the device, where each value is needed
+  // (prover_kernels.hip.hpp k_rng_fill).  Draw order = oracle/halo2_ref.py: the blinding rows of every advice column in
+  // column order, then per lookup its permuted input and permuted table, then the permutation and lookup products, then
+  // the n coefficients of the random polynomial.
+  zkp::RngSeed rseed;
+  memcpy(rseed.w, seed, 32);
+  const size_t nbl_all = n - u;
+  const uint64_t ctr_adv = 0, ctr_lk = (uint64_t)cfg.n_advice() * nbl_all, ctr_pz = ctr_lk + 2 * (uint64_t)cfg.n_lookup * nbl_all,
+                 ctr_lz = ctr_pz + (uint64_t)cfg.n_chunks() * (nbl_all - 1), ctr_rand = ctr_lz + (uint64_t)cfg.n_lookup * (nbl_all - 1);
+  auto rng_fill = [&](hipStream_t stream, uint64_t ctr0, uint64_t ctr_col_stride, Fr *dst, size_t per_col, size_t col_stride, size_t n_cols) -> int {
+    if (!per_col || !n_cols) return ZKFHE_OK;
+    zkp::k_rng_fill<<<grid_for(ctx, per_col * n_cols), 256, 0, stream>>>(rseed, ctr0, ctr_col_stride, dst, per_col, col_stride, n_cols);
+    ZK_LAUNCH_CHECK(ctx);
+    return ZKFHE_OK;
+  };
   Transcript tr(cfg.transcript);
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
@@ -963,31 +1013,22 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   CK(zkfhe_sync(ctx));
   CK(alloc_witness_buffers(ctx, pk, ws));
   ws->ring_off = 0;
-  trace.mark("setup (rng thread, workspace)");
-  // random polynomial, early: coefficients (the tail of the blinding stream) -> auxiliary stream -> commitment, enqueued by a
-  // helper thread as soon as the draws exist.  The main stream is idle here (synchronised above) and only touches this
-  // region again after waiting for ev_rand.
-  struct EarlyRand {
-    std::thread th;
-    int rc = 0;
-    ~EarlyRand() {
-      if (th.joinable()) th.join();
-    }
-  } early;
-  const bool early_rand = !srs->sharded();   // a sharded commitment is a collective: it stays on the main stream, in protocol order
-  if (early_rand) early.th = std::thread([&, n] {
+  trace.mark("setup (workspace)");
+  // random polynomial, early: its coefficients (the tail of the blinding stream) depend on no challenge, so they are drawn and
+  // committed on the auxiliary stream beside the phase-0 / witness work.  The main stream is idle here (synchronised above)
+  // and only touches this region again after waiting for ev_rand.  A sharded commitment is a collective: it stays on the
+  // main stream, in protocol order.
+  const bool early_rand = !srs->sharded();
+  if (early_rand) {
     zkfhe_ctx *aux = ws->aux;
-    (void)hipSetDevice(aux->device);
     Fr *rand_dev = ws->misc.fr() + 8 * n;
     G1Affine *pt_dev = (G1Affine *)ws->points.p + std::max<size_t>(ws->n_all, cfg.n_perm());
-    memcpy(ws->host_rand, rng.tail(), n * 32);
-    int rc = hipMemcpyAsync(rand_dev, ws->host_rand, n * 32, hipMemcpyHostToDevice, aux->stream) == hipSuccess ? 0 : ZKFHE_EHIP;
-    if (!rc) rc = zkfhe_fr_to_mont(aux, (const zkfhe_fr *)rand_dev, (zkfhe_fr *)rand_dev, n);
-    if (!rc) rc = zkfhe_msm_batch(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_affine *)pt_dev);
-    if (!rc && hipMemcpyAsync(ws->host_rand_pt, pt_dev, sizeof(G1Affine), hipMemcpyDeviceToHost, aux->stream) != hipSuccess) rc = ZKFHE_EHIP;
-    if (!rc && hipEventRecord(ws->ev_rand, aux->stream) != hipSuccess) rc = ZKFHE_EHIP;
-    early.rc = rc;
-  });
+    CK(rng_fill(aux->stream, ctr_rand, 0, rand_dev, n, n, 1));
+    if (int rc = zkfhe_msm_batch(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_affine *)pt_dev))
+      return zk_fail_msg(ctx, rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(aux));
+    ZK_HIP(ctx, hipMemcpyAsync(ws->host_rand_pt, pt_dev, sizeof(G1Affine), hipMemcpyDeviceToHost, aux->stream));
+    ZK_HIP(ctx, hipEventRecord(ws->ev_rand, aux->stream));
+  }
   const CircuitInput in = CircuitInput::parse_json(input_json);
   trace.mark("parse_json");
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
@@ -1005,23 +1046,25 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   as.place(ctx0, true);
   trace.mark("place phase 0");
   auto blind_and_upload = [&](unsigned c_lo, unsigned c_hi) -> int {
-    for (unsigned c = c_lo; c < c_hi; ++c) {
-      U256 *col = as.t.advice[c];
-      for (size_t r = u; r < n; ++r) col[r] = rng.next();
-    }
-    // the table is pinned and column-contiguous: one DMA for the whole phase
+    // the table is pinned and column-contiguous: one DMA for the whole phase; the blinding rows u .. n-1 are drawn on the device
     ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c_lo * n, as.t.advice[c_lo], (size_t)(c_hi - c_lo) * n * 32, hipMemcpyHostToDevice, ctx->stream));
-    return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
-                            (size_t)(c_hi - c_lo) * n);
+    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
+                        (size_t)(c_hi - c_lo) * n));
+    return rng_fill(ctx->stream, ctr_adv + (uint64_t)c_lo * nbl_all, nbl_all, ws->adv_l.fr() + (size_t)c_lo * n + u, nbl_all, n, c_hi - c_lo);
   };
   std::vector<AffinePoint> adv_commit(cfg.n_advice()), pts;
   trace.mark("transcript: instances");
   CK(blind_and_upload(0, cfg.n_gate0));
   trace.mark("blind + upload phase 0");
   const bool host_witness = witness_on_host();
+  // see "Early phase-1 commitment" below.  Opt-in (ZKFHE_EARLY_P1=1): measured with the Poseidon transcript it shortens a
+  // single wave of 20 concurrent proofs by 3.5 % (the GPU works while every proof hashes its public inputs) and costs 4.6 %
+  // in steady state (two extra small commitments per proof); with Blake2b there is nothing to hide.
+  const char *early_env = getenv("ZKFHE_EARLY_P1");
+  const bool early_p1 = early_env && early_env[0] == '1' && !host_witness && cfg.n_lookup > 0 && cfg.lookup_bits == 8;
   GpuPhase1 g1(ctx, pk, ws);
   // the few phase-0 columns go through the full-width basis: zkfhe_msm_batch takes its direct-sum path for them
-  const zkfhe_basis *p0_basis = (size_t)cfg.n_gate0 * n <= ((size_t)1 << 15) ? srs->g_lagrange : small_basis;
+  const zkfhe_basis *p0_basis = (size_t)cfg.n_gate0 * n <= ((size_t)1 << 16) ? srs->g_lagrange : small_basis;
   if (host_witness) {
     CK(commit_cols(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   } else {
@@ -1031,6 +1074,28 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_HIP(ctx, hipMemcpyAsync(ws->host_pts, ws->points.p, cfg.n_gate0 * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
     CK(g1.launch(st));
+    if (early_p1) {
+      // Early phase-1 commitment.  Of the phase-1 columns only the RLC columns and the 16 constrain_mul gate cells depend on
+      // the challenge the transcript yields after the phase-0 commitment -- and with the Poseidon transcript that challenge
+      // is 2561 sequential permutations away (the public inputs).  So the gate and lookup columns are placed, blinded,
+      // permuted and committed NOW, with those cells zero and the RLC columns zero; afterwards the missing cells are
+      // committed as sparse correction columns and added (a commitment is linear in its column).  Same points, same bytes.
+      const size_t nbl0 = n - u, n_adv1 = cfg.n_advice() - cfg.n_gate0, n_early = n_adv1 + 2 * cfg.n_lookup;
+      CK(g1.place_early());
+      CK(rng_fill(ctx->stream, ctr_adv + (uint64_t)cfg.n_gate0 * nbl0, nbl0, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n + u, nbl0, n, cfg.adv_rlc0() - cfg.n_gate0));
+      ZK_HIP(ctx, hipMemsetAsync(ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, 0, (size_t)cfg.n_rlc * n * 32, ctx->stream));
+      int *err_dev = (int *)ws->wblind.p;
+      ZK_HIP(ctx, hipMemsetAsync(err_dev, 0, 4, ctx->stream));
+      zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), err_dev);
+      ZK_LAUNCH_CHECK(ctx);
+      CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl0, ws->la_l.fr() + u, nbl0, n, cfg.n_lookup));
+      CK(rng_fill(ctx->stream, ctr_lk + nbl0, 2 * nbl0, ws->ls_l.fr() + u, nbl0, n, cfg.n_lookup));
+      G1Affine *early_dev = (G1Affine *)ws->points.p;   // the phase-0 points above are copied out in stream order before this
+      CK(srs_msm(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, early_dev));
+      ZK_HIP(ctx, hipMemcpyAsync(ws->host_early, early_dev, n_early * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+      ZK_HIP(ctx, hipMemcpyAsync(ws->host_early_err, err_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+      ZK_HIP(ctx, hipEventRecord(ws->ev_early, ctx->stream));
+    }
     ZK_HIP(ctx, hipEventSynchronize(ws->ev_pts));
     pts.resize(cfg.n_gate0);
     for (unsigned c = 0; c < cfg.n_gate0; ++c) pts[c] = point_canon(ws->host_pts[c]);
@@ -1053,7 +1118,40 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     trace.mark("rlc context");
     as.place(ctx_rlc, true);
     trace.mark("place rlc");
-    CK(g1.finish(evals));
+    if (!early_p1) {
+      CK(g1.finish(evals));
+    } else {
+      // the challenge-dependent rest: the reserved gate cells (into the columns and into sparse correction columns), the RLC
+      // columns; two small commitments, then early + correction on the host
+      const GpuPhase1::PatchPlan plan = g1.patch_plan();
+      const size_t np = plan.columns.size(), n_adv1 = cfg.n_advice() - cfg.n_gate0;
+      Fr *patch_cols = ws->tmp_c.fr();
+      std::vector<zkfhe_sparse_term> terms;
+      const bool sparse = !srs->sharded() && zkfhe_basis_has_multiples(srs->g_lagrange);
+      CK(g1.patch(evals, plan, patch_cols, sparse ? &terms : nullptr));
+      CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
+      G1Affine *fix_dev = (G1Affine *)ws->points.p + n_adv1 + 2 * cfg.n_lookup;
+      if (np && sparse) {
+        // a dozen non-zero cells: one wave per correction column over the digit-multiple table
+        zkfhe_sparse_term *terms_dev = (zkfhe_sparse_term *)((char *)ws->small.p + 920 * 1024);
+        CK(up(ctx, ws, terms_dev, terms.data(), terms.size() * sizeof(zkfhe_sparse_term)));
+        CK(zkfhe_msm_sparse(ctx, srs->g_lagrange, terms_dev, terms.size(), np, (zkfhe_g1_affine *)fix_dev));
+      } else if (np) {
+        CK(srs_msm(ctx, srs, srs->g_lagrange, patch_cols, np, fix_dev));
+      }
+      if (cfg.n_rlc) CK(srs_msm(ctx, srs, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, cfg.n_rlc, fix_dev + np));
+      std::vector<G1Affine> fix(np + cfg.n_rlc);
+      if (!fix.empty()) CK(zkfhe_download(ctx, fix.data(), fix_dev, fix.size() * sizeof(G1Affine)));
+      ZK_HIP(ctx, hipEventSynchronize(ws->ev_early));
+      if (*ws->host_early_err) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
+      for (size_t t = 0; t < np; ++t) {   // early commitment + correction, on the host (at most a handful of additions)
+        G1Affine &e = ws->host_early[plan.columns[t]];
+        zk::G1X acc = zk::g1x_from_affine(e);
+        zk::g1x_add_affine(acc, fix[t], false);
+        e = zk::g1x_to_affine(acc);
+      }
+      for (unsigned j = 0; j < cfg.n_rlc; ++j) ws->host_early[cfg.adv_rlc0() - cfg.n_gate0 + j] = fix[np + j];
+    }
     trace.mark("gpu phase 1 (enqueue)");
   }
   std::vector<std::vector<U256>> lookup_inputs(host_witness ? cfg.n_lookup : 0);
@@ -1062,36 +1160,36 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const double t_wit = now_ms();
   if (host_witness) {
     CK(blind_and_upload(cfg.n_gate0, cfg.n_advice()));
-  } else {
+  } else if (!early_p1) {
     // blinding rows of the device-generated columns (same draw order as the host path: column by column)
     const unsigned nc = cfg.adv_rlc0() - cfg.n_gate0;
-    for (size_t i = 0; i < (size_t)nc * nbl; ++i) ws->host_wblind[i] = rng.next();
-    CK(upload_canon(ctx, ws->wblind.fr(), ws->host_wblind, (size_t)nc * nbl));
-    ZK_HIP(ctx, hipMemcpy2DAsync(ws->adv_l.fr() + (size_t)cfg.n_gate0 * n + u, n * 32, ws->wblind.fr(), nbl * 32, nbl * 32, nc, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(rng_fill(ctx->stream, ctr_adv + (uint64_t)cfg.n_gate0 * nbl, nbl, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n + u, nbl, n, nc));
     CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
   }
   trace.mark("blind + upload phase 1");
   std::vector<AffinePoint> la_commit, ls_commit;
   const bool merged = !host_witness && cfg.n_lookup > 0;   // permuted lookup columns committed together with the advice
-  if (merged) {
+  if (early_p1) {
+    const size_t n_adv1 = cfg.n_advice() - cfg.n_gate0;
+    pts.resize(n_adv1);
+    for (size_t c = 0; c < n_adv1; ++c) pts[c] = point_canon(ws->host_early[c]);
+    la_commit.resize(cfg.n_lookup), ls_commit.resize(cfg.n_lookup);
+    for (unsigned i = 0; i < cfg.n_lookup; ++i) {
+      la_commit[i] = point_canon(ws->host_early[n_adv1 + i]);
+      ls_commit[i] = point_canon(ws->host_early[n_adv1 + cfg.n_lookup + i]);
+    }
+  } else if (merged) {
     // Single-expression lookups do not use theta, so the permuted columns can be built before the advice commitment is
     // hashed: one MSM call over [phase-1 advice | la | ls] (contiguous in all_l) instead of two, same points, same
     // transcript order, same draw order of the blinding values.
     if (cfg.lookup_bits != 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "the device lookup permutation is built for lookup_bits = 8");
-    const size_t nc = cfg.adv_rlc0() - cfg.n_gate0;       // staging slots already used by the advice blinding rows
-    U256 *hst = ws->host_wblind + nc * nbl;
-    Fr *dst = ws->wblind.fr() + nc * nbl;
-    lookup_err = (int *)(dst + 2 * (size_t)cfg.n_lookup * nbl);
+    lookup_err = (int *)ws->wblind.p;
     ZK_HIP(ctx, hipMemsetAsync(lookup_err, 0, 4, ctx->stream));
     zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
     ZK_LAUNCH_CHECK(ctx);
-    for (unsigned i = 0; i < cfg.n_lookup; ++i) {   // la_i then ls_i, lookup by lookup; staged as [la columns | ls columns]
-      U256 *a = hst + (size_t)i * nbl, *s = hst + ((size_t)cfg.n_lookup + i) * nbl;
-      for (size_t r = 0; r < nbl; ++r) a[r] = rng.next();
-      for (size_t r = 0; r < nbl; ++r) s[r] = rng.next();
-    }
-    CK(upload_canon(ctx, dst, hst, 2 * (size_t)cfg.n_lookup * nbl));
-    ZK_HIP(ctx, hipMemcpy2DAsync(ws->la_l.fr() + u, n * 32, dst, nbl * 32, nbl * 32, 2 * cfg.n_lookup, hipMemcpyDeviceToDevice, ctx->stream));
+    // blinding rows: la_i then ls_i, lookup by lookup -- two interleaved runs of the stream
+    CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl, ws->la_l.fr() + u, nbl, n, cfg.n_lookup));
+    CK(rng_fill(ctx->stream, ctr_lk + nbl, 2 * nbl, ws->ls_l.fr() + u, nbl, n, cfg.n_lookup));
     const size_t n_adv1 = cfg.n_advice() - cfg.n_gate0;
     CK(commit_cols(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_adv1 + 2 * cfg.n_lookup, (G1Affine *)ws->points.p, pts));
     int e = 0;
@@ -1116,11 +1214,12 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         U256 *colA = stA + (size_t)i * n, *colS = stS + (size_t)i * n;
         std::copy(ap.begin(), ap.end(), colA);
         std::copy(sp.begin(), sp.end(), colS);
-        for (size_t r = u; r < n; ++r) colA[r] = rng.next();
-        for (size_t r = u; r < n; ++r) colS[r] = rng.next();
+        for (size_t r = u; r < n; ++r) colA[r] = colS[r] = fe::zero();
       }
       ZK_HIP(ctx, hipMemcpyAsync(ws->la_l.p, ws->host_blind, 2 * (size_t)cfg.n_lookup * n * 32, hipMemcpyHostToDevice, ctx->stream));
       CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
+      CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl, ws->la_l.fr() + u, nbl, n, cfg.n_lookup));
+      CK(rng_fill(ctx->stream, ctr_lk + nbl, 2 * nbl, ws->ls_l.fr() + u, nbl, n, cfg.n_lookup));
       CK(commit_cols(ctx, srs, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
       ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
       la_commit.resize(cfg.n_lookup);
@@ -1180,11 +1279,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_LAUNCH_CHECK(ctx);
     // blinding rows u+1 .. n-1 (drawn per chunk, in order)
     const size_t nb = n - u - 1;
-    std::vector<U256> blind(nch * nb);
-    for (auto &b : blind) b = rng.next();
-    Fr *bdev = ws->misc.fr();
-    CK(upload_canon(ctx, bdev, blind.data(), blind.size()));
-    ZK_HIP(ctx, hipMemcpy2DAsync(ws->pz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nch, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(rng_fill(ctx->stream, ctr_pz, nb, ws->pz_l.fr() + (u + 1), nb, n, nch));
   }
   // ------------------------------------------------------------ lookup grand products
   if (cfg.n_lookup) {
@@ -1202,11 +1297,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     for (size_t i = 0; i < nl; ++i)
       if (!(totals[i] == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup argument does not close");
     const size_t nb = n - u - 1;
-    std::vector<U256> blind(nl * nb);
-    for (auto &b : blind) b = rng.next();
-    Fr *bdev = ws->misc.fr();
-    CK(upload_canon(ctx, bdev, blind.data(), blind.size()));
-    ZK_HIP(ctx, hipMemcpy2DAsync(ws->lz_l.fr() + (u + 1), n * 32, bdev, nb * 32, nb * 32, nl, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(rng_fill(ctx->stream, ctr_lz, nb, ws->lz_l.fr() + (u + 1), nb, n, nl));
   }
   std::vector<AffinePoint> pz_commit, lz_commit;
   CK(commit_cols(ctx, srs, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, (G1Affine *)ws->points.p, pz_commit));  // pz | lz contiguous
@@ -1216,18 +1307,13 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   for (const auto &p : lz_commit) tr.write_point(p);
   // ------------------------------------------------------------ vanishing: random polynomial (coefficient form)
   Fr *rand_c = ws->misc.fr() + 8 * n, *rand_l = ws->misc.fr() + 9 * n, *H_c = ws->misc.fr() + 10 * n, *H_l = ws->misc.fr() + 11 * n;
-  // committed at the start of the proof on the auxiliary stream (see below "random polynomial, early"); its n draws are the
-  // last of the blinding stream, consumed here
+  // committed at the start of the proof on the auxiliary stream ("random polynomial, early"): the last n draws of the stream
   if (early_rand) {
-    rng.skip(n);
-    early.th.join();
-    if (early.rc) return zk_fail_msg(ctx, early.rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(ws->aux));
     ZK_HIP(ctx, hipEventSynchronize(ws->ev_rand));
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_rand, 0));   // later reads of rand_c on the main stream
     tr.write_point(point_canon(*ws->host_rand_pt));
   } else {
-    for (size_t i = 0; i < n; ++i) ws->host_rand[i] = rng.next();
-    CK(upload_canon(ctx, rand_c, ws->host_rand, n));
+    CK(rng_fill(ctx->stream, ctr_rand, 0, rand_c, n, n, 1));
     std::vector<AffinePoint> rand_commit;
     CK(commit_cols(ctx, srs, srs->g, rand_c, 1, (G1Affine *)ws->points.p, rand_commit));
     tr.write_point(rand_commit[0]);

@@ -23,6 +23,94 @@ __global__ void __launch_bounds__(256) k_powers(Fr start, Fr base, Fr *__restric
 }
 
 // SRS: den[i] = n (s - w^i)   (inverted by the caller);  then li[i] = w^i (s^n - 1) * inv[i]
+// ---- the blinding stream on the device ------------------------------------------------------------------------------
+// draw(i) = Blake2b-512(person "zkfhe-rng", seed[32] || i as u64 LE) reduced mod r (transcript.hpp `Rng`, oracle/halo2_ref.py
+// `Rng`): counter based, so every blinding row / random coefficient of a proof is a pure function of (seed, index) and is
+// written where it is needed -- no host hashing (it was 50 k hashes = 12 ms of host CPU per k = 13 proof) and no upload.
+__device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int n) { return (x >> n) | (x << (64 - n)); }
+__device__ __forceinline__ Fr rng_draw(const unsigned long long seed[4], unsigned long long ctr) {
+  typedef unsigned long long u64;
+  const u64 IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+  const unsigned char S[12][16] = {
+      {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+      {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+      {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+      {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+      {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+      {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+  u64 h[8], m[16], v[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = IV[i];
+  h[0] ^= 0x01010040ULL;                 // digest length 64, no key, fanout = depth = 1
+  h[6] ^= 0x6e722d6568666b7aULL;         // personalisation "zkfhe-rn"
+  h[7] ^= 0x0000000000000067ULL;         //                 "g" + zero padding
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m[i] = 0;
+  m[0] = seed[0], m[1] = seed[1], m[2] = seed[2], m[3] = seed[3], m[4] = ctr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = h[i];
+    v[i + 8] = IV[i];
+  }
+  v[12] ^= 40;        // 40 message bytes
+  v[14] = ~v[14];     // last block
+#define ZK_B2G(a, b, c, d, x, y)          \
+  v[a] = v[a] + v[b] + (x);               \
+  v[d] = rotr64(v[d] ^ v[a], 32);         \
+  v[c] = v[c] + v[d];                     \
+  v[b] = rotr64(v[b] ^ v[c], 24);         \
+  v[a] = v[a] + v[b] + (y);               \
+  v[d] = rotr64(v[d] ^ v[a], 16);         \
+  v[c] = v[c] + v[d];                     \
+  v[b] = rotr64(v[b] ^ v[c], 63);
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    ZK_B2G(0, 4, 8, 12, m[S[r][0]], m[S[r][1]])
+    ZK_B2G(1, 5, 9, 13, m[S[r][2]], m[S[r][3]])
+    ZK_B2G(2, 6, 10, 14, m[S[r][4]], m[S[r][5]])
+    ZK_B2G(3, 7, 11, 15, m[S[r][6]], m[S[r][7]])
+    ZK_B2G(0, 5, 10, 15, m[S[r][8]], m[S[r][9]])
+    ZK_B2G(1, 6, 11, 12, m[S[r][10]], m[S[r][11]])
+    ZK_B2G(2, 7, 8, 13, m[S[r][12]], m[S[r][13]])
+    ZK_B2G(3, 4, 9, 14, m[S[r][14]], m[S[r][15]])
+  }
+#undef ZK_B2G
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+  // from_bytes_wide: lo + hi * 2^256 mod r, as a Montgomery value
+  Fr lo, hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lo.l[2 * i] = (zk::u32)h[i];
+    lo.l[2 * i + 1] = (zk::u32)(h[i] >> 32);
+    hi.l[2 * i] = (zk::u32)h[4 + i];
+    hi.l[2 * i + 1] = (zk::u32)(h[4 + i] >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {   // 2^256 < 6 r
+    zk::fp_reduce_once<zk::FrP>(lo.l);
+    zk::fp_reduce_once<zk::FrP>(hi.l);
+  }
+  // lo, hi canonical integers: (lo + hi 2^256) 2^256 = lo * R2 / R ... as Montgomery values: mont(lo) + mont(hi) * mont(2^256)
+  const Fr r2 = Fr::r2();
+  const Fr lom = zk::fp_mul<zk::FrP>(lo, r2);                        // lo in Montgomery form
+  const Fr him = zk::fp_mul<zk::FrP>(zk::fp_mul<zk::FrP>(hi, r2), r2);   // (hi * 2^256) in Montgomery form
+  return zk::fp_add<zk::FrP>(lom, him);
+}
+struct RngSeed {
+  unsigned long long w[4];
+};
+// dst[c * col_stride + j] = draw(ctr0 + c * ctr_col_stride + j)   (Montgomery), j < per_col, c < n_cols
+__global__ void __launch_bounds__(256) k_rng_fill(RngSeed seed, unsigned long long ctr0, unsigned long long ctr_col_stride, Fr *__restrict__ dst,
+                                                  size_t per_col, size_t col_stride, size_t n_cols) {
+  const size_t total = per_col * n_cols;
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = g / per_col, j = g - c * per_col;
+    dst[c * col_stride + j] = rng_draw(seed.w, ctr0 + c * ctr_col_stride + j);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_srs_den(const Fr *__restrict__ wpow, Fr s, Fr nn, Fr *__restrict__ out, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = (s - wpow[i]) * nn;
