@@ -238,7 +238,7 @@ struct GadgetArgs {
 };
 // blockIdx.y selects one of the gadget calls of a dependency level: calls whose inputs are ready run side by side in one
 // launch (24 calls, 5 levels: see GpuPhase1::launch)
-__global__ void __launch_bounds__(256) k_gadget(const GadgetArgs *__restrict__ calls) {
+static __global__ void __launch_bounds__(256) k_gadget(const GadgetArgs *__restrict__ calls) {
   const GadgetArgs g = calls[blockIdx.y];
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= g.count) return;
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) k_gadget(const GadgetArgs *__restrict__ c
 }
 
 // stream -> columns: column c, rows 0..len_c-1  <-  stream[start_c ..]  (a break-point duplicate is simply the next cell)
-__global__ void __launch_bounds__(256) k_place(const Fr *__restrict__ stream, const unsigned *__restrict__ col_start,
+static __global__ void __launch_bounds__(256) k_place(const Fr *__restrict__ stream, const unsigned *__restrict__ col_start,
                                                const unsigned *__restrict__ col_len, unsigned n_cols, size_t n, Fr *__restrict__ cols) {
   const size_t total = (size_t)n_cols * n;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
@@ -278,12 +278,12 @@ __global__ void __launch_bounds__(256) k_place(const Fr *__restrict__ stream, co
   }
 }
 // the four gate cells of every constrain_mul depend on the phase-1 challenge: they are written after the rest of the column was
-// committed (prover.hip "early phase-1 commitment") -- into the advice columns and into the sparse correction columns
+// committed (prove.hip "early phase-1 commitment") -- into the advice columns and into the sparse correction columns
 struct PatchCell {
   Fr *dst_adv, *dst_patch;
   unsigned value;   // index into the values array
 };
-__global__ void __launch_bounds__(64) k_patch_cells(const PatchCell *__restrict__ cells, unsigned count, const Fr *__restrict__ values) {
+static __global__ void __launch_bounds__(64) k_patch_cells(const PatchCell *__restrict__ cells, unsigned count, const Fr *__restrict__ values) {
   const unsigned i = threadIdx.x;
   if (i >= count) return;
   const Fr v = values[cells[i].value];
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(64) k_patch_cells(const PatchCell *__restrict_
   *cells[i].dst_patch = v;
 }
 // lookup advice columns: the k-th looked-up cell goes to column k / max_rows, row k % max_rows
-__global__ void __launch_bounds__(256) k_place_lookups(const Fr *__restrict__ stream, const unsigned *__restrict__ src_off, size_t n_lookups,
+static __global__ void __launch_bounds__(256) k_place_lookups(const Fr *__restrict__ stream, const unsigned *__restrict__ src_off, size_t n_lookups,
                                                        unsigned max_rows, size_t n, unsigned n_lookup_cols, Fr *__restrict__ cols) {
   const size_t total = (size_t)n_lookup_cols * n;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
@@ -301,18 +301,18 @@ __global__ void __launch_bounds__(256) k_place_lookups(const Fr *__restrict__ st
   }
 }
 // deferred inverses: gather the slots, (batch invert), scatter back
-__global__ void __launch_bounds__(256) k_gather(const Fr *__restrict__ src, const unsigned *__restrict__ idx, size_t count, Fr *__restrict__ dst) {
+static __global__ void __launch_bounds__(256) k_gather(const Fr *__restrict__ src, const unsigned *__restrict__ idx, size_t count, Fr *__restrict__ dst) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < count) dst[i] = src[idx[i]];
 }
-__global__ void __launch_bounds__(256) k_scatter(Fr *__restrict__ dst, const unsigned *__restrict__ idx, size_t count, const Fr *__restrict__ src) {
+static __global__ void __launch_bounds__(256) k_scatter(Fr *__restrict__ dst, const unsigned *__restrict__ idx, size_t count, const Fr *__restrict__ src) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < count) dst[idx[i]] = src[i];
 }
 
 // halo2 permute_expression_pair for an 8-bit table, one workgroup per lookup column.
 // in: Lagrange column (Montgomery), rows < u are the inputs.  out_a / out_s rows < u (Montgomery); err set if a value > 255.
-__global__ void __launch_bounds__(1024) k_lookup_permute(const Fr *__restrict__ in, size_t n, unsigned u, Fr *__restrict__ out_a, Fr *__restrict__ out_s,
+static __global__ void __launch_bounds__(1024) k_lookup_permute(const Fr *__restrict__ in, size_t n, unsigned u, Fr *__restrict__ out_a, Fr *__restrict__ out_s,
                                                         int *__restrict__ err) {
   __shared__ unsigned cnt[256], start[257], hole0[257], left0[257];
   __shared__ Fr mont[256];

@@ -1,0 +1,199 @@
+// Shared declarations of the circuit-level translation units (srs.hip, keygen.hip, prove.hip): handles, the per-context
+// workspace, small host helpers.  Not part of the public ABI.
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <stdexcept>
+
+#include "../../include/zkfhe.h"
+#include "bfv_circuit.hpp"
+#include "gpu_witness.hip.hpp"
+#include "prover_kernels.hip.hpp"
+#include "shplonk.hpp"
+#include "transcript.hpp"
+#include "vk.hpp"
+
+using namespace zkhost;
+using zk::Fr;
+using zk::G1Affine;
+
+namespace zkhost {
+CircuitConfig config_from_c(const zkfhe_bfv_config *c);
+BfvParams params_from_c(const zkfhe_bfv_params *p);
+}  // namespace zkhost
+
+static const uint64_t DELTA_CANON[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL, 0x09226b6e22c6f0caULL};
+static const uint64_t COSET_G = 7;
+
+#define CK(x)                 \
+  do {                        \
+    int rc__ = (x);           \
+    if (rc__) return rc__;    \
+  } while (0)
+
+struct zkfhe_srs {
+  uint32_t k = 0;
+  zkfhe_basis *g = nullptr, *g_lagrange = nullptr;
+  // the same Lagrange points with narrower windows, for columns of small values (advice, permuted lookups): their cost is
+  // the per-bucket work (merge, marginals), not the additions, so 8x fewer buckets beats 30 % more windows
+  zkfhe_basis *g_lagrange_small = nullptr;
+  // point-range shard (zkfhe_srs_create_sharded): the bases above hold points [lo, hi) only and every commitment goes through
+  // zkfhe_msm_batch_sharded over `comm`
+  zkfhe_comm *comm = nullptr;
+  size_t lo = 0, hi = 0;
+  bool sharded() const { return comm != nullptr && zkfhe_comm_world(comm) > 1; }
+};
+
+// commitment MSM of `n_cols` full columns (stride n): the whole basis, or this rank's rows + all-gather + sum
+static inline int srs_msm(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out) {
+  if (!srs->sharded()) return zkfhe_msm_batch(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_affine *)dev_out);
+  return zkfhe_msm_batch_sharded(ctx, srs->comm, basis, (const zkfhe_fr *)(cols + srs->lo), (size_t)1 << srs->k, n_cols, (zkfhe_g1_affine *)dev_out);
+}
+
+struct DevBuf {
+  int device = 0;  // not the context: a workspace outlives the zkfhe_ctx it was made for if the caller destroys that first
+  void *p = nullptr;
+  size_t bytes = 0;
+  int alloc(zkfhe_ctx *c, size_t b) {
+    device = c->device;
+    bytes = b;
+    return zkfhe_dev_alloc(c, b, &p);
+  }
+  void release() {
+    if (p) {
+      (void)hipSetDevice(device);
+      (void)hipFree(p);
+    }
+    p = nullptr;
+  }
+  Fr *fr() const { return (Fr *)p; }
+};
+
+
+struct View {  // a slice of a larger device allocation
+  void *p = nullptr;
+  Fr *fr() const { return (Fr *)p; }
+};
+
+struct Workspace {
+  // every polynomial of one proof, Lagrange form, contiguous: [advice | la | ls | pz | lz | instance] (all_l) and the
+  // same order on the extended coset (all_ext) -- one iNTT launch and one coset-NTT launch cover all of them
+  DevBuf all_l, all_ext;
+  View adv_l, la_l, ls_l, pz_l, lz_l, inst_l, adv_ext, la_ext, ls_ext, pz_ext, lz_ext, inst_ext;
+  size_t n_all = 0;
+  U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
+  U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
+  U256 *host_pool = nullptr;   // pinned staging for the coefficient arrays of the GPU witness generator
+  uint8_t *ring = nullptr;      // pinned bump arena for the small tables of one proof: uploads from it need no host wait
+  size_t ring_off = 0;
+  static constexpr size_t RING_BYTES = (size_t)4 << 20;
+  G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
+  hipEvent_t ev_pts = nullptr;
+  // the random polynomial of the vanishing argument depends on no challenge: it is uploaded and committed at the start of
+  // the proof on an auxiliary context (own stream, scratch and tickets) beside the phase-0 / witness work
+  zkfhe_ctx *aux = nullptr;
+  G1Affine *host_rand_pt = nullptr;  // pinned: the commitment
+  hipEvent_t ev_rand = nullptr;
+  // early phase-1 commitment (everything that does not depend on the phase-1 challenge): points + lookup error flag, pinned
+  G1Affine *host_early = nullptr;
+  int *host_early_err = nullptr;
+  hipEvent_t ev_early = nullptr;
+  DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
+  DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
+  std::vector<DevBuf *> all() {
+    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio, &stream, &pool, &invtmp, &wblind};
+  }
+};
+
+struct zkfhe_bfv_pk;
+// keygen.hip
+int up(zkfhe_ctx *ctx, Workspace *ws, void *dst, const void *src, size_t bytes);
+int get_workspace(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace **out);
+void free_workspace(Workspace *ws);
+int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext);
+// prove.hip
+int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws);
+
+static inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static inline Fr mont(const U256 &v) { return fe::to_mont(v); }
+static inline Fr mont_u64(uint64_t v) { return fe::to_mont(fe::from_u64(v)); }
+static inline U256 canon(const Fr &f) { return fe::from_mont(f); }
+static inline Fr fr_pow(Fr b, uint64_t e) {
+  Fr r = Fr::one();
+  while (e) {
+    if (e & 1) r = r * b;
+    b = b * b;
+    e >>= 1;
+  }
+  return r;
+}
+static inline Fr fr_inv(const Fr &a) { return zk::fp_inv<zk::FrP>(a); }
+
+static inline AffinePoint point_canon(const G1Affine &p) {
+  AffinePoint a;
+  zk::Fq x = zk::fp_from_mont<zk::FqP>(p.x), y = zk::fp_from_mont<zk::FqP>(p.y);
+  memcpy(a.x.l, x.l, 32);
+  memcpy(a.y.l, y.l, 32);
+  return a;
+}
+
+static inline unsigned grid_for(zkfhe_ctx *ctx, size_t work) {
+  size_t b = (work + 255) / 256;
+  size_t cap = (size_t)ctx->num_cu * 16;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// upload canonical values and convert to Montgomery on the device
+static inline int upload_canon(zkfhe_ctx *ctx, Fr *dst, const U256 *src, size_t count) {
+  ZK_HIP(ctx, hipMemcpyAsync(dst, src, count * 32, hipMemcpyHostToDevice, ctx->stream));
+  return zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)dst, (zkfhe_fr *)dst, count);
+}
+
+// Small host -> device tables of a proof (expression groups, powers, pointer lists, ...): staged in the workspace's pinned
+// arena and copied without waiting -- the arena is only recycled at the start of the next proof, after a stream sync.
+
+
+// commit `n_cols` columns (device, Montgomery) and return canonical affine points
+static inline int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
+  CK(srs_msm(ctx, srs, basis, cols, n_cols, dev_out));
+  std::vector<G1Affine> h(n_cols);
+  CK(zkfhe_download(ctx, h.data(), dev_out, n_cols * sizeof(G1Affine)));
+  out.resize(n_cols);
+  for (size_t i = 0; i < n_cols; ++i) out[i] = point_canon(h[i]);
+  return ZKFHE_OK;
+}
+
+struct GpuPolyMul : PolyMulBackend {
+  zkfhe_ctx *ctx;
+  Workspace *ws;
+  GpuPolyMul(zkfhe_ctx *c, Workspace *w) : ctx(c), ws(w) {}
+  std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) override;
+};
+
+
+struct zkfhe_bfv_pk {
+  CircuitConfig cfg;
+  BfvParams prm;
+  DevBuf fixed_l, sigma_l, fixed_ext, sigma_ext, l_ext, xs_ext, dpow;
+  std::vector<AffinePoint> fixed_commit, sigma_commit;
+  U256 vk_digest;
+  // structure of the phase-1 gate stream, recorded at keygen for the GPU witness generator
+  size_t gate1_cells = 0, n_lookup_cells = 0, n_inv_slots = 0;
+  // cosets of the extended domain the quotient is evaluated on: 3 (degree < 3n), or all 4 with ZKFHE_CHECK_QUOTIENT set when
+  // the key is built (the fourth gives the degree check).  Every extended array has this many rows per column.
+  int ext_rows = 3;
+  DevBuf lookup_src, inv_slots, place_start, place_len;   // device: u32 lists
+  // per-context prover workspaces: one proof at a time per zkfhe_ctx, any number of contexts (streams)
+  // may prove concurrently against the same key (everything above is read-only after keygen)
+  std::map<uint64_t, Workspace *> workspaces;   // keyed by zkfhe_ctx::uid (never reused), not by address
+  std::mutex mu;
+};
+

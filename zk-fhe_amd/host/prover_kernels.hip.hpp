@@ -11,7 +11,7 @@ using zk::Fr;
 
 // ------------------------------------------------------------------------------------------- small utilities
 // out[i] = start * base^i
-__global__ void __launch_bounds__(256) k_powers(Fr start, Fr base, Fr *__restrict__ out, size_t n) {
+static __global__ void __launch_bounds__(256) k_powers(Fr start, Fr base, Fr *__restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr r = start, b = base;
     for (size_t e = i; e; e >>= 1) {
@@ -102,7 +102,7 @@ struct RngSeed {
   unsigned long long w[4];
 };
 // dst[c * col_stride + j] = draw(ctr0 + c * ctr_col_stride + j)   (Montgomery), j < per_col, c < n_cols
-__global__ void __launch_bounds__(256) k_rng_fill(RngSeed seed, unsigned long long ctr0, unsigned long long ctr_col_stride, Fr *__restrict__ dst,
+static __global__ void __launch_bounds__(256) k_rng_fill(RngSeed seed, unsigned long long ctr0, unsigned long long ctr_col_stride, Fr *__restrict__ dst,
                                                   size_t per_col, size_t col_stride, size_t n_cols) {
   const size_t total = per_col * n_cols;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
@@ -111,21 +111,21 @@ __global__ void __launch_bounds__(256) k_rng_fill(RngSeed seed, unsigned long lo
   }
 }
 
-__global__ void __launch_bounds__(256) k_srs_den(const Fr *__restrict__ wpow, Fr s, Fr nn, Fr *__restrict__ out, size_t n) {
+static __global__ void __launch_bounds__(256) k_srs_den(const Fr *__restrict__ wpow, Fr s, Fr nn, Fr *__restrict__ out, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = (s - wpow[i]) * nn;
 }
-__global__ void __launch_bounds__(256) k_srs_li(const Fr *__restrict__ wpow, Fr snm1, Fr *__restrict__ inv_inout, size_t n) {
+static __global__ void __launch_bounds__(256) k_srs_li(const Fr *__restrict__ wpow, Fr snm1, Fr *__restrict__ inv_inout, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) inv_inout[i] = wpow[i] * snm1 * inv_inout[i];
 }
-__global__ void __launch_bounds__(256) k_fill_point(zk::G1Affine p, zk::G1Affine *__restrict__ out, size_t n) {
+static __global__ void __launch_bounds__(256) k_fill_point(zk::G1Affine p, zk::G1Affine *__restrict__ out, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = p;
 }
 
 // sigma_l[cell] = delta^(col of target) * omega^(row of target)
-__global__ void __launch_bounds__(256) k_sigma_values(const uint32_t *__restrict__ target, const Fr *__restrict__ dpow,
+static __global__ void __launch_bounds__(256) k_sigma_values(const uint32_t *__restrict__ target, const Fr *__restrict__ dpow,
                                                       const Fr *__restrict__ wpow, Fr *__restrict__ out, size_t cells, int log_n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= cells) return;
@@ -149,7 +149,7 @@ __device__ __forceinline__ const Fr *perm_col(const PermArgs &a, unsigned c) {
   return c < a.n_advice ? a.adv + (size_t)c * a.n : (c == a.n_advice ? a.constcol : a.inst);
 }
 // num[j][i] = prod_c (v_c + beta delta^c w^i + gamma), den[j][i] = prod_c (v_c + beta sigma_c + gamma)
-__global__ void __launch_bounds__(256) k_perm_num_den(PermArgs a, Fr *__restrict__ num, Fr *__restrict__ den) {
+static __global__ void __launch_bounds__(256) k_perm_num_den(PermArgs a, Fr *__restrict__ num, Fr *__restrict__ den) {
   const size_t total = (size_t)a.n_chunks * a.n;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const unsigned j = (unsigned)(g / a.n);
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_perm_num_den(PermArgs a, Fr *__restrict
   }
 }
 // lookup: num = (a + beta)(s + gamma), den = (a' + beta)(s' + gamma)
-__global__ void __launch_bounds__(256) k_lookup_num_den(const Fr *__restrict__ a_cols, const Fr *__restrict__ table, const Fr *__restrict__ la,
+static __global__ void __launch_bounds__(256) k_lookup_num_den(const Fr *__restrict__ a_cols, const Fr *__restrict__ table, const Fr *__restrict__ la,
                                                         const Fr *__restrict__ ls, Fr beta, Fr gamma, unsigned n_lookup, size_t n,
                                                         Fr *__restrict__ num, Fr *__restrict__ den) {
   const size_t total = (size_t)n_lookup * n;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) k_lookup_num_den(const Fr *__restrict__ a
 
 // Exclusive running product per column: z[0] = 1, z[i+1] = z[i] * r[i] for i < u; z has u+1 defined entries.
 // One workgroup of 1024 threads per column; thread t owns rows [t*per, (t+1)*per).  `total[col]` = z[u].
-__global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__restrict__ ratio, Fr *__restrict__ z, Fr *__restrict__ total, size_t n,
+static __global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__restrict__ ratio, Fr *__restrict__ z, Fr *__restrict__ total, size_t n,
                                                          unsigned u) {
   __shared__ Fr sh[1024];
   const size_t col = blockIdx.x;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__restrict__ 
   if (threadIdx.x == 1023) total[col] = sh[1023];
 }
 // z[col][0..u] *= carry[col]
-__global__ void __launch_bounds__(256) k_scale_rows(Fr *__restrict__ z, const Fr *__restrict__ carry, size_t n, unsigned rows, unsigned n_cols) {
+static __global__ void __launch_bounds__(256) k_scale_rows(Fr *__restrict__ z, const Fr *__restrict__ carry, size_t n, unsigned rows, unsigned n_cols) {
   const size_t total = (size_t)n_cols * rows;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const unsigned col = (unsigned)(g / rows);
@@ -236,7 +236,7 @@ struct QArgs {
   unsigned rows;  // cosets evaluated (3 or 4) = rows per column of every extended array (column stride rows * n)
 };
 
-__global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
+static __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
   const size_t n = (size_t)1 << a.log_n, ne = n * a.rows;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (p >= ne) return;
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
 }
 
 // h_ext[p] = (sum_g ypow[g] * partials[g][p]) * zinv[k1]
-__global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
+static __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
                                                           const Fr *__restrict__ zinv, unsigned log_n, unsigned rows, Fr *__restrict__ h_ext) {
   const size_t n = (size_t)1 << log_n, ne = n * rows;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__
 struct Mat3 {
   Fr v[9];
 };
-__global__ void __launch_bounds__(256) k_ext3_combine(const Fr *__restrict__ rows3, const Fr *__restrict__ pw, Mat3 vinv, size_t n, Fr *__restrict__ h_c) {
+static __global__ void __launch_bounds__(256) k_ext3_combine(const Fr *__restrict__ rows3, const Fr *__restrict__ pw, Mat3 vinv, size_t n, Fr *__restrict__ h_c) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr t[3];
@@ -338,13 +338,13 @@ __global__ void __launch_bounds__(256) k_ext3_combine(const Fr *__restrict__ row
 
 // ------------------------------------------------------------------------------------------- evaluations
 // barycentric weights: d[r][i] = z_r - w^i (inverted by the caller), then b[r][i] = c * w^i * inv
-__global__ void __launch_bounds__(256) k_bary_den(const Fr *__restrict__ wpow, const Fr *__restrict__ pts, unsigned n_pts, size_t n,
+static __global__ void __launch_bounds__(256) k_bary_den(const Fr *__restrict__ wpow, const Fr *__restrict__ pts, unsigned n_pts, size_t n,
                                                   Fr *__restrict__ out) {
   const size_t total = (size_t)n_pts * n;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x)
     out[g] = pts[g / n] - wpow[g % n];
 }
-__global__ void __launch_bounds__(256) k_bary_weights(const Fr *__restrict__ wpow, Fr c, size_t total, size_t n, Fr *__restrict__ inout) {
+static __global__ void __launch_bounds__(256) k_bary_weights(const Fr *__restrict__ wpow, Fr c, size_t total, size_t n, Fr *__restrict__ inout) {
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x)
     inout[g] = inout[g] * wpow[g % n] * c;
 }
@@ -355,7 +355,7 @@ struct EvalJob {
   int rot[4];  // indices into the weight table
 };
 // gridDim.y row slices (long columns): slice y sums rows [y n / Y, (y + 1) n / Y) into out[(y * jobs + job) * 4 + r]
-__global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ jobs, const Fr *__restrict__ bw, size_t n, Fr *__restrict__ out) {
+static __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ jobs, const Fr *__restrict__ bw, size_t n, Fr *__restrict__ out) {
   __shared__ Fr sh[256];
   const EvalJob job = jobs[blockIdx.x];
   Fr acc[4];
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ j
 
 // ------------------------------------------------------------------------------------------- SHPLONK
 // out[i] = sum_m s[m] * ptr[m][i]
-__global__ void __launch_bounds__(256) k_lincomb_ptrs(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, size_t n,
+static __global__ void __launch_bounds__(256) k_lincomb_ptrs(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, size_t n,
                                                       Fr *__restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr acc = Fr::zero();
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) k_lincomb_ptrs(const Fr *const *__restric
 }
 // the same sum split over blockIdx.y chunks of `per` pointers: partial[chunk][i]; k_sum_rows adds the chunks up.  One thread
 // looping over ~600 columns is a 0.7 ms dependent chain; 13 chunks of 48 run side by side.
-__global__ void __launch_bounds__(256) k_lincomb_ptrs_chunked(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, unsigned per, size_t n,
+static __global__ void __launch_bounds__(256) k_lincomb_ptrs_chunked(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, unsigned per, size_t n,
                                                               Fr *__restrict__ partial) {
   const unsigned k0 = blockIdx.y * per, k1 = min(k0 + per, m);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) k_lincomb_ptrs_chunked(const Fr *const *_
     partial[(size_t)blockIdx.y * n + i] = acc;
   }
 }
-__global__ void __launch_bounds__(256) k_sum_rows(const Fr *__restrict__ partial, unsigned rows, size_t n, Fr *__restrict__ out) {
+static __global__ void __launch_bounds__(256) k_sum_rows(const Fr *__restrict__ partial, unsigned rows, size_t n, Fr *__restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr acc = partial[i];
     for (unsigned r = 1; r < rows; ++r) acc = acc + partial[(size_t)r * n + i];
@@ -415,7 +415,7 @@ struct ShSet {
   int n_pts, pad[3];
 };
 // zs[j][i] = prod_{p in S_j} (w^i - p)
-__global__ void __launch_bounds__(256) k_sh_zs(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ wpow, size_t n,
+static __global__ void __launch_bounds__(256) k_sh_zs(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ wpow, size_t n,
                                                Fr *__restrict__ zs) {
   const size_t total = (size_t)n_sets * n;
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) k_sh_zs(const ShSet *__restrict__ sets, u
   }
 }
 // hq[i] = sum_j v^j (F_j[i] - r_j(w^i)) * zs_inv[j][i]
-__global__ void __launch_bounds__(256) k_sh_h(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ F, const Fr *__restrict__ zs_inv,
+static __global__ void __launch_bounds__(256) k_sh_h(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ F, const Fr *__restrict__ zs_inv,
                                               const Fr *__restrict__ wpow, size_t n, Fr *__restrict__ hq) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const Fr w = wpow[i];
@@ -444,11 +444,11 @@ __global__ void __launch_bounds__(256) k_sh_h(const ShSet *__restrict__ sets, un
   }
 }
 // den[i] = w^i - u (inverted by the caller);  W[i] = (sum_j coef_j (F_j[i] - r_j(u)) - ztu * hq[i]) * inv[i]
-__global__ void __launch_bounds__(256) k_sh_den(const Fr *__restrict__ wpow, Fr u, size_t n, Fr *__restrict__ out) {
+static __global__ void __launch_bounds__(256) k_sh_den(const Fr *__restrict__ wpow, Fr u, size_t n, Fr *__restrict__ out) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = wpow[i] - u;
 }
-__global__ void __launch_bounds__(256) k_sh_w(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ F, const Fr *__restrict__ hq,
+static __global__ void __launch_bounds__(256) k_sh_w(const ShSet *__restrict__ sets, unsigned n_sets, const Fr *__restrict__ F, const Fr *__restrict__ hq,
                                               Fr ztu, const Fr *__restrict__ inv, size_t n, Fr *__restrict__ W) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr acc = Fr::zero();

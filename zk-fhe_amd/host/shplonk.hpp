@@ -1,4 +1,4 @@
-// Opening bookkeeping shared by the prover (prover.hip) and the verifier (verifier.cpp): which polynomial is opened at
+// Opening bookkeeping shared by the prover (prove.hip) and the verifier (verifier.cpp): which polynomial is opened at
 // which rotation, in which order the evaluations are written, and how halo2's SHPLONK groups them.
 //
 // Restates (third-party halo2_proofs, reached from reference examples/bfv.rs:311; mirrored by oracle/halo2_ref.py
