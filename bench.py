@@ -169,7 +169,11 @@ def main():
         steady = n_more / (time.perf_counter() - ts)
         si += n_more
 
-    # dominant kernel (k_msm_accumulate) timed live with HIP events on the library's stream, in a separate untimed pass
+    # dominant kernel timed live with HIP events on the library's stream, in a separate untimed pass: k_msm_table (the sum of
+    # table points of a commitment batch) when the SRS holds a digit-multiple table wide enough for such calls, else the
+    # bucket pipeline's k_msm_accumulate
+    table_bits, table_wide = srs.table_bits()
+    msm_kernel = "k_msm_table" if table_wide else "k_msm_accumulate"
     ctx.prof_enable(True)
     for _ in range(2):
         pk.prove(inputs[si % len(inputs)], seeds[si % len(seeds)])
@@ -180,7 +184,7 @@ def main():
 
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, rocprofv3 --pmc)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["bytes_per_launch"] if not big else None
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["bytes_per_launch"] if (not big and table_wide) else None
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
@@ -216,7 +220,7 @@ def main():
                        "steady_state_proofs_per_s": steady,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": msm_kernel, "table_digit_bits": table_bits, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
                          "launches_per_proof": msm["launches"] / 2,
                          # the bound that actually binds this kernel (SURVEY.md 8(d) "secondary, honest bound"): 256-bit modular
@@ -224,7 +228,7 @@ def main():
                          "int_alu": {"achieved": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9, "peak": MODMUL_PEAK_G,
                                      "unit": "G modmul/s", "frac": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G,
                                      "mixed_additions_per_proof": msm["ops"] / 2},
-                         "msm_direct": {"avg_launch_ms": direct["total_ms"] / max(1, direct["launches"]), "launches_per_proof": direct["launches"] / 2},
+                         "msm_few_columns": {"avg_launch_ms": direct["total_ms"] / max(1, direct["launches"]), "launches_per_proof": direct["launches"] / 2},
                          "ntt_tile": {"achieved": ntt_ach, "int_alu_frac": (ntt["ops"] / (ntt["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G) if ntt["launches"] else None, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
             "cpu_baseline": cpu,
         }

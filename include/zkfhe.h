@@ -70,7 +70,8 @@ int zkfhe_timer_start(zkfhe_ctx *ctx);
 int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms);   /* waits for the stop event */
 
 /* Per-kernel profiling with HIP events on the context's stream.  While enabled, zkfhe_msm_batch and
- * zkfhe_ntt_batch bracket their dominant kernel (which 0: k_msm_accumulate, 1: k_ntt_tile, 2: k_msm_direct) with an event pair
+ * zkfhe_ntt_batch bracket their dominant kernel (which 0: the summing kernel of a wide MSM call -- k_msm_table or k_msm_accumulate --, 1: k_ntt_tile,
+ * 2: k_msm_table of a call of a few columns) with an event pair
  * and wait for it, accumulating duration, launch count and ALGORITHMIC bytes (MSM: 96 B per term, NTT: 64 B per
  * point -- BASELINE.md).  Meant for a separate, untimed pass (it serialises the stream). */
 int zkfhe_prof_enable(zkfhe_ctx *ctx, int on);
@@ -130,6 +131,10 @@ typedef struct { zkfhe_fr scalar; uint32_t row; uint32_t slot; } zkfhe_sparse_te
 int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots,
                      zkfhe_g1_affine *out_dev);
 int zkfhe_basis_has_multiples(const zkfhe_basis *basis);
+/* Digit width of the basis' digit-multiple table (0: none).  *wide_calls (optional) = 1 when calls of many columns take the
+ * table path too (k_msm_table), 0 when they take the bucket pipeline (k_msm_accumulate ...) and only calls of <= 8 columns
+ * go through the table. */
+int zkfhe_basis_table_bits(const zkfhe_basis *basis, int *wide_calls);
 
 /* ---- intra-proof multi-GPU: commitments sharded by point range (replaces nothing in the reference,
  * whose prover is single-process -- the seam is again best_multiexp inside ParamsKZG::{commit, commit_lagrange}) ----------
@@ -251,6 +256,8 @@ int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_h
  * called with it shard every commitment over `comm` (see "intra-proof multi-GPU").  comm must outlive the SRS. */
 int zkfhe_srs_create_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out);
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs);
+/* zkfhe_basis_table_bits of the Lagrange half of the SRS (the basis of the advice / permutation / lookup commitments). */
+int zkfhe_srs_table_bits(const zkfhe_srs *srs, int *wide_calls);
 
 /* keygen (README.md:28-38): circuit structure from the (empty) input, fixed + sigma polynomials, their
  * commitments, the vk digest; everything the prover needs stays resident in HBM. */

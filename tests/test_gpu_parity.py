@@ -197,34 +197,44 @@ def test_msm_vs_oracle(ctx, n, c):
     B.destroy()
 
 
-@pytest.mark.parametrize("n,n_cols", [(256, 1), (1000, 3), (8192, 1), (8192, 3), (8192, 4), (16384, 2), (65536, 1)])
-def test_msm_direct_sum_path(ctx, n, n_cols):
-    """Calls of a few columns on a default basis take the direct-sum path (digit-multiple table, k_msm_direct): every
-    windows-per-thread variant (E = 8 .. 64), non-power-of-two n, an identity base, zero / one / r-1 / (r+-1)/2 scalars,
-    short and negative-short columns; called twice (the ticket counters must reset themselves) and against the bucket
-    path of the same basis (ZKFHE_DIRECT_MAX_TERMS cannot change mid-process: a wider call does that)."""
+@pytest.mark.parametrize("n,n_cols,bits", [(256, 1, 0), (1000, 3, 8), (1000, 3, 9), (8192, 1, 0), (8192, 3, 10), (8192, 4, 11), (8192, 17, 13),
+                                           (16384, 2, 8), (65536, 1, 8), (2048, 40, 12), (2048, 300, 10)])
+def test_msm_table_path(ctx, monkeypatch, n, n_cols, bits):
+    """A default basis (window_bits = 0) gets a digit-multiple table and every call against it is a plain sum of table
+    points (k_msm_table): forced table widths 8 .. 13 and the budget's own choice, a lone column (butterfly per visit) and
+    hundreds (256 partials per visit), non-power-of-two n, an identity base, zero / one / r-1 / (r+-1)/2 scalars, short
+    and negative-short columns; called twice (the ticket counters must reset themselves) and against the bucket pipeline
+    of the same points (explicit window_bits: no table)."""
     import zk_fhe_amd as zk
+    if bits:
+        monkeypatch.setenv("ZKFHE_TABLE_BITS", str(bits))
+        monkeypatch.setenv("ZKFHE_TABLE_GB", "48")
+    else:
+        monkeypatch.setenv("ZKFHE_TABLE_GB", "2")
     rng = np.random.default_rng(31 * n + n_cols)
     bases = _bases(n, seed=n + n_cols)
     bases[n // 5] = 0
-    sc = [[int.from_bytes(rng.bytes(32), "little") % pyref.R for _ in range(n)] for _ in range(n_cols)]
+    sc = [[int.from_bytes(rng.bytes(32), "little") % pyref.R for _ in range(n)] for _ in range(min(n_cols, 4))]
     sc[0][:8] = [0, 1, pyref.R - 1, (pyref.R - 1) // 2, (pyref.R + 1) // 2, 2, 8, pyref.R - 8]
     if n_cols > 1:
         sc[1] = [int(rng.integers(0, 1 << 29)) if i % 3 else (pyref.R - int(rng.integers(1, 1000))) for i in range(n)]
     if n_cols > 2:
         sc[2] = [[0, 1, 536870908][int(rng.integers(0, 3))] for _ in range(n)]
+    if n_cols > 3:
+        sc[3] = [0] * n
     S = np.stack([orc.ints_to_mont(col) for col in sc])
+    if n_cols > 4:   # many columns: the four above, cyclically shifted copies in between
+        S = np.stack([np.roll(S[j % 4], j // 4, axis=0) for j in range(n_cols)])
     B = zk.Basis(ctx, bases)
-    want = orc.msm(S, bases)
+    assert B.has_table
+    Bb = zk.Basis(ctx, bases, 11)
+    assert not Bb.has_table
+    want = ctx.msm(Bb, S)
+    assert np.array_equal(want[:4], orc.msm(S[:4], bases))
     for _ in range(2):
         assert np.array_equal(ctx.msm(B, S), want)
-    # the same columns inside a call too wide for the direct path: the bucket pipeline must agree
-    reps = (1 << 16) // n // n_cols + 1
-    if n * n_cols * (reps + 1) <= (1 << 22):
-        wide = np.concatenate([S] * (reps + 1))
-        got = ctx.msm(B, wide)
-        assert np.array_equal(got[:n_cols], want) and np.array_equal(got[-n_cols:], want)
     B.destroy()
+    Bb.destroy()
 
 
 @pytest.mark.parametrize("c", [10, 13, 16])

@@ -24,7 +24,7 @@ EXPORTS = [
     "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain", "zkfhe_fq29_sqr_chain",
     "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
-    "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_basis_has_multiples",
+    "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_basis_has_multiples", "zkfhe_basis_table_bits", "zkfhe_srs_table_bits",
     "zkfhe_comm_unique_id", "zkfhe_comm_create", "zkfhe_comm_create_with_transport", "zkfhe_comm_destroy", "zkfhe_comm_rank", "zkfhe_comm_world",
     "zkfhe_comm_point_range", "zkfhe_comm_all_gather", "zkfhe_msm_batch_sharded", "zkfhe_srs_create_sharded",
     "zkfhe_witness_poly_mul_u64", "zkfhe_witness_div_mod",
@@ -144,6 +144,11 @@ class Basis:
         ctx._check(ctx.lib.zkfhe_basis_create(ctx.h, b.ctypes.data_as(ctypes.c_void_p), b.shape[0], int(window_bits), ctypes.byref(h)))
         self.h = h
         self.n = b.shape[0]
+
+    @property
+    def has_table(self):
+        """True when the basis holds a digit-multiple table (every MSM against it is a plain sum of table points)."""
+        return bool(self.ctx.lib.zkfhe_basis_has_multiples(self.h))
 
     def destroy(self):
         if self.h:
@@ -664,6 +669,14 @@ class Srs:
         ctx._check(lib.zkfhe_srs_from_points(ctx.h, k, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
         self.h = h
         return self
+
+    def table_bits(self):
+        """(digit width of the Lagrange half's digit-multiple table or 0, whether calls of many columns take the table path)."""
+        lib = self.ctx.lib
+        lib.zkfhe_srs_table_bits.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        wide = ctypes.c_int()
+        bits = lib.zkfhe_srs_table_bits(self.h, ctypes.byref(wide))
+        return int(bits), bool(wide.value)
 
     def destroy(self):
         if self.h:

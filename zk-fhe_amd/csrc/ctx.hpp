@@ -42,7 +42,7 @@ struct zkfhe_ctx {
   static constexpr size_t BOUNCE_BYTES = (size_t)1 << 20;
   void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[4] = {0, 0, 0, 0};
-  unsigned *tickets = nullptr;   // 256 zeroed counters: "last workgroup done" tickets of the direct-sum MSM (self-resetting)
+  unsigned *tickets = nullptr;   // zeroed counters: "last workgroup done" tickets of the table-path MSM, one per column (self-resetting)
 };
 
 struct zkfhe_basis {
@@ -50,9 +50,11 @@ struct zkfhe_basis {
   int c = 0;        // window bits
   int windows = 0;  // number of signed windows
   zk::G1Affine *table = nullptr;  // [windows][n] : 2^(c*w) * P_i
-  // digit-multiple table of the direct-sum path (msm.hip "few columns"): mult[(w*n + i)*8 + d-1] = d * 16^w * P_i,
-  // d = 1..8, w < 64 -- 32 KiB per base point; built for n <= 2^16 (256 MiB at n = 2^13, 2 GiB at 2^16)
+  // digit-multiple table (msm.hip k_msm_table): mult[(i*mw + w) * 2^(mc-1) + j-1] = j * 2^(mc*w) * P_i, j = 1..2^(mc-1),
+  // mw = ceil(255/mc) signed windows; mc is the widest width whose table fits the per-basis budget (23.6 GB at n = 2^13,
+  // mc = 12).  nullptr: calls against this basis take the bucket pipeline over `table`.
   zk::G1Affine *mult = nullptr;
+  int mc = 0, mw = 0;
 };
 
 int zk_fail(zkfhe_ctx *ctx, int code, const char *what, hipError_t e, const char *file, int line);

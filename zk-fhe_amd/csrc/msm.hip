@@ -28,13 +28,12 @@
 // reduction in the point formulas).  The tables, partials, buckets and marginals hold packed 256-bit words in that
 // form; k_msm_weighted / k_msm_direct convert the one result per MSM back before normalising it.
 //
-// Calls of a few columns (the random polynomial, the quotient pieces, the two SHPLONK commitments, the phase-0 advice: five
-// of the prover's seven calls) do not fill the chip and their cost is the LENGTH of the dependent chain -- one point
-// operation is ~10 us for a wave whether 1 or 64 lanes are live -- so they take the direct-sum path (k_msm_direct): with
-// the digit-multiple table d * 16^w * P_i (d = 1..8) of the basis resident in HBM an MSM is a plain sum of <= 64 n table
-// points: no sort, no buckets, no weights.  One launch: a few mixed additions per lane, a butterfly, and the last workgroup
-// of a column (ticket counter) folds the per-workgroup partials and normalises.  22 point operations end to end at
-// n = 2^13 instead of ~70 through the bucket pipeline (13 launches).
+// When the digit-multiple table of a basis fits its HBM budget (zkfhe_basis_create: 43 GB per SRS half at n = 2^13, 13-bit
+// digits) the whole pipeline above is replaced by k_msm_table: T[i][w][j] = j * 2^(13 w) * P_i is resident, so an MSM is a
+// plain sum of <= 20 n table points per column -- no sort, no buckets, no weights, one launch (+ a fold) instead of
+// thirteen.  Same additions as the bucket pipeline's accumulation, none of the rest: 0.9x the VALU instructions on full-width
+// columns, 0.67x on witness columns, and 0.2 ms instead of 0.54 for a lone column (profiles/r2_msm_table.md).  The bucket
+// pipeline stays for bases whose table would not fit (n >= 2^18) or would force so many more windows that it loses.
 #include <vector>
 #include <cstring>
 
@@ -92,6 +91,7 @@ __device__ __forceinline__ void for_each_digit(const Fr &mont, int c, int window
 // counts their digits in LDS (K+1 counters); only the non-zero bins touch global memory, with one atomic per
 // (workgroup, bucket) instead of one per entry -- device-scope atomics are memory transactions on this chip
 // (profiles/r1_pmc_traffic.md: 144 MB of writes per launch before this change).
+constexpr size_t MSM_MAX_COLS = 4096;   // columns per call (ticket counters of the table path)
 constexpr unsigned SORT_CHUNK = 2048;   // scalars per workgroup
 constexpr unsigned SORT_THREADS = 512;
 
@@ -578,45 +578,86 @@ __global__ void __launch_bounds__(64) k_msm_small(const G1X *__restrict__ bucket
   if (lane == 0) out[col] = g1x_to_affine(g1x29_to_std(W));
 }
 
-// ---- direct-sum path for calls of a few columns ------------------------------------------------------------------
-constexpr int DM_WINDOWS = 64, DM_MULTS = 8;   // 4-bit signed digits: windows, multiples per window
+// ---- digit-multiple table path ---------------------------------------------------------------------------------------
+// With T[(i*W + w)*J + j-1] = j * 2^(c*w) * P_i  (j = 1..J = 2^(c-1), W = ceil(255/c) signed windows) resident in HBM an MSM is
+// a plain sum of at most n*W table points: no sort, no buckets, no weights, no doublings.  At n = 2^13, c = 12 the table is
+// 23.6 GB of the 288 -- the SRS is fixed for the life of the prover, HBM is what this chip has most of.
+struct BiasArg {
+  u32 l[9];   // sum_w 2^(c*w + c-1): with it, window w of (s + bias) minus 2^(c-1) is a signed digit in [-J, J-1] and the digits
+};            // sum to s without a carry chain; the zero windows of a short scalar stay zero digits
 
-// mult[(w*n + i)*8 + d-1] = d * 16^w * P_i.  One thread per base point walks its 64 windows; every point is normalised on
-// its own (a 40 us inversion each: 20 ms per thread, once per basis).
-__global__ void __launch_bounds__(64) k_basis_multiples(const G1Affine *__restrict__ bases, size_t n, G1Affine *__restrict__ mult) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  G1Affine cur = bases[i];
-  for (int w = 0; w < DM_WINDOWS; ++w) {
-    G1Affine *m = mult + ((size_t)w * n + i) * DM_MULTS;
-    m[0] = g1_affine_to_29(cur);   // stored in the 2^261 Montgomery form of the MSM kernels
-    if (cur.is_identity()) {
-      for (int d = 1; d < DM_MULTS; ++d) m[d] = cur;
-      continue;
-    }
-    G1X acc = g1x_from_affine_dbl(cur);
-    m[1] = g1_affine_to_29(g1x_to_affine(acc));
-    for (int d = 2; d < DM_MULTS; ++d) {
-      g1x_add_affine(acc, cur, false);
-      m[d] = g1_affine_to_29(g1x_to_affine(acc));
-    }
-    cur = g1x_to_affine(g1x_dbl(acc));   // 16 * (16^w P_i)
+__device__ __forceinline__ u32 bits_at(const u32 (&l)[9], int bit, int c) {
+  const int limb = bit >> 5, sh = bit & 31;
+  u32 lo = 0, hi = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {   // selects, not indexed loads: the limbs stay in registers
+    if (k == limb) lo = l[k];
+    if (k == limb + 1) hi = l[k];
+  }
+  return (u32)((((u64)hi << 32) | lo) >> sh) & ((1u << c) - 1);
+}
+
+// |s| (sign-magnitude, < 2^253) + bias; returns the sign, and in `bits` the bit length of |s|: windows above
+// bits / c + 1 hold zero digits (a negative digit carries one into the next window, not further)
+__device__ __forceinline__ bool biased_scalar(const Fr &mont, const BiasArg &B, u32 (&out)[9], int &bits) {
+  Fr s = fp_from_mont<FrP>(mont);
+  const bool neg = fr_gt_half(s);
+  if (neg) s = fp_neg<FrP>(s);
+  bits = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (s.l[k]) bits = 32 * k + 32 - __clz(s.l[k]);
+  u32 carry = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u64 v = (u64)s.l[k] + B.l[k] + carry;
+    out[k] = (u32)v;
+    carry = (u32)(v >> 32);
+  }
+  out[8] = B.l[8] + carry;
+  return neg;
+}
+
+// One thread per (point, window) row: j * B for j = 1..J, each normalised on its own (a 40 us inversion per entry and lane;
+// 369 M entries at n = 2^13, c = 12 -- a quarter of a second per basis, once).
+__global__ void __launch_bounds__(64) k_basis_multiples(const G1Affine *__restrict__ bases, size_t n, int c, int W, G1Affine *__restrict__ T) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= n * (size_t)W) return;
+  const size_t i = t / (size_t)W;
+  const int w = (int)(t % (size_t)W);
+  const size_t J = (size_t)1 << (c - 1);
+  G1Affine *row = T + t * J;
+  G1Affine b = bases[i];
+  if (!b.is_identity() && w) b = g1x_to_affine(g1x_mul_pow2(g1x_from_affine(b), c * w));
+  if (b.is_identity()) {
+    for (size_t j = 0; j < J; ++j) row[j] = b;
+    return;
+  }
+  row[0] = g1_affine_to_29(b);   // stored in the 2^261 Montgomery form of the MSM kernels
+  if (J == 1) return;
+  G1X acc = g1x_from_affine_dbl(b);
+  row[1] = g1_affine_to_29(g1x_to_affine(acc));
+  for (size_t j = 2; j < J; ++j) {
+    g1x_add_affine(acc, b, false);
+    row[j] = g1_affine_to_29(g1x_to_affine(acc));
   }
 }
 
-// sum of 256 XYZZ points held one per thread -> thread 0 (6-step butterfly per wave, then the four wave sums through LDS)
-__device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [4] */) {
-  for (int m = 1; m < 64; m <<= 1) {
-    const G1X29 other = g1x_shfl_xor(v, m);
-    g1x29_add(v, other);
-  }
-  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// Sum of 256 XYZZ points held one per thread -> thread 0.  Across the waves first, through LDS (waves 2, 3 hand theirs to
+// waves 0, 1, then wave 1 to wave 0: three wave-wide additions), then a 6-step butterfly in wave 0 alone: 9 wave-wide
+// additions where a 256-lane butterfly issues 26.
+__device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [128] */) {
+  const unsigned wv = threadIdx.x >> 6;
   __syncthreads();
-  if (lane == 0) sh[wv] = g1x29_store(v);
+  if (wv >= 2) sh[threadIdx.x - 128] = g1x29_store(v);
+  __syncthreads();
+  if (wv < 2) g1x29_add(v, g1x29_load(sh[threadIdx.x]));
+  __syncthreads();
+  if (wv == 1) sh[threadIdx.x - 64] = g1x29_store(v);
   __syncthreads();
   if (wv == 0) {
-    v = g1x29_load(lane < 4 ? sh[lane] : G1X::identity());
-    for (int m = 1; m < 4; m <<= 1) {
+    g1x29_add(v, g1x29_load(sh[threadIdx.x]));
+    for (int m = 1; m < 64; m <<= 1) {
       const G1X29 other = g1x_shfl_xor(v, m);
       g1x29_add(v, other);
     }
@@ -624,69 +665,147 @@ __device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [4] */) {
   return v;
 }
 
-// E windows per thread; thread t of a column handles scalar i = t % n, windows (t / n) * E .. + E - 1 (lanes of a wave read
-// consecutive scalars).  Signed digits without a carry chain: with B = 0x88..8, nibble_w(s + B) - 8 is in [-8, 7], the digits
-// sum to s, and the zero nibbles of a short scalar stay zero digits.
-template <int E>
-__global__ void __launch_bounds__(256) k_msm_direct(const Fr *__restrict__ scalars, size_t col_stride, size_t n, const G1Affine *__restrict__ mult,
-                                                    unsigned blocks_per_col, G1X *__restrict__ partials /* [n_cols][blocks_per_col] */,
-                                                    unsigned *__restrict__ tickets /* [n_cols], zero on entry and on exit */,
-                                                    G1Affine *__restrict__ out) {
-  __shared__ G1X sh[4];
-  __shared__ unsigned last;
-  const unsigned col = blockIdx.x / blocks_per_col, blk = blockIdx.x % blocks_per_col;
-  const size_t t = (size_t)blk * 256 + threadIdx.x;
-  const size_t i = t % n;
-  const unsigned w0 = (unsigned)(t / n) * E;
+// Work item = chunk of P <= 256 consecutive points of one column.  Every column has a chunk counter; a grid of persistent
+// workgroups (three per CU) is spread over the columns, each draws chunks of its column until the counter runs out and then
+// moves on to the next column that has chunks left -- a workgroup on a full-width column draws few chunks, one on a column of
+// 0/1 cells many, and the accumulators live as long as the workgroup stays with a column (witness columns mix 0/1 cells,
+// 8-bit range cells and full-width values: 0.5 to 22 additions per scalar).  Per chunk: the non-zero digits of the P
+// scalars are compacted into an LDS list of table offsets (digit mask per thread, prefix sum over the workgroup), then
+// the 256 threads take the list entries round-robin: every lane has the same number of mixed additions (+-1).
+// Leaving a column, the workgroup appends to that column's partial list: with TREE one butterfly and one partial (calls of a
+// few columns: thousands of short visits per column, the fold must stay short); without, every thread stores its accumulator
+// as it is -- 256 partials per visit and no butterfly (eight dependent point additions with most lanes idle cost as much as
+// eleven useful ones), and no point-addition code besides the loop's in the kernel: 160 registers, three waves per SIMD,
+// nothing spilled.  k_msm_table_fold sums the lists.
+template <bool TREE>
+__global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__restrict__ scalars, size_t col_stride, size_t n, const G1Affine *__restrict__ T, int c, int W, BiasArg B,
+                                                   unsigned P, unsigned cpc /* chunks per column */, unsigned n_cols, unsigned max_part,
+                                                   G1X *__restrict__ partials /* [n_cols][max_part][TREE ? 1 : 256] */,
+                                                   unsigned *__restrict__ n_part /* [n_cols] visits recorded, zero on entry */,
+                                                   unsigned *__restrict__ col_next /* [n_cols] next chunk, zero on entry */,
+                                                   unsigned *__restrict__ lists /* [gridDim.x][P * W] */, unsigned long long *__restrict__ adds) {
+  // the entry list of the chunk in flight: in global memory (written and read by this workgroup only: it stays in this CU's
+  // L1 / this XCD's L2), not in LDS -- with no LDS to its name the kernel shares a CU with the NTT tile kernel (147 KB of the
+  // 160), whose waves wait on LDS while these issue multiply-adds
+  unsigned *__restrict__ lst = lists + (size_t)blockIdx.x * P * (unsigned)W;
+  __shared__ G1X sh[TREE ? 128 : 1];
+  __shared__ unsigned wave_cnt[4], item_sh;
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int half = 1 << (c - 1);
   G1X29 acc = G1X29::identity();
-  if (w0 < (unsigned)DM_WINDOWS) {
-    Fr s = fp_from_mont<FrP>(scalars[(size_t)col * col_stride + i]);
-    const bool neg = fr_gt_half(s);
-    if (neg) s = fp_neg<FrP>(s);
-    // s + 0x8888...8: no overflow (s < 2^253)
-    u32 carry = 0;
+  unsigned col = (unsigned)(((unsigned long long)blockIdx.x * n_cols) / gridDim.x), done = 0, total = 0;
+  for (;;) {
+    __syncthreads();   // the previous chunk's list is consumed
+    if (threadIdx.x == 0) item_sh = atomicAdd(&col_next[col], 1u);
+    __syncthreads();
+    const unsigned chunk = item_sh;
+    if (chunk >= cpc) {
+      // this column has no chunks left: hand over what was summed, then look for the next column that has some
+      if (done) {
+        if (TREE) acc = block_sum_256(acc, sh);
+        __syncthreads();
+        if (threadIdx.x == 0) item_sh = atomicAdd(&n_part[col], 1u);
+        __syncthreads();
+        const size_t slot = (size_t)col * max_part + item_sh;
+        if (TREE) {
+          if (threadIdx.x == 0) partials[slot] = g1x29_store(acc);
+        } else {
+          partials[slot * 256 + threadIdx.x] = g1x29_store(acc);
+        }
+        acc = G1X29::identity();
+        done = 0;
+      }
+      // next: the column with the most chunks left (not the neighbour: the workgroups would pile up on it for a chunk each,
+      // and every visit costs the fold 256 additions)
+      __syncthreads();
+      if (threadIdx.x == 0) item_sh = 0;
+      __syncthreads();
+      unsigned best = 0;   // (chunks left << 12) | column, n_cols <= 4096
+      for (unsigned j = threadIdx.x; j < n_cols; j += 256) {
+        const unsigned nx = __hip_atomic_load(&col_next[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nx < cpc) best = max(best, ((cpc - nx) << 12) | j);
+      }
+      if (best) atomicMax(&item_sh, best);
+      __syncthreads();
+      const unsigned found = item_sh;
+      if (!found) break;
+      col = found & 4095u;
+      continue;
+    }
+    ++done;
+    {
+      const size_t i = (size_t)chunk * P + threadIdx.x;
+      const bool valid = threadIdx.x < P && i < n;
+      u32 sb[9];
+      bool neg = false;
+      unsigned long long mask = 0;
+      if (valid) {
+        int bits;
+        neg = biased_scalar(scalars[(size_t)col * col_stride + i], B, sb, bits);
+        const int wtop = min(W, bits / c + 2);
+        for (int w = 0; w < wtop; ++w)
+          if ((int)bits_at(sb, w * c, c) != half) mask |= 1ull << w;
+      }
+      const unsigned mine = (unsigned)__popcll(mask);
+      unsigned incl = mine;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u64 v = (u64)s.l[k] + 0x88888888u + carry;
-      s.l[k] = (u32)v;
-      carry = (u32)(v >> 32);
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += t;
+      }
+      if (lane == 63) wave_cnt[wv] = incl;
+      __syncthreads();
+      unsigned off = incl - mine;
+      for (unsigned v = 0; v < wv; ++v) off += wave_cnt[v];
+      const unsigned row0 = (unsigned)i * (unsigned)W;
+      while (mask) {
+        const int w = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int d = (int)bits_at(sb, w * c, c) - half;
+        lst[off++] = (((row0 + (unsigned)w) << (c - 1)) + (unsigned)(d < 0 ? -d : d) - 1u) | ((neg != (d < 0)) ? 0x80000000u : 0u);
+      }
     }
-    // E nibbles starting at window w0 (E is a multiple of 8: whole limbs)
-    const G1Affine *base = mult + ((size_t)w0 * n + i) * DM_MULTS;
-    const size_t wstride = n * DM_MULTS;
-    auto digit = [&](int e) { return (int)((s.l[(w0 + e) >> 3] >> (((w0 + e) & 7) * 4)) & 15u) - 8; };
-    // two-deep software pipeline over the table gathers
-    int d = digit(0);
+    __syncthreads();
+    const unsigned M = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    total += M;
+    // software pipeline: the entry two steps ahead and the table point one step ahead are in flight during an addition
+    unsigned e = threadIdx.x, en = 0, en2 = 0;
     G1Affine p;
-    if (d) p = base[(d < 0 ? -d : d) - 1];
-#pragma unroll 1
-    for (int e = 0; e < E; ++e) {
-      const int dn = e + 1 < E ? digit(e + 1) : 0;
-      G1Affine pn;
-      if (dn) pn = base[(size_t)(e + 1) * wstride + (dn < 0 ? -dn : dn) - 1];
-      if (d) g1x29_add_affine(acc, g1a29_load(p), neg != (d < 0));
-      d = dn;
-      p = pn;
+    if (e < M) {
+      en = lst[e];
+      p = T[en & 0x7fffffffu];
+    }
+    if (e + 256 < M) en2 = lst[e + 256];
+    while (e < M) {
+      const unsigned e2 = e + 256;
+      unsigned en3 = 0;
+      G1Affine p2;
+      if (e2 < M) p2 = T[en2 & 0x7fffffffu];
+      if (e2 + 256 < M) en3 = lst[e2 + 256];
+      g1x29_add_affine(acc, g1a29_load(p), (en >> 31) != 0);
+      e = e2;
+      en = en2;
+      en2 = en3;
+      p = p2;
     }
   }
-  acc = block_sum_256(acc, sh);
-  G1X *mine = partials + (size_t)col * blocks_per_col;
+  if (adds && threadIdx.x == 0 && total) atomicAdd(adds, (unsigned long long)total);
+}
+
+// out[col] = sum of the column's partial list (n_part[col] * L entries), normalised; the counters go back to zero
+__global__ void __launch_bounds__(256) k_msm_table_fold(const G1X *__restrict__ partials, unsigned max_part, unsigned L, unsigned *__restrict__ n_part,
+                                                        unsigned *__restrict__ col_next, G1Affine *__restrict__ out) {
+  __shared__ G1X sh[128];
+  const unsigned col = blockIdx.x;
+  const unsigned np = n_part[col] * L;
+  const G1X *mine = partials + (size_t)col * max_part * L;
+  G1X29 f = G1X29::identity();
+  for (unsigned b = threadIdx.x; b < np; b += 256) g1x29_add(f, g1x29_load(mine[b]));
+  f = block_sum_256(f, sh);
   if (threadIdx.x == 0) {
-    mine[blk] = g1x29_store(acc);
-    __threadfence();
-    last = atomicAdd(&tickets[col], 1u) == blocks_per_col - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last) return;
-  // the last workgroup of this column folds all partials and normalises.  The fences are agent-scope release / acquire:
-  // the other workgroups' partials may sit in another XCD's L2
-  __threadfence();
-  G1X29 v = G1X29::identity();
-  for (unsigned b = threadIdx.x; b < blocks_per_col; b += 256) g1x29_add(v, g1x29_load(mine[b]));
-  v = block_sum_256(v, sh);
-  if (threadIdx.x == 0) {
-    out[col] = g1x_to_affine(g1x29_to_std(v));
-    tickets[col] = 0;
+    out[col] = g1x_to_affine(g1x29_to_std(f));
+    n_part[col] = 0;
+    col_next[col] = 0;
   }
 }
 
@@ -730,11 +849,12 @@ __global__ void __launch_bounds__(256) k_g1_mul(const G1Affine *__restrict__ p, 
 }
 
 // A handful of non-zero scalars against a basis with a digit-multiple table: out[slot] = sum over the cells of that slot of
-// scalar * P_row.  One wave per slot, lanes over (cell, window) pairs, a butterfly, one normalisation.  (The prover's early
+// scalar * P_row.  One wave per slot, lanes over the windows, a butterfly, one normalisation.  (The prover's early
 // phase-1 commitment: the 16 challenge-dependent gate cells of the constrain_mul gates, as corrections to <= 4 columns.)
-__global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__restrict__ terms, unsigned n_terms, size_t n, const G1Affine *__restrict__ mult,
-                                                   G1Affine *__restrict__ out) {
+__global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__restrict__ terms, unsigned n_terms, const G1Affine *__restrict__ T, int c, int W,
+                                                   BiasArg B, G1Affine *__restrict__ out) {
   const unsigned slot = blockIdx.x, lane = threadIdx.x;
+  const int half = 1 << (c - 1);
   G1X29 acc = G1X29::identity();
   for (unsigned t = 0; t < n_terms; ++t) {
     if (terms[t].slot != slot) continue;
@@ -744,19 +864,12 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
       s.l[2 * i] = (u32)terms[t].scalar.l[i];
       s.l[2 * i + 1] = (u32)(terms[t].scalar.l[i] >> 32);
     }
-    s = fp_from_mont<FrP>(s);
-    const bool neg = fr_gt_half(s);
-    if (neg) s = fp_neg<FrP>(s);
-    u32 carry = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u64 v = (u64)s.l[k] + 0x88888888u + carry;
-      s.l[k] = (u32)v;
-      carry = (u32)(v >> 32);
-    }
-    const int d = (int)((s.l[lane >> 3] >> ((lane & 7) * 4)) & 15u) - 8;   // window = lane
+    u32 sb[9];
+    int bits;
+    const bool neg = biased_scalar(s, B, sb, bits);
+    const int d = (int)lane < W ? (int)bits_at(sb, (int)lane * c, c) - half : 0;   // window = lane (W <= 64)
     if (d) {
-      const G1Affine p = mult[((size_t)lane * n + terms[t].row) * DM_MULTS + (d < 0 ? -d : d) - 1];
+      const G1Affine p = T[(((size_t)terms[t].row * W + lane) << (c - 1)) + (size_t)(d < 0 ? -d : d) - 1];
       g1x29_add_affine(acc, g1a29_load(p), neg != (d < 0));
     }
   }
@@ -767,49 +880,79 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
   if (lane == 0) out[slot] = g1x_to_affine(g1x29_to_std(acc));
 }
 
-// largest basis that gets a digit-multiple table, and the largest call (columns x n scalars) sent down the direct-sum path
-size_t direct_max_n() {
-  static long v = -1;
-  if (v < 0) {
-    const char *e = getenv("ZKFHE_DIRECT_MAX_LOGN");
-    v = 1L << (e ? atoi(e) : 16);
-    if (e && atoi(e) <= 0) v = 0;
-  }
-  return (size_t)v;
-}
-size_t direct_max_terms() {
-  static long v = -1;
-  if (v < 0) {
-    const char *e = getenv("ZKFHE_DIRECT_MAX_TERMS");
-    v = e ? atol(e) : (1L << 16);
-  }
-  return (size_t)v;
+// Window width of the digit-multiple table: the widest whose table fits the per-basis budget (ZKFHE_TABLE_GB, default 48;
+// ZKFHE_TABLE_BITS forces a width, 0 = no table: every call takes the bucket pipeline).
+int table_bits(size_t n) {
+  // read per basis (creation is rare): tests switch widths inside one process
+  const char *e = getenv("ZKFHE_TABLE_BITS");
+  const int forced = e ? atoi(e) : -1;
+  const char *g = getenv("ZKFHE_TABLE_GB");
+  const double budget = (g ? atof(g) : 48.0) * 1073741824.0;
+  auto fits = [&](int c) {
+    const double entries = (double)n * (double)((255 + c - 1) / c) * (double)(1u << (c - 1));
+    return c >= 8 && c <= 14 && entries < 2147483648.0 && entries * sizeof(G1Affine) <= budget;
+  };
+  if (forced >= 0) return forced > 0 && fits(forced) ? forced : 0;
+  for (int c = 14; c >= 8; --c)
+    if (fits(c)) return c;
+  return 0;
 }
 
-int msm_direct(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t col_stride, size_t n_cols, G1Affine *out) {
+BiasArg table_bias(int c, int W) {
+  BiasArg B;
+  memset(&B, 0, sizeof(B));
+  for (int w = 0; w < W; ++w) {
+    const int bit = c * w + c - 1;
+    B.l[bit >> 5] |= 1u << (bit & 31);
+  }
+  return B;
+}
+
+int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t col_stride, size_t n_cols, G1Affine *out) {
   const size_t n = basis->n;
+  const int c = basis->mc, W = basis->mw;
+  // n_part | col_next | adds
+  const size_t words = 2 * MSM_MAX_COLS + 4;
   if (!ctx->tickets) {
-    ZK_HIP(ctx, hipMalloc((void **)&ctx->tickets, 256 * sizeof(unsigned)));
-    ZK_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, 256 * sizeof(unsigned), ctx->stream));
+    ZK_HIP(ctx, hipMalloc((void **)&ctx->tickets, words * sizeof(unsigned)));
+    ZK_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, words * sizeof(unsigned), ctx->stream));
   }
-  // windows per thread: as few as keep about one wave per SIMD (a lane's chain is E - 1 additions + the 8-step fold)
-  const size_t simds = (size_t)ctx->num_cu * 4;
-  int E = 8;
-  while (E < 64 && n_cols * n * (DM_WINDOWS / E) / 64 > simds + simds / 2) E <<= 1;
-  const unsigned blocks_per_col = (unsigned)((n * (DM_WINDOWS / E) + 255) / 256);
-  void *p0;
-  int rc = zk_scratch(ctx, 0, n_cols * (size_t)blocks_per_col * sizeof(G1X), &p0);
+  unsigned *n_part = ctx->tickets, *col_next = ctx->tickets + MSM_MAX_COLS;
+  unsigned long long *adds = (unsigned long long *)(ctx->tickets + 2 * MSM_MAX_COLS);
+  const size_t grid_max = (size_t)ctx->num_cu * 3;
+  // chunk: 256 points when the call fills the chip that way, else 128 (a lone column of 2^13: 64 workgroups, 11 additions
+  // per thread and a 9-addition butterfly each -- a smaller chunk shortens the chain and multiplies the butterflies)
+  size_t P = 256;
+  while (P > 128 && n_cols * ((n + P - 1) / P) < grid_max) P >>= 1;
+  const size_t cpc = (n + P - 1) / P, n_items = n_cols * cpc;
+  const size_t grid = n_items < grid_max ? n_items : grid_max;
+  const size_t max_part = cpc < grid ? cpc : grid;   // visits to one column
+  const bool tree = n_cols <= 16;
+  const unsigned L = tree ? 1 : 256;
+  void *p0, *p1;
+  int rc = zk_scratch(ctx, 0, n_cols * max_part * L * sizeof(G1X), &p0);
   if (rc) return rc;
-  const unsigned grid = (unsigned)(n_cols * blocks_per_col);
+  rc = zk_scratch(ctx, 1, grid * P * (size_t)W * 4, &p1);
+  if (rc) return rc;
+  const bool big = n_cols * n > ((size_t)1 << 16);
+  const int slot = big ? 0 : 2;
+  if (ctx->prof_on) ZK_HIP(ctx, hipMemsetAsync(adds, 0, 8, ctx->stream));
   zk_prof_begin(ctx);
-  switch (E) {
-    case 8: k_msm_direct<8><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-    case 16: k_msm_direct<16><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-    case 32: k_msm_direct<32><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-    default: k_msm_direct<64><<<grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, blocks_per_col, (G1X *)p0, ctx->tickets, out); break;
-  }
+  if (tree)
+    k_msm_table<true><<<(unsigned)grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, c, W, table_bias(c, W), (unsigned)P, (unsigned)cpc, (unsigned)n_cols,
+                                                             (unsigned)max_part, (G1X *)p0, n_part, col_next, (unsigned *)p1, ctx->prof_on ? adds : nullptr);
+  else
+    k_msm_table<false><<<(unsigned)grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, c, W, table_bias(c, W), (unsigned)P, (unsigned)cpc, (unsigned)n_cols,
+                                                              (unsigned)max_part, (G1X *)p0, n_part, col_next, (unsigned *)p1, ctx->prof_on ? adds : nullptr);
   ZK_LAUNCH_CHECK(ctx);
-  zk_prof_end(ctx, 2, 96.0 * (double)n * (double)n_cols);
+  zk_prof_end(ctx, slot, 96.0 * (double)n * (double)n_cols);
+  k_msm_table_fold<<<(unsigned)n_cols, 256, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
+  ZK_LAUNCH_CHECK(ctx);
+  if (ctx->prof_on) {
+    unsigned long long h = 0;
+    ZK_HIP(ctx, hipMemcpy(&h, adds, 8, hipMemcpyDeviceToHost));
+    ctx->prof_ops[slot] += (double)h;
+  }
   return ZKFHE_OK;
 }
 
@@ -848,15 +991,18 @@ int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t
   ZK_HIP(ctx, hipMemcpyAsync(tmp, bases_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
   k_basis_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)tmp, n, c, windows, b->table);
   ZK_LAUNCH_CHECK(ctx);
-  if (window_bits == 0 && n >= 256 && n <= direct_max_n()) {
-    // digit-multiple table for calls of a few columns (k_msm_direct): 32 KiB per base point
-    e = hipMalloc((void **)&b->mult, n * (size_t)DM_WINDOWS * DM_MULTS * sizeof(G1Affine));
+  const int mc = window_bits == 0 && n >= 256 ? table_bits(n) : 0;
+  if (mc) {
+    // digit-multiple table (k_msm_table): every call against this basis is a plain sum of table points
+    b->mc = mc;
+    b->mw = (255 + mc - 1) / mc;
+    e = hipMalloc((void **)&b->mult, (n * (size_t)b->mw << (mc - 1)) * sizeof(G1Affine));
     if (e != hipSuccess) {
       hipFree(b->table);
       delete b;
       return zk_fail(ctx, e == hipErrorOutOfMemory ? ZKFHE_ENOMEM : ZKFHE_EHIP, "hipMalloc(basis multiples)", e, __FILE__, __LINE__);
     }
-    k_basis_multiples<<<zk_blocks(n, 64), 64, 0, ctx->stream>>>((const G1Affine *)tmp, n, b->mult);
+    k_basis_multiples<<<zk_blocks(n * (size_t)b->mw, 64), 64, 0, ctx->stream>>>((const G1Affine *)tmp, n, mc, b->mw, b->mult);
     ZK_LAUNCH_CHECK(ctx);
   }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -890,8 +1036,11 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, scalars_dev != nullptr && out_dev != nullptr && col_stride >= basis->n);
   const size_t n = basis->n;
-  if (basis->mult && n_cols <= 256 && n_cols * n <= direct_max_terms())
-    return msm_direct(ctx, basis, (const Fr *)scalars_dev, col_stride, n_cols, (G1Affine *)out_dev);
+  ZK_ARG(ctx, n_cols <= MSM_MAX_COLS);
+  // the table path when its windows are at most two more than the bucket pipeline's (whose sort and bucket reduction cost
+  // about that much), and always for calls of a few columns, where the pipeline's thirteen dependent launches are the cost
+  if (basis->mult && (basis->mw <= basis->windows + 2 || n_cols <= 8))
+    return msm_table(ctx, basis, (const Fr *)scalars_dev, col_stride, n_cols, (G1Affine *)out_dev);
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
@@ -1020,12 +1169,18 @@ extern "C" {
 int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots, zkfhe_g1_affine *out_dev) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, basis != nullptr && basis->mult != nullptr && terms_dev != nullptr && out_dev != nullptr && n_slots > 0 && n_slots <= 65535 && n_terms <= 4096);
-  k_msm_sparse<<<(unsigned)n_slots, 64, 0, ctx->stream>>>(terms_dev, (unsigned)n_terms, basis->n, basis->mult, (G1Affine *)out_dev);
+  k_msm_sparse<<<(unsigned)n_slots, 64, 0, ctx->stream>>>(terms_dev, (unsigned)n_terms, basis->mult, basis->mc, basis->mw, table_bias(basis->mc, basis->mw),
+                                                     (G1Affine *)out_dev);
   ZK_LAUNCH_CHECK(ctx);
   return ZKFHE_OK;
 }
 
 int zkfhe_basis_has_multiples(const zkfhe_basis *basis) { return basis && basis->mult ? 1 : 0; }
+
+int zkfhe_basis_table_bits(const zkfhe_basis *basis, int *wide_calls) {
+  if (wide_calls) *wide_calls = basis && basis->mult && basis->mw <= basis->windows + 2 ? 1 : 0;
+  return basis && basis->mult ? basis->mc : 0;
+}
 
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {
   ZK_ENTER(ctx);

@@ -506,8 +506,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const char *early_env = getenv("ZKFHE_EARLY_P1");
   const bool early_p1 = early_env && early_env[0] == '1' && !host_witness && cfg.n_lookup > 0 && cfg.lookup_bits == 8;
   GpuPhase1 g1(ctx, pk, ws);
-  // the few phase-0 columns go through the full-width basis: zkfhe_msm_batch takes its direct-sum path for them
-  const zkfhe_basis *p0_basis = (size_t)cfg.n_gate0 * n <= ((size_t)1 << 16) ? srs->g_lagrange : small_basis;
+  const zkfhe_basis *p0_basis = small_basis;
   if (host_witness) {
     CK(commit_cols(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p, pts));
   } else {

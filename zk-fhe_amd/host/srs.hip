@@ -54,7 +54,7 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
         const char *e = getenv("ZKFHE_SMALL_C");
         small_c = e ? atoi(e) : 10;
       }
-      if (small_c > 0 && k >= 12 && k <= 14) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, small_c, &srs->g_lagrange_small));
+      if (small_c > 0 && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, small_c, &srs->g_lagrange_small));
     }
   }
   sc.release();
@@ -81,13 +81,18 @@ int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_h
   srs->hi = n;
   int rc = zkfhe_basis_create(ctx, g_host, n, 0, &srs->g);
   if (!rc) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 0, &srs->g_lagrange);
-  if (!rc && k >= 12 && k <= 14) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
+  if (!rc && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
   if (rc) {
     zkfhe_srs_destroy(ctx, srs);
     return rc;
   }
   *out = srs;
   return ZKFHE_OK;
+}
+
+int zkfhe_srs_table_bits(const zkfhe_srs *srs, int *wide_calls) {
+  if (wide_calls) *wide_calls = 0;
+  return srs ? zkfhe_basis_table_bits(srs->g_lagrange, wide_calls) : 0;
 }
 
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {
