@@ -56,6 +56,8 @@ int main() {
     const F29 X = f29_sub(f29_add(A, B), C, P2), Y = f29_add(f29_neg(D, P4), A);
     const Fq xs = fp_sub<FqP>(fp_add<FqP>(a, b), c), ys = fp_sub<FqP>(a, d);
     if (!eq(times32(f29_pack(f29_canonical(f29_mul(X, Y)))), fp_mul<FqP>(xs, ys))) { if (bad++ < 5) printf("lazy mul mismatch at %d\n", it); }
+    if (!eq(times32(f29_pack(f29_canonical(f29_sqr(A)))), fp_mul<FqP>(a, a)) || !eq(times32(f29_pack(f29_canonical(f29_sqr(X)))), fp_mul<FqP>(xs, xs)) ||
+        !eq(times32(f29_pack(f29_canonical(f29_sqr(Y)))), fp_mul<FqP>(ys, ys))) { if (bad++ < 5) printf("sqr mismatch at %d\n", it); }
     if (!eq(f29_pack(f29_canonical(X)), xs) || !eq(f29_pack(f29_canonical(Y)), ys)) { if (bad++ < 5) printf("add/sub mismatch at %d\n", it); }
     const F29 W = f29_weak_reduce(f29_add(f29_add(X, Y), f29_add(X, Y)));   // < 16 p in
     if (!eq(f29_pack(f29_canonical(W)), fp_dbl<FqP>(fp_add<FqP>(xs, ys)))) { if (bad++ < 5) printf("weak reduce mismatch at %d\n", it); }

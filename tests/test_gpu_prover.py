@@ -184,13 +184,14 @@ def test_device_and_host_witness_generators_agree(ctx):
             host, inst_h, _ = pk.prove(text, b"w-%d" % i)
             assert inst_d == inst_h
             assert first_diff(dev, host) is None, "first differing 32-byte item: %s" % first_diff(dev, host)
-            # ZKFHE_EARLY_P1=1: the phase-1 columns committed before the challenge, the challenge-dependent cells as sparse
-            # corrections added afterwards -- the same points, hence the same bytes
+            # The default with the Poseidon transcript commits the phase-1 columns before the challenge and adds the
+            # challenge-dependent cells as sparse corrections afterwards (ZKFHE_EARLY_P1, prove.hip) -- the same points,
+            # hence the same bytes as with the plain order
             os.environ.pop("ZKFHE_WITNESS", None)
-            os.environ["ZKFHE_EARLY_P1"] = "1"
-            early, inst_e, _ = pk.prove(text, b"w-%d" % i)
+            os.environ["ZKFHE_EARLY_P1"] = "0"
+            plain, inst_e, _ = pk.prove(text, b"w-%d" % i)
             os.environ.pop("ZKFHE_EARLY_P1", None)
-            assert inst_e == inst_d and first_diff(early, dev) is None
+            assert inst_e == inst_d and first_diff(plain, dev) is None
     finally:
         os.environ.pop("ZKFHE_WITNESS", None)
         os.environ.pop("ZKFHE_EARLY_P1", None)

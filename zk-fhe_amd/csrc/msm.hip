@@ -938,7 +938,9 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
   const int slot = big ? 0 : 2;
   if (ctx->prof_on) ZK_HIP(ctx, hipMemsetAsync(adds, 0, 8, ctx->stream));
   zk_prof_begin(ctx);
-  if (tree)
+  static const char *exp_skip = getenv("ZKFHE_EXP_SKIP_MSM");
+  if (exp_skip && ((big && exp_skip[0] != 's') || (!big && exp_skip[0] == 's'))) {
+  } else if (tree)
     k_msm_table<true><<<(unsigned)grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, c, W, table_bias(c, W), (unsigned)P, (unsigned)cpc, (unsigned)n_cols,
                                                              (unsigned)max_part, (G1X *)p0, n_part, col_next, (unsigned *)p1, ctx->prof_on ? adds : nullptr);
   else

@@ -408,11 +408,12 @@ struct OpenItem {
 struct Trace {
   bool on;
   double t0, last;
-  Trace() : on(getenv("ZKFHE_TRACE") != nullptr), t0(now_ms()), last(t0) {}
+  unsigned long tid;   // proofs in flight on other threads: their lines interleave
+  Trace() : on(getenv("ZKFHE_TRACE") != nullptr), t0(now_ms()), last(t0), tid((unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) % 10000) {}
   void mark(const char *what) {
     if (!on) return;
     const double t = now_ms();
-    fprintf(stderr, "[zkfhe trace] %8.3f ms (+%7.3f) %s\n", t - t0, t - last, what);
+    fprintf(stderr, "[zkfhe trace %04lu] %8.3f ms (+%7.3f) %s\n", tid, t - t0, t - last, what);
     last = t;
   }
 };
@@ -500,11 +501,13 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   CK(blind_and_upload(0, cfg.n_gate0));
   trace.mark("blind + upload phase 0");
   const bool host_witness = witness_on_host();
-  // see "Early phase-1 commitment" below.  Opt-in (ZKFHE_EARLY_P1=1): measured with the Poseidon transcript it shortens a
-  // single wave of 20 concurrent proofs by 3.5 % (the GPU works while every proof hashes its public inputs) and costs 4.6 %
-  // in steady state (two extra small commitments per proof); with Blake2b there is nothing to hide.
+  // see "Early phase-1 commitment" below.  On with the Poseidon transcript, whose challenge after the phase-0 commitment is
+  // 2561 sequential permutations (the public inputs, ~20 ms of host time) away: measured on a wave of 20 concurrent proofs
+  // +9 % (the GPU commits while every proof hashes), -1.5 % in steady state (two extra small commitments per proof).  With
+  // Blake2b there is nothing to hide.  ZKFHE_EARLY_P1=0 / 1 overrides.
   const char *early_env = getenv("ZKFHE_EARLY_P1");
-  const bool early_p1 = early_env && early_env[0] == '1' && !host_witness && cfg.n_lookup > 0 && cfg.lookup_bits == 8;
+  const bool early_want = early_env ? early_env[0] == '1' : cfg.transcript == TR_POSEIDON;
+  const bool early_p1 = early_want && !host_witness && cfg.n_lookup > 0 && cfg.lookup_bits == 8;
   GpuPhase1 g1(ctx, pk, ws);
   const zkfhe_basis *p0_basis = small_basis;
   if (host_witness) {
