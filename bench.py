@@ -184,7 +184,7 @@ def main():
 
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, rocprofv3 --pmc)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["bytes_per_launch"] if (not big and table_wide) else None
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r2b_pmc_traffic.json")))["bytes_per_launch"] if (not big and table_wide) else None
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:

@@ -938,9 +938,7 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
   const int slot = big ? 0 : 2;
   if (ctx->prof_on) ZK_HIP(ctx, hipMemsetAsync(adds, 0, 8, ctx->stream));
   zk_prof_begin(ctx);
-  static const char *exp_skip = getenv("ZKFHE_EXP_SKIP_MSM");
-  if (exp_skip && ((big && exp_skip[0] != 's') || (!big && exp_skip[0] == 's'))) {
-  } else if (tree)
+  if (tree)
     k_msm_table<true><<<(unsigned)grid, 256, 0, ctx->stream>>>(scalars, col_stride, n, basis->mult, c, W, table_bias(c, W), (unsigned)P, (unsigned)cpc, (unsigned)n_cols,
                                                              (unsigned)max_part, (G1X *)p0, n_part, col_next, (unsigned *)p1, ctx->prof_on ? adds : nullptr);
   else
@@ -1041,7 +1039,9 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
   ZK_ARG(ctx, n_cols <= MSM_MAX_COLS);
   // the table path when its windows are at most two more than the bucket pipeline's (whose sort and bucket reduction cost
   // about that much), and always for calls of a few columns, where the pipeline's thirteen dependent launches are the cost
-  if (basis->mult && (basis->mw <= basis->windows + 2 || n_cols <= 8))
+  static const char *wide_env = getenv("ZKFHE_TABLE_WIDE");   // 1 / 0: force the choice for calls of many columns
+  const bool wide = wide_env ? wide_env[0] == '1' : basis->mw <= basis->windows + 2;
+  if (basis->mult && (wide || n_cols <= 8))
     return msm_table(ctx, basis, (const Fr *)scalars_dev, col_stride, n_cols, (G1Affine *)out_dev);
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
@@ -1180,7 +1180,8 @@ int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_spars
 int zkfhe_basis_has_multiples(const zkfhe_basis *basis) { return basis && basis->mult ? 1 : 0; }
 
 int zkfhe_basis_table_bits(const zkfhe_basis *basis, int *wide_calls) {
-  if (wide_calls) *wide_calls = basis && basis->mult && basis->mw <= basis->windows + 2 ? 1 : 0;
+  const char *wide_env = getenv("ZKFHE_TABLE_WIDE");
+  if (wide_calls) *wide_calls = basis && basis->mult && (wide_env ? wide_env[0] == '1' : basis->mw <= basis->windows + 2) ? 1 : 0;
   return basis && basis->mult ? basis->mc : 0;
 }
 

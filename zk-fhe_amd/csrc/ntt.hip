@@ -178,8 +178,6 @@ __global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows
 }
 
 int launch_tile_dyn(zkfhe_ctx *ctx, int log_tile, const TileArgs &a, unsigned tiles, unsigned cols) {
-  static const bool exp_skip = getenv("ZKFHE_EXP_SKIP_NTT") != nullptr;
-  if (exp_skip && log_tile == 13) return 0;
   switch (log_tile) {
     case 3: return zk_launch_tile_3(ctx, a, tiles, cols);
     case 4: return zk_launch_tile_4(ctx, a, tiles, cols);

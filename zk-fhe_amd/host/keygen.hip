@@ -7,12 +7,22 @@ std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const st
   if (ws->polyio.bytes < 2 * n * 8 + 2 * n * 32) throw std::runtime_error("polynomial too long for the prover workspace");
   uint64_t *da = (uint64_t *)ws->polyio.p, *db = da + n;
   Fr *dout = (Fr *)(db + n);
-  std::vector<U256> host(2 * n - 1);
-  int rc = zkfhe_upload(ctx, da, a.data(), n * 8);
-  if (!rc) rc = zkfhe_upload(ctx, db, b.data(), n * 8);
+  // operands through the pinned ring, the product back into pinned memory: pageable copies take a process-wide staging
+  // path in the runtime, and twenty proofs starting together queued on it (5 ms per product instead of 0.25)
+  std::vector<U256> pageable;
+  const U256 *host = ws->host_poly;
+  int rc = up(ctx, ws, da, a.data(), n * 8);
+  if (!rc) rc = up(ctx, ws, db, b.data(), n * 8);
   if (!rc) rc = zkfhe_witness_poly_mul_u64(ctx, da, db, n, (zkfhe_fr *)dout);
   if (!rc) rc = zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)dout, (zkfhe_fr *)dout, 2 * n - 1);
-  if (!rc) rc = zkfhe_download(ctx, host.data(), dout, (2 * n - 1) * 32);
+  if (!rc && ws->host_poly && 2 * n - 1 <= ws->host_poly_len) {
+    if (hipMemcpyAsync(ws->host_poly, dout, (2 * n - 1) * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZKFHE_EHIP;
+    if (!rc) rc = zkfhe_sync(ctx);
+  } else if (!rc) {
+    pageable.resize(2 * n - 1);
+    host = pageable.data();
+    rc = zkfhe_download(ctx, pageable.data(), dout, (2 * n - 1) * 32);
+  }
   if (rc) throw std::runtime_error(std::string("GPU poly mul failed: ") + zkfhe_last_error(ctx));
   std::vector<BigInt> out(2 * n - 1);
   for (size_t i = 0; i < out.size(); ++i) out[i] = fe::to_bigint(host[i]);
@@ -72,7 +82,7 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int e
 void free_workspace(Workspace *ws) {
   (void)hipSetDevice(ws->all_l.device);
   for (DevBuf *b : ws->all()) b->release();
-  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_pts, (void *)ws->ring, (void *)ws->host_rand_pt,
+  for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_poly, (void *)ws->host_pts, (void *)ws->ring, (void *)ws->host_rand_pt,
                   (void *)ws->host_early, (void *)ws->host_early_err})
     if (h) (void)hipHostFree(h);
   if (ws->ev_pts) (void)hipEventDestroy(ws->ev_pts);

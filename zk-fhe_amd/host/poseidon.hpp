@@ -78,7 +78,7 @@ inline F from_canon(const U256 &v) {
   memcpy(a.l, v.l, 32);
   return mul(a, R2);
 }
-inline U256 to_canon(const F &a) {
+inline U256 to_canon(const F &a) {   // a below 2 r
   const F r = mul(a, F{{1, 0, 0, 0}});
   U256 v;
   memcpy(v.l, r.l, 32);
@@ -96,6 +96,153 @@ inline F inv(const F &a) {  // a^(r-2); used nine times, for the Cauchy matrix
     b = mul(b, b);
   }
   return r;
+}
+
+// ---- "weak" arithmetic of the permutation: values below 2 r, reduced only when they leave the sponge -------------------
+// r < 2^254, so with R = 2^256 a Montgomery product of two values below 2 r is again below 2 r (4 r^2 / R + r < 1.76 r): the
+// conditional subtraction after every product goes.  A three-term inner product is reduced ONCE (48 + 20 word products
+// instead of 108), a square takes 10 + 20 instead of 36.
+static const uint64_t P2[4] = {0x87c3eb27e0000002ULL, 0x5067d090f372e122ULL, 0x70a08b6d0302b0baULL, 0x60c89ce5c2634053ULL};  // 2 r
+
+// t < 4 r  ->  t - 2 r if t >= 2 r else t
+inline F fold_2r(uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3) {
+  unsigned long long br;
+  const uint64_t r0 = __builtin_subcll(t0, P2[0], 0, &br);
+  const uint64_t r1 = __builtin_subcll(t1, P2[1], br, &br);
+  const uint64_t r2 = __builtin_subcll(t2, P2[2], br, &br);
+  const uint64_t r3 = __builtin_subcll(t3, P2[3], br, &br);
+  const uint64_t keep = (uint64_t)0 - (uint64_t)br;
+  return F{{(t0 & keep) | (r0 & ~keep), (t1 & keep) | (r1 & ~keep), (t2 & keep) | (r2 & ~keep), (t3 & keep) | (r3 & ~keep)}};
+}
+inline F addw(const F &a, const F &b) {   // a, b < 2 r -> < 2 r
+  unsigned long long c;
+  const uint64_t t0 = __builtin_addcll(a.l[0], b.l[0], 0, &c);
+  const uint64_t t1 = __builtin_addcll(a.l[1], b.l[1], c, &c);
+  const uint64_t t2 = __builtin_addcll(a.l[2], b.l[2], c, &c);
+  const uint64_t t3 = __builtin_addcll(a.l[3], b.l[3], c, &c);  // < 4 r < 2^256
+  return fold_2r(t0, t1, t2, t3);
+}
+inline F mulw(const F &a, const F &b) {   // a, b < 2 r -> < 2 r, no final subtraction
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t bi = b.l[i];
+    u128 A = (u128)a.l[0] * bi + t0;
+    const uint64_t m = (uint64_t)A * INV;
+    u128 C = (u128)m * P[0] + (uint64_t)A;
+    A = (u128)a.l[1] * bi + t1 + (uint64_t)(A >> 64);
+    C = (u128)m * P[1] + (uint64_t)A + (uint64_t)(C >> 64);
+    t0 = (uint64_t)C;
+    A = (u128)a.l[2] * bi + t2 + (uint64_t)(A >> 64);
+    C = (u128)m * P[2] + (uint64_t)A + (uint64_t)(C >> 64);
+    t1 = (uint64_t)C;
+    A = (u128)a.l[3] * bi + t3 + (uint64_t)(A >> 64);
+    C = (u128)m * P[3] + (uint64_t)A + (uint64_t)(C >> 64);
+    t2 = (uint64_t)C;
+    t3 = (uint64_t)(C >> 64) + (uint64_t)(A >> 64);
+  }
+  return F{{t0, t1, t2, t3}};
+}
+// T (eight words, below 0.8 * 2^512 - R r) -> T / R mod r, below T / R + r
+inline void mont_reduce_wide(uint64_t T[8], uint64_t out[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t m = T[i] * INV;
+    u128 C = (u128)m * P[0] + T[i];
+    C = (u128)m * P[1] + T[i + 1] + (uint64_t)(C >> 64);
+    T[i + 1] = (uint64_t)C;
+    C = (u128)m * P[2] + T[i + 2] + (uint64_t)(C >> 64);
+    T[i + 2] = (uint64_t)C;
+    C = (u128)m * P[3] + T[i + 3] + (uint64_t)(C >> 64);
+    T[i + 3] = (uint64_t)C;
+    unsigned long long c;
+    T[i + 4] = __builtin_addcll(T[i + 4], (uint64_t)(C >> 64), 0, &c);
+    for (int k = i + 5; k < 8; ++k) T[k] = __builtin_addcll(T[k], 0, c, &c);
+  }
+  out[0] = T[4], out[1] = T[5], out[2] = T[6], out[3] = T[7];
+}
+// T += a * b (eight-word accumulator, no carry out by the callers' bounds)
+inline void mac_wide(uint64_t T[8], const F &a, const F &b) {
+  uint64_t p[8];
+  u128 c = (u128)a.l[0] * b.l[0];
+  p[0] = (uint64_t)c;
+  c = (u128)a.l[1] * b.l[0] + (uint64_t)(c >> 64);
+  p[1] = (uint64_t)c;
+  c = (u128)a.l[2] * b.l[0] + (uint64_t)(c >> 64);
+  p[2] = (uint64_t)c;
+  c = (u128)a.l[3] * b.l[0] + (uint64_t)(c >> 64);
+  p[3] = (uint64_t)c;
+  p[4] = (uint64_t)(c >> 64);
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    c = (u128)a.l[0] * b.l[i] + p[i];
+    p[i] = (uint64_t)c;
+    c = (u128)a.l[1] * b.l[i] + p[i + 1] + (uint64_t)(c >> 64);
+    p[i + 1] = (uint64_t)c;
+    c = (u128)a.l[2] * b.l[i] + p[i + 2] + (uint64_t)(c >> 64);
+    p[i + 2] = (uint64_t)c;
+    c = (u128)a.l[3] * b.l[i] + p[i + 3] + (uint64_t)(c >> 64);
+    p[i + 3] = (uint64_t)c;
+    p[i + 4] = (uint64_t)(c >> 64);
+  }
+  unsigned long long cy = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) T[k] = __builtin_addcll(T[k], p[k], cy, &cy);
+}
+// m . s, constants m below r, s below 2 r: sum below 6 r^2, reduced once to below 2.2 r, folded below 2 r
+inline F dot3w(const F m[3], const F s[3]) {
+  uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[4];
+  mac_wide(T, m[0], s[0]);
+  mac_wide(T, m[1], s[1]);
+  mac_wide(T, m[2], s[2]);
+  mont_reduce_wide(T, o);
+  return fold_2r(o[0], o[1], o[2], o[3]);
+}
+// a^2, a below 2 r -> below 2 r: the six cross products once, doubled
+inline F sqrw(const F &a) {
+  uint64_t T[8], o[4];
+  u128 c = (u128)a.l[0] * a.l[1];
+  T[1] = (uint64_t)c;
+  c = (u128)a.l[0] * a.l[2] + (uint64_t)(c >> 64);
+  T[2] = (uint64_t)c;
+  c = (u128)a.l[0] * a.l[3] + (uint64_t)(c >> 64);
+  T[3] = (uint64_t)c;
+  T[4] = (uint64_t)(c >> 64);
+  c = (u128)a.l[1] * a.l[2] + T[3];
+  T[3] = (uint64_t)c;
+  c = (u128)a.l[1] * a.l[3] + T[4] + (uint64_t)(c >> 64);
+  T[4] = (uint64_t)c;
+  T[5] = (uint64_t)(c >> 64);
+  c = (u128)a.l[2] * a.l[3] + T[5];
+  T[5] = (uint64_t)c;
+  T[6] = (uint64_t)(c >> 64);
+  // double (the cross sum is below 2^509: the shifted-out bit is zero), then add the squares
+  T[7] = T[6] >> 63;
+  T[6] = (T[6] << 1) | (T[5] >> 63);
+  T[5] = (T[5] << 1) | (T[4] >> 63);
+  T[4] = (T[4] << 1) | (T[3] >> 63);
+  T[3] = (T[3] << 1) | (T[2] >> 63);
+  T[2] = (T[2] << 1) | (T[1] >> 63);
+  T[1] = T[1] << 1;
+  unsigned long long cy;
+  c = (u128)a.l[0] * a.l[0];
+  T[0] = (uint64_t)c;
+  T[1] = __builtin_addcll(T[1], (uint64_t)(c >> 64), 0, &cy);
+  c = (u128)a.l[1] * a.l[1];
+  T[2] = __builtin_addcll(T[2], (uint64_t)c, cy, &cy);
+  T[3] = __builtin_addcll(T[3], (uint64_t)(c >> 64), cy, &cy);
+  c = (u128)a.l[2] * a.l[2];
+  T[4] = __builtin_addcll(T[4], (uint64_t)c, cy, &cy);
+  T[5] = __builtin_addcll(T[5], (uint64_t)(c >> 64), cy, &cy);
+  c = (u128)a.l[3] * a.l[3];
+  T[6] = __builtin_addcll(T[6], (uint64_t)c, cy, &cy);
+  T[7] = __builtin_addcll(T[7], (uint64_t)(c >> 64), cy, &cy);
+  mont_reduce_wide(T, o);   // 4 r^2 / R + r < 1.76 r
+  return F{{o[0], o[1], o[2], o[3]}};
+}
+inline F pow5w(const F &x) { return mulw(sqrw(sqrw(x)), x); }
+inline F canon(const F &a) {   // below 2 r -> below r
+  return reduce_once(a.l[0], a.l[1], a.l[2], a.l[3]);
 }
 
 static const int T = 3, RATE = 2, R_F = 8, R_P = 57, ROUNDS = R_F + R_P;
@@ -228,24 +375,24 @@ inline const Constants &constants() {
 }
 
 inline void full_round(F s[T], const F rc[T], const F m[T][T]) {
-  const F a = pow5(add(s[0], rc[0])), b = pow5(add(s[1], rc[1])), d = pow5(add(s[2], rc[2]));
-  const F v[T] = {a, b, d};
-  s[0] = dot3(m[0], v);
-  s[1] = dot3(m[1], v);
-  s[2] = dot3(m[2], v);
+  const F v[T] = {pow5w(addw(s[0], rc[0])), pow5w(addw(s[1], rc[1])), pow5w(addw(s[2], rc[2]))};
+  s[0] = dot3w(m[0], v);
+  s[1] = dot3w(m[1], v);
+  s[2] = dot3w(m[2], v);
 }
 
+// state in, state out: below 2 r (weak); the constants are canonical
 inline void permute(F s[T]) {
   const Constants &c = constants();
   const int half = R_F / 2;
   for (int r = 0; r < half; ++r) full_round(s, c.rc[r], r == half - 1 ? c.pre : c.mds);
   for (int r = 0; r < R_P; ++r) {
-    const F x = pow5(add(s[0], c.pc[r][0]));
-    const F y = add(s[1], c.pc[r][1]), z = add(s[2], c.pc[r][2]);
+    const F x = pow5w(addw(s[0], c.pc[r][0]));
+    const F y = addw(s[1], c.pc[r][1]), z = addw(s[2], c.pc[r][2]);
     const F v[T] = {x, y, z};
-    s[0] = dot3(c.s_row[r], v);
-    s[1] = add(mul(c.s_col[r][0], x), y);
-    s[2] = add(mul(c.s_col[r][1], x), z);
+    s[0] = dot3w(c.s_row[r], v);
+    s[1] = addw(mulw(c.s_col[r][0], x), y);
+    s[2] = addw(mulw(c.s_col[r][1], x), z);
   }
   for (int r = half + R_P; r < ROUNDS; ++r) full_round(s, c.rc[r], c.mds);
 }
@@ -263,8 +410,8 @@ class Sponge {
   void update(const U256 &x) {
     buf[n_buf++] = from_canon(x);
     if (n_buf == RATE) {
-      st[1] = add(st[1], buf[0]);
-      st[2] = add(st[2], buf[1]);
+      st[1] = addw(st[1], buf[0]);
+      st[2] = addw(st[2], buf[1]);
       permute(st);
       n_buf = 0;
       ++n_perm;
@@ -273,10 +420,10 @@ class Sponge {
   U256 squeeze() {
     // what is left is a chunk of 0 or 1 elements: absorbed with a 1 in the first free word
     if (n_buf == 1) {
-      st[1] = add(st[1], buf[0]);
-      st[2] = add(st[2], ONE);
+      st[1] = addw(st[1], buf[0]);
+      st[2] = addw(st[2], ONE);
     } else {
-      st[1] = add(st[1], ONE);
+      st[1] = addw(st[1], ONE);
     }
     permute(st);
     n_buf = 0;

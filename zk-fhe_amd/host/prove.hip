@@ -14,6 +14,8 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   CK(ws->pool.alloc(ctx, 40 * (2 * N + 8) * 32));
   CK(ws->invtmp.alloc(ctx, (pk->n_inv_slots + 8) * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pool, 24 * (2 * N + 8) * 32, hipHostMallocDefault));
+  ws->host_poly_len = 2 * N + 8;
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_poly, ws->host_poly_len * 32, hipHostMallocDefault));
   CK(ws->wblind.alloc(ctx, 256));   // the lookup-permutation error flag
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->ring, Workspace::RING_BYTES, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));

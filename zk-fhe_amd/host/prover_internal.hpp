@@ -89,6 +89,8 @@ struct Workspace {
   U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
   U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
   U256 *host_pool = nullptr;   // pinned staging for the coefficient arrays of the GPU witness generator
+  U256 *host_poly = nullptr;   // pinned: the product of a phase-0 polynomial multiplication comes back here
+  size_t host_poly_len = 0;
   uint8_t *ring = nullptr;      // pinned bump arena for the small tables of one proof: uploads from it need no host wait
   size_t ring_off = 0;
   static constexpr size_t RING_BYTES = (size_t)4 << 20;
