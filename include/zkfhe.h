@@ -177,6 +177,11 @@ int zkfhe_g1_mul(zkfhe_ctx *ctx, const zkfhe_g1_affine *p_dev, const zkfhe_fr *k
  * out: 2N-1 Montgomery Fr values (exact integers, < 2^132 << r).  N a power of two <= 2^20. */
 int zkfhe_witness_poly_mul_u64(zkfhe_ctx *ctx, const uint64_t *a_dev, const uint64_t *b_dev, size_t n,
                                zkfhe_fr *out_dev);
+/* The same product on the host for short, narrow polynomials (n a power of two <= 2048, every coefficient below 2^32: the
+ * k = 13 circuit's pk_i * u): an exact NTT convolution over p = 2^64 - 2^32 + 1 on one core (host/poly_ntt64.hpp), which is
+ * what Poly::mul uses for them inside zkfhe_bfv_prove.  lo / hi: 2n - 1 coefficients as 128-bit integers.  ZKFHE_EINVAL when
+ * the operands do not fit. */
+int zkfhe_host_poly_mul_u32(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *lo, uint64_t *hi);
 /* RangeChip::div_mod witness (src/poly_chip.rs:236-246): for canonical values a[i] < 2^128 held as
  * Montgomery Fr, q a u64 modulus: div[i] = floor(a/q), rem[i] = a mod q (both returned as Montgomery Fr). */
 int zkfhe_witness_div_mod(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, uint64_t q, zkfhe_fr *div_dev,

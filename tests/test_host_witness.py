@@ -133,3 +133,44 @@ def test_mock_checks_every_row(pinned):
     bad["c0"][2] = str(PRM[1] + 1)
     with pytest.raises(zk.ZkfheError):
         zk.bfv_mock(json.dumps(bad), PRM, zcfg_nobp, GAMMA)
+
+
+def test_host_poly_mul_u32_is_the_integer_product():
+    """Poly::mul (src/poly.rs:75-103) for short narrow polynomials runs an NTT convolution over 2^64 - 2^32 + 1 on the host
+    (host/poly_ntt64.hpp, what the k = 13 prover uses for pk_i * u): every coefficient against Python integers -- random
+    32-bit operands, the all-maximum case (the largest sums: n * (2^32 - 1)^2), the ternary shape of u (0 / 1 / Q - 1), n = 2
+    and the largest n; operands that do not fit are refused."""
+    import ctypes
+    import numpy as np
+    import zk_fhe_amd as zk
+    lib = zk.load_library()
+    lib.zkfhe_host_poly_mul_u32.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t] + [ctypes.c_void_p] * 2
+    rng = np.random.default_rng(5)
+    Q = 536870909
+
+    def run(a, b):
+        n = len(a)
+        A, B = np.array(a, dtype=np.uint64), np.array(b, dtype=np.uint64)
+        lo, hi = np.zeros(2 * n - 1, dtype=np.uint64), np.zeros(2 * n - 1, dtype=np.uint64)
+        rc = lib.zkfhe_host_poly_mul_u32(A.ctypes.data, B.ctypes.data, n, lo.ctypes.data, hi.ctypes.data)
+        return rc, [int(lo[i]) | (int(hi[i]) << 64) for i in range(2 * n - 1)]
+
+    def want(a, b):
+        c = [0] * (2 * len(a) - 1)
+        for i, x in enumerate(a):
+            if x:
+                for j, y in enumerate(b):
+                    c[i + j] += x * y
+        return c
+
+    cases = [([3, 5], [7, 11])]
+    for n in (8, 256, 1024, 2048):
+        cases.append(([int(x) for x in rng.integers(0, 1 << 32, n)], [int(x) for x in rng.integers(0, 1 << 32, n)]))
+    cases.append(([(1 << 32) - 1] * 2048, [(1 << 32) - 1] * 2048))
+    cases.append(([int(x) for x in rng.integers(0, Q, 1024)], [[0, 1, Q - 1][int(t)] for t in rng.integers(0, 3, 1024)]))
+    for a, b in cases:
+        rc, got = run(a, b)
+        assert rc == 0 and got == want(a, b)
+    assert run([1 << 32, 1], [1, 1])[0] != 0          # a coefficient of 33 bits
+    assert run([1, 2, 3], [1, 2, 3])[0] != 0          # not a power of two
+    assert run([1] * 4096, [1] * 4096)[0] != 0        # too long

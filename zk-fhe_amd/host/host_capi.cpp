@@ -307,6 +307,17 @@ int zkfhe_transcript_bytes(const zkfhe_transcript *t, uint8_t *out, size_t cap, 
   return ZKFHE_OK;
 }
 
+int zkfhe_host_poly_mul_u32(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *lo, uint64_t *hi) {
+  if (!a || !b || !lo || !hi) return ZKFHE_EINVAL;
+  const std::vector<uint64_t> va(a, a + n), vb(b, b + n);
+  if (!gl::fits(va, vb)) return ZKFHE_EINVAL;
+  std::vector<uint64_t> l, h;
+  gl::poly_mul_u32(va, vb, l, h);
+  memcpy(lo, l.data(), l.size() * 8);
+  memcpy(hi, h.data(), h.size() * 8);
+  return ZKFHE_OK;
+}
+
 int zkfhe_poseidon_permute(uint8_t state_le[96]) {
   if (!state_le) return ZKFHE_EINVAL;
   pos::F s[3];

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "halo2_base.hpp"
+#include "poly_ntt64.hpp"
 
 namespace zkhost {
 
@@ -82,11 +83,31 @@ class Poly {
         c[i] += coefficients[i];
         c[i + db] += coefficients[i];
       }
-    } else if (small && poly_mul_backend() && ((da + 1) & da) == 0) {
+    } else if (small && ((da + 1) & da) == 0 && (poly_mul_backend() || (da + 1 <= 2048 && max_bits <= 32 && other.max_bits <= 32))) {
       std::vector<uint64_t> a(da + 1), b(db + 1);
       for (size_t i = 0; i <= da; ++i) a[i] = coefficients[i].to_u64();
       for (size_t i = 0; i <= db; ++i) b[i] = other.coefficients[i].to_u64();
-      c = poly_mul_backend()->mul_u64(a, b);
+      if (gl::fits(a, b)) {
+        // short and narrow (N <= 2048, 32-bit coefficients): exact NTT convolution on this core (poly_ntt64.hpp)
+        std::vector<uint64_t> lo, hi;
+        gl::poly_mul_u32(a, b, lo, hi);
+        c.resize(lo.size());
+        for (size_t i = 0; i < c.size(); ++i) {
+          U256 v = fe::zero();
+          v.l[0] = lo[i];
+          v.l[1] = hi[i];
+          c[i] = fe::to_bigint(v);
+        }
+      } else if (poly_mul_backend()) {
+        c = poly_mul_backend()->mul_u64(a, b);
+      } else {
+        c.assign(da + db + 1, BigInt());
+        for (size_t i = 0; i <= da; ++i) {
+          if (coefficients[i].is_zero()) continue;
+          for (size_t j = 0; j <= db; ++j)
+            if (!other.coefficients[j].is_zero()) c[i + j] += coefficients[i] * other.coefficients[j];
+        }
+      }
     } else {
       c.assign(da + db + 1, BigInt());
       for (size_t i = 0; i <= da; ++i) {
