@@ -991,19 +991,26 @@ int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t
   ZK_HIP(ctx, hipMemcpyAsync(tmp, bases_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
   k_basis_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)tmp, n, c, windows, b->table);
   ZK_LAUNCH_CHECK(ctx);
-  const int mc = window_bits == 0 && n >= 256 ? table_bits(n) : 0;
-  if (mc) {
-    // digit-multiple table (k_msm_table): every call against this basis is a plain sum of table points
-    b->mc = mc;
-    b->mw = (255 + mc - 1) / mc;
-    e = hipMalloc((void **)&b->mult, (n * (size_t)b->mw << (mc - 1)) * sizeof(G1Affine));
+  int mc = window_bits == 0 && n >= 256 ? table_bits(n) : 0;
+  // a digit-multiple table (k_msm_table): every call against this basis becomes a plain sum of table points.  It is an
+  // accelerator, not a requirement: on a device that does not have the room (other tenants, many SRS alive) the width drops
+  // until it fits, and without any table the calls take the bucket pipeline
+  for (; mc >= 8; --mc) {
+    const int mw = (255 + mc - 1) / mc;
+    const size_t bytes = (n * (size_t)mw << (mc - 1)) * sizeof(G1Affine);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + total_b / 8) continue;   // an eighth of the device stays free for proving keys and workspaces
+    e = hipMalloc((void **)&b->mult, bytes);
     if (e != hipSuccess) {
-      hipFree(b->table);
-      delete b;
-      return zk_fail(ctx, e == hipErrorOutOfMemory ? ZKFHE_ENOMEM : ZKFHE_EHIP, "hipMalloc(basis multiples)", e, __FILE__, __LINE__);
+      (void)hipGetLastError();
+      b->mult = nullptr;
+      continue;
     }
-    k_basis_multiples<<<zk_blocks(n * (size_t)b->mw, 64), 64, 0, ctx->stream>>>((const G1Affine *)tmp, n, mc, b->mw, b->mult);
+    b->mc = mc;
+    b->mw = mw;
+    k_basis_multiples<<<zk_blocks(n * (size_t)mw, 64), 64, 0, ctx->stream>>>((const G1Affine *)tmp, n, mc, mw, b->mult);
     ZK_LAUNCH_CHECK(ctx);
+    break;
   }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = b;
