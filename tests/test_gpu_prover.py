@@ -260,15 +260,24 @@ def test_proving_key_save_and_load(ctx, tmp_path):
     assert proof2 == proof and inst2 == inst
     pk2.destroy()
     raw = bytearray(open(path, "rb").read())
-    for damage in ("magic", "commit", "short"):
+    # where the BFV parameters sit: magic | 8 x u32 | three break-point lists (u64 count + u32 each) | N Q T B
+    off = 8 + 32
+    for _ in range(3):
+        off += 8 + 4 * int.from_bytes(raw[off:off + 8], "little")
+    assert int.from_bytes(raw[off:off + 8], "little") == 1024 and int.from_bytes(raw[off + 8:off + 16], "little") == prm.Q
+    for damage in ("magic", "commit", "short", "ring degree", "modulus"):
         bad = bytearray(raw)
         if damage == "magic":
             bad[0] ^= 1
+        elif damage == "ring degree":
+            bad[off:off + 8] = (2048).to_bytes(8, "little")          # 5 N + 1 public inputs no longer fit the usable rows
+        elif damage == "modulus":
+            bad[off + 8:off + 16] = (1 << 63).to_bytes(8, "little")  # outside the range the witness kernels divide by
         elif damage == "commit":
             bad[len(raw) - (163 + 199) * 8192 * 32 - 8 - 32 - 64] ^= 1     # inside the last sigma commitment
         else:
             bad = bad[: len(bad) // 2]
-        p2 = str(tmp_path / ("bad_%s.pk" % damage))
+        p2 = str(tmp_path / ("bad_%s.pk" % damage.replace(" ", "_")))
         open(p2, "wb").write(bytes(bad))
         with pytest.raises(zk.ZkfheError):
             zk.BfvProvingKey.load(ctx, srs, p2, 1024)

@@ -436,6 +436,11 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
     cfg.bp_gate0 = r.vec32(1 << 16), cfg.bp_gate1 = r.vec32(1 << 16), cfg.bp_rlc = r.vec32(1 << 16);
     pk->prm.N = r.u64(), pk->prm.Q = r.u64(), pk->prm.T = r.u64(), pk->prm.B = r.u64();
     pk->gate1_cells = r.u64();
+    // the parameters against the layout they were keyed for: N a power of two whose 5 N + 1 public inputs fit the usable
+    // rows, Q within the range the witness kernels divide by, T and B below Q
+    if (!r.ok || pk->prm.N < 2 || (pk->prm.N & (pk->prm.N - 1)) || 5 * (uint64_t)pk->prm.N + 1 > cfg.u() || pk->prm.Q < 2 ||
+        pk->prm.Q >= ((uint64_t)1 << 63) || pk->prm.T < 1 || pk->prm.T >= pk->prm.Q || pk->prm.B >= pk->prm.Q)
+      return fail("BFV parameters do not fit the recorded layout");
     const size_t n = cfg.n(), max_cells = (size_t)cfg.n_gate1 * n;
     const std::vector<uint32_t> lookup_src = r.vec32(max_cells), inv_slots = r.vec32(max_cells), place_start = r.vec32(cfg.n_gate1), place_len = r.vec32(cfg.n_gate1);
     if (!r.ok || pk->gate1_cells > max_cells || place_start.size() != cfg.n_gate1 || place_len.size() != cfg.n_gate1) return fail("bad structure lists");
