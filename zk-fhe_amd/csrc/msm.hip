@@ -5,7 +5,8 @@
 // The result is a group element, so any exact algorithm gives identical bytes once normalised to
 // affine; parity is checked against oracle/oracle.c orc_msm.
 //
-// Algorithm: Pippenger with ONE bucket set per MSM and per-window precomputed bases.
+// Two algorithms.  (1) The bucket pipeline -- Pippenger with ONE bucket set per MSM and per-window precomputed bases (wide calls
+// at n >= 2^15, every call at n >= 2^18):
 //   * The SRS is fixed, HBM is 288 GB: zkfhe_basis_create stores T[w][i] = 2^(c*w) * P_i for every
 //     signed window w (n*W*64 bytes; 10 MiB at n = 2^13, c = 13).  Digit d of scalar i in window w then
 //     contributes sign(d) * T[w][i] to bucket |d| -- all windows share the same 2^(c-1) buckets, so
@@ -20,19 +21,19 @@
 //     cells).  A bucket's partials are merged by a thread (<= 8), by eight lanes (<= 128) or by a wave.
 //   * bucket reduction sum_b b*B_b for K <= 32768 buckets: idx = 64 a + b; row and column marginal sums, then per MSM a
 //     lane-parallel double-and-add over the marginals and a shuffle tree; the result is normalised to affine in the
-//     same kernel (k_msm_marginals, k_msm_weighted; k_msm_reduce is the generic fallback for larger K).
+//     same kernel (k_msm_marginals, k_msm_weighted; k_msm_small for fewer than 64 buckets).
 // All MSMs of a batch (columns sharing the basis) run through each stage in ONE launch.
 //
 // Field arithmetic of every kernel between the tables and the final normalisation: radix 2^29, nine limbs, Montgomery
 // constant 2^261 (fq29.hip.hpp: 162 carry-free multiply-adds per product instead of 128 multiply-add + carry pairs, lazy
 // reduction in the point formulas).  The tables, partials, buckets and marginals hold packed 256-bit words in that
-// form; k_msm_weighted / k_msm_direct convert the one result per MSM back before normalising it.
+// form; k_msm_weighted / k_msm_table_fold convert the one result per MSM back before normalising it.
 //
-// When the digit-multiple table of a basis fits its HBM budget (zkfhe_basis_create: 43 GB per SRS half at n = 2^13, 13-bit
+// (2) When the digit-multiple table of a basis fits its HBM budget (zkfhe_basis_create: 43 GB per SRS half at n = 2^13, 13-bit
 // digits) the whole pipeline above is replaced by k_msm_table: T[i][w][j] = j * 2^(13 w) * P_i is resident, so an MSM is a
 // plain sum of <= 20 n table points per column -- no sort, no buckets, no weights, one launch (+ a fold) instead of
 // thirteen.  Same additions as the bucket pipeline's accumulation, none of the rest: 0.9x the VALU instructions on full-width
-// columns, 0.67x on witness columns, and 0.2 ms instead of 0.54 for a lone column (profiles/r2_msm_table.md).  The bucket
+// columns, 0.75x on witness columns, and 0.2 ms instead of 0.54 for a lone column (profiles/r2b_msm_table.md).  The bucket
 // pipeline stays for bases whose table would not fit (n >= 2^18) or would force so many more windows that it loses.
 #include <vector>
 #include <cstring>
