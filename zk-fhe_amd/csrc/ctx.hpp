@@ -31,11 +31,11 @@ struct zkfhe_ctx {
   int num_cu = 0;
   std::map<int, NttDomain> domains;
   // grow-only scratch arenas (bytes)
-  // profiling (zkfhe_prof_*): [0] = k_msm_accumulate, [1] = k_ntt_tile
+  // profiling (zkfhe_prof_*): [0] = the summing kernel of a wide MSM call (k_msm_table / k_msm_accumulate), [1] = k_ntt_tile
   bool prof_on = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: host waits sleep instead of spinning (zk_wait)
-  double prof_ms[3] = {0, 0, 0}, prof_bytes[3] = {0, 0, 0}, prof_ops[3] = {0, 0, 0};   // [2] = k_msm_direct
+  double prof_ms[3] = {0, 0, 0}, prof_bytes[3] = {0, 0, 0}, prof_ops[3] = {0, 0, 0};   // [2] = k_msm_table of a call of a few columns
   uint64_t prof_launches[3] = {0, 0, 0};
   // pinned bounce buffer for small host<->device transfers (pageable copies go through the runtime's shared staging path)
   void *bounce = nullptr;
