@@ -116,3 +116,31 @@ def test_host_transcript_random_schedule(kind):
             assert host.squeeze() == orc.squeeze()
     assert host.squeeze() == orc.squeeze()
     assert host.stream() == bytes(orc.out)
+
+
+def test_vector_and_scalar_permutation_agree():
+    """host/poseidon_ifma.cpp runs the multiplications by constants of the permutation on AVX-512 IFMA lanes (when the CPU has
+    them) beside the scalar S-box chain; ZKFHE_POSEIDON_SCALAR=1 keeps everything on the scalar path.  The same 400 chained and
+    random permutations in a subprocess with the variable set and in this process must agree word for word (on a CPU without
+    IFMA both runs take the scalar path and the test is vacuous, which it says)."""
+    import subprocess
+    import sys
+    prog = (
+        "import sys, random; sys.path.insert(0, ROOT); import zk_fhe_amd as zk\n"
+        "R = 21888242871839275222246405745257275088548364400416034343698204186575808495617\n"
+        "rnd = random.Random(7); st = [1, 2, 3]; out = []\n"
+        "for i in range(400):\n"
+        "    st = zk.poseidon_permute(st if i & 1 else [rnd.randrange(R) for _ in range(3)]); out.append(st)\n"
+        "edge = [[0, 0, 0], [R - 1, R - 1, R - 1], [1 << 253, (1 << 253) + 1, R - 2]]\n"
+        "out += [zk.poseidon_permute(e) for e in edge]\n"
+        "print(' '.join(hex(x) for s in out for x in s))\n"
+    ).replace("ROOT", repr(os.path.dirname(HERE)))
+    env = dict(os.environ)
+    env.pop("ZKFHE_POSEIDON_SCALAR", None)
+    a = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True).stdout.strip()
+    env["ZKFHE_POSEIDON_SCALAR"] = "1"
+    b = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True).stdout.strip()
+    assert a == b and len(a) > 10
+    flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    if "avx512ifma" not in flags:
+        print("no AVX-512 IFMA on this CPU: both runs took the scalar path")

@@ -55,7 +55,11 @@ def newest_header(host):
 
 
 def compile_one(src, obj, extra):
-    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    if src.endswith(".cpp"):
+        # host-only translation units (C ABI glue, verifier, the AVX-512 Poseidon core): plain C++, no device pass
+        cmd = [hipcc(), "-x", "c++"] + [f for f in FLAGS if not f.startswith("--offload-arch")] + extra + ["-c", src, "-o", obj]
+    else:
+        cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (os.path.basename(obj), r.stdout[-4000:]))

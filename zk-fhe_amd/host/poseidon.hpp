@@ -381,11 +381,12 @@ inline void full_round(F s[T], const F rc[T], const F m[T][T]) {
   s[2] = dot3w(m[2], v);
 }
 
-// state in, state out: below 2 r (weak); the constants are canonical
-inline void permute(F s[T]) {
+// poseidon_ifma.cpp: the permutation with the multiplications by constants on AVX-512 IFMA lanes beside the S-box chain;
+// false (nothing done) on a CPU without IFMA or with ZKFHE_POSEIDON_SCALAR set
+bool permute_ifma(F s[T]);
+
+inline void partial_rounds_scalar(F s[T]) {
   const Constants &c = constants();
-  const int half = R_F / 2;
-  for (int r = 0; r < half; ++r) full_round(s, c.rc[r], r == half - 1 ? c.pre : c.mds);
   for (int r = 0; r < R_P; ++r) {
     const F x = pow5w(addw(s[0], c.pc[r][0]));
     const F y = addw(s[1], c.pc[r][1]), z = addw(s[2], c.pc[r][2]);
@@ -394,7 +395,18 @@ inline void permute(F s[T]) {
     s[1] = addw(mulw(c.s_col[r][0], x), y);
     s[2] = addw(mulw(c.s_col[r][1], x), z);
   }
+}
+
+// state in, state out: below 2 r (weak); the constants are canonical
+inline void permute_scalar(F s[T]) {
+  const Constants &c = constants();
+  const int half = R_F / 2;
+  for (int r = 0; r < half; ++r) full_round(s, c.rc[r], r == half - 1 ? c.pre : c.mds);
+  partial_rounds_scalar(s);
   for (int r = half + R_P; r < ROUNDS; ++r) full_round(s, c.rc[r], c.mds);
+}
+inline void permute(F s[T]) {
+  if (!permute_ifma(s)) permute_scalar(s);
 }
 
 // snark-verifier util/hash/poseidon.rs `Poseidon<F, L, 3, 2>`.  Full chunks are permuted as they arrive (the result is the
