@@ -75,32 +75,7 @@ class Rng:
         return [self.next() for _ in range(k)]
 
 
-def point_compress(P):
-    """32-byte LE x; bit 7 of byte 31 = y & 1; bit 6 = identity"""
-    if P is None:
-        b = bytearray(32)
-        b[31] |= 0x40
-        return bytes(b)
-    x, y = P
-    b = bytearray(x.to_bytes(32, "little"))
-    if y & 1:
-        b[31] |= 0x80
-    return bytes(b)
-
-
-def point_decompress(b):
-    b = bytearray(b)
-    if b[31] & 0x40:
-        return None
-    sign = b[31] >> 7
-    b[31] &= 0x3F
-    x = int.from_bytes(b, "little")
-    y2 = (x * x * x + 3) % Q
-    y = pow(y2, (Q + 1) // 4, Q)
-    assert y * y % Q == y2, "not on curve"
-    if (y & 1) != sign:
-        y = Q - y
-    return (x, y)
+from oracle.point_encoding import point_compress, point_decompress  # noqa: E402,F401  (the one definition of the layout)
 
 
 class Blake2bTranscript:

@@ -143,34 +143,7 @@ class Sponge:
         return self.state[1]
 
 
-def point_compress(P):
-    """halo2curves bn256 G1Affine::to_bytes: 32-byte LE x, bit 7 of byte 31 = y & 1 (sign), bit 6 = identity"""
-    if P is None:
-        b = bytearray(32)
-        b[31] |= 0x40
-        return bytes(b)
-    x, y = P
-    b = bytearray(x.to_bytes(32, "little"))
-    if y & 1:
-        b[31] |= 0x80
-    return bytes(b)
-
-
-def point_decompress(b):
-    b = bytearray(b)
-    if b[31] & 0x40:
-        assert not any(b[:31]) and b[31] == 0x40, "non-canonical identity encoding"
-        return None
-    sign = b[31] >> 7
-    b[31] &= 0x3F
-    x = int.from_bytes(b, "little")
-    assert x < Q, "x coordinate not canonical"
-    y2 = (x * x * x + 3) % Q
-    y = pow(y2, (Q + 1) // 4, Q)
-    assert y * y % Q == y2, "not on curve"
-    if (y & 1) != sign:
-        y = Q - y
-    return (x, y)
+from oracle.point_encoding import point_compress, point_decompress  # noqa: E402,F401  (the one definition of the layout)
 
 
 class PoseidonTranscript:

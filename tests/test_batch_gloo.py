@@ -110,34 +110,54 @@ def test_point_ranges_partition():
         assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
 
 
-# ---- intra-proof sharding with the REAL prover: two ranks share GPU 0, the all-gather of the partial commitments goes through
+# ---- intra-proof sharding with the REAL prover: the ranks share GPU 0, the all-gather of the partial commitments goes through
 # gloo (zkfhe_comm_create_with_transport); on an 8-GPU node the same library path runs over RCCL (zkfhe_comm_create).
-def _sharded_worker(rank, world, port, out):
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden", "bfv")
+
+
+def _circuit(which):
+    """(keygen input text, proving input text, (N, Q, T, B), config maker) for "toy" (k = 9, N = 8) and "bfv13" (the reference's
+    data/bfv/bfv.in at k = 13 with the pinned configs/bfv.json layout)."""
+    import zk_fhe_amd as zk
+    from oracle import circuit_ref as C
+    if which == "toy":
+        from tests.test_proof_oracle import synth_input
+        prm = C.BfvParams(N=8)
+        inp = json.dumps(synth_input(8, prm.Q, prm.T, prm.B, 1))
+        cfg = zk.bfv_auto_config(inp, (8, prm.Q, prm.T, prm.B), 9, unusable_rows=9)
+        return inp, inp, (8, prm.Q, prm.T, prm.B), cfg, 9
+    prm = C.BfvParams()
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    return (open(os.path.join(G, "bfv_empty.in")).read(), open(os.path.join(G, "bfv.in")).read(), (1024, prm.Q, prm.T, prm.B),
+            zk.BfvConfig.from_pinning(cfgj), 13)
+
+
+def _sharded_worker(rank, world, port, which, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("ZKFHE_TABLE_GB", "4")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import torch  # noqa: F401
     import zk_fhe_amd as zk
-    from oracle import circuit_ref as C
-    from tests.test_proof_oracle import synth_input
     ctx = zk.Context(0)
-    prm = C.BfvParams(N=8)
-    inp = json.dumps(synth_input(8, prm.Q, prm.T, prm.B, 1))
-    cfg = zk.bfv_auto_config(inp, (8, prm.Q, prm.T, prm.B), 9, unusable_rows=9)
+    text_kg, text, params, cfg, k = _circuit(which)
     comm = zk.Comm(ctx, rank, world, all_gather=lambda b: B.all_gather_bytes(b, world))
-    lo, hi = comm.point_range(512)
-    srs = zk.Srs(ctx, 9, comm=comm)
-    pk = zk.BfvProvingKey(ctx, srs, inp, (8, prm.Q, prm.T, prm.B), cfg)
-    proof, inst, _ = pk.prove(inp, b"shard")
+    lo, hi = comm.point_range(1 << k)
+    srs = zk.Srs(ctx, k, comm=comm)
+    pk = zk.BfvProvingKey(ctx, srs, text_kg, params, cfg)
+    proof, inst, _ = pk.prove(text, b"shard")
     info = pk.info()
-    # a k = 13 column batch through zkfhe_msm_batch_sharded directly as well: 5 columns x 8192 over the two point ranges
-    res = {"rank": rank, "range": (lo, hi), "proof": proof, "inst": list(inst), "vk": info["vk_digest"]}
+    res = {"rank": rank, "range": (lo, hi), "proof": proof, "inst": list(inst), "vk": info["vk_digest"], "table_bits": srs.table_bits()}
     if rank == 0:
         # the unsharded reference on the same GPU, same seed
-        srs1 = zk.Srs(ctx, 9)
-        pk1 = zk.BfvProvingKey(ctx, srs1, inp, (8, prm.Q, prm.T, prm.B), cfg)
-        res["proof_1gpu"], _, _ = pk1.prove(inp, b"shard")
+        srs1 = zk.Srs(ctx, k)
+        pk1 = zk.BfvProvingKey(ctx, srs1, text_kg, params, cfg)
+        res["proof_1gpu"], _, _ = pk1.prove(text, b"shard")
         res["vk_1gpu"] = pk1.info()["vk_digest"]
+        res["table_bits_1gpu"] = srs1.table_bits()
+        ok, why = zk.bfv_verify(pk1.export_vk(), inst, proof)
+        res["verified"] = (ok, why)
         pk1.destroy()
         srs1.destroy()
     out.put(res)
@@ -149,20 +169,115 @@ def _sharded_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.gpu
-def test_sharded_prover_two_ranks_one_gpu_same_bytes():
-    """zkfhe_srs_create_sharded + zkfhe_bfv_keygen / zkfhe_bfv_prove over a 2-rank communicator: every commitment is the
-    sum of two point-range partials gathered across processes; verifying key and proof must equal the single-GPU ones."""
+def _run_ranks(target, world, *args, timeout=900):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in ps:
         p.start()
-    got = sorted([q.get(timeout=600), q.get(timeout=600)], key=lambda r: r["rank"])
+    got = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda r: r["rank"])
     for p in ps:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert got[0]["range"] == (0, 256) and got[1]["range"] == (256, 512)
-    assert got[0]["proof"] == got[1]["proof"] and got[0]["inst"] == got[1]["inst"]          # all ranks hold the same proof
-    assert got[0]["vk"] == got[0]["vk_1gpu"] and got[0]["proof"] == got[0]["proof_1gpu"]    # ... the single-GPU one
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,world", [("toy", 2), ("bfv13", 2), ("bfv13", 4)])
+def test_sharded_prover_ranks_share_one_gpu_same_bytes(which, world):
+    """zkfhe_srs_create_sharded + zkfhe_bfv_keygen / zkfhe_bfv_prove over a W-rank communicator: every commitment is the sum of
+    W point-range partials gathered across processes; verifying key and proof must equal the single-GPU ones.  "bfv13" is the
+    reference's bfv.in at k = 13: each rank's SRS slice takes the digit-multiple table path (k_msm_table) with its own,
+    wider digits (a slice of 2^13 / W points fits more bits into the same budget than the whole basis)."""
+    got = _run_ranks(_sharded_worker, world, which)
+    n = 512 if which == "toy" else 8192
+    assert [g["range"] for g in got] == [(n * r // world, n * (r + 1) // world) for r in range(world)]
+    for g in got[1:]:
+        assert g["proof"] == got[0]["proof"] and g["inst"] == got[0]["inst"] and g["vk"] == got[0]["vk"]   # all ranks hold the same proof
+    assert got[0]["vk"] == got[0]["vk_1gpu"] and got[0]["proof"] == got[0]["proof_1gpu"]                  # ... the single-GPU one
+    assert got[0]["verified"][0], got[0]["verified"][1]
+    if which == "bfv13":
+        assert all(g["table_bits"][0] >= got[0]["table_bits_1gpu"][0] >= 8 for g in got)   # the table path ran on every slice
+
+
+def _msm_worker(rank, world, port, log_n, n_cols, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("ZKFHE_TABLE_GB", "4")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    from oracle import binding as orc
+    from oracle import pyref
+    n = 1 << log_n
+    ctx = zk.Context(0)
+    rng = np.random.default_rng(99 + log_n)
+    bases = orc.g1_powers(orc.ints_to_mont([4242])[0], orc.ints_to_mont([0x7654321])[0], n)
+    bases[n // 3] = 0
+    S = np.frombuffer(rng.bytes(n_cols * n * 32), dtype=np.uint64).reshape(n_cols, n, 4).copy()
+    S[..., 3] &= (1 << 60) - 1       # below r: valid (non-canonical Montgomery representatives are still field elements)
+    S[1] = orc.ints_to_mont([int(v) for v in rng.integers(0, 256, n)])   # a witness-like short column
+    S[2, : n // 2] = 0
+    comm = zk.Comm(ctx, rank, world, all_gather=lambda b: B.all_gather_bytes(b, world))
+    lo, hi = comm.point_range(n)
+    slice_basis = zk.Basis(ctx, bases[lo:hi])
+    got = ctx.msm_sharded(comm, slice_basis, S, lo)
+    res = {"rank": rank, "got": got.tobytes(), "slice_table": slice_basis.has_table}
+    if rank == 0:
+        full = zk.Basis(ctx, bases)
+        res["single"] = ctx.msm(full, S).tobytes()
+        res["oracle"] = orc.msm(S[:2], bases).tobytes()
+        full.destroy()
+    out.put(res)
+    dist.barrier()
+    slice_basis.destroy()
+    comm.destroy()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,world,n_cols", [(13, 2, 5), (13, 4, 20), (18, 2, 3)])
+def test_msm_batch_sharded_directly(log_n, world, n_cols):
+    """zkfhe_msm_batch_sharded on its own: k = 13 column batches (table path on every slice; 20 columns = the 256-partials-per-visit
+    fold) and a k = 18 batch (BASELINE config 5 regime: no table exists for a slice of 2^17 points under the suite's budget,
+    so every rank runs the bucket pipeline on its point range).  All ranks must hold the single-GPU commitments; two columns are
+    also checked against the CPU oracle."""
+    got = _run_ranks(_msm_worker, world, log_n, n_cols, timeout=1500)
+    for g in got:
+        assert g["got"] == got[0]["single"]
+    assert got[0]["single"][: 2 * 64] == got[0]["oracle"]
+    assert all(g["slice_table"] == (log_n <= 13) for g in got)
+
+
+@pytest.mark.gpu
+def test_rccl_transport_one_rank_smoke():
+    """The RCCL branch of csrc/comm.hip on ONE GPU: zkfhe_comm_unique_id (ncclGetUniqueId), zkfhe_comm_create with world = 1
+    and an id (a real ncclCommInitRank), zkfhe_comm_all_gather (ncclAllGather of ncclUint8 on the context's stream) and a whole
+    zkfhe_msm_batch_sharded through it -- the dlopen'ed entry points, their prototypes (taken from rccl.h at build time) and the
+    datatype constant all execute.  The multi-rank topology itself needs the 8-GPU node."""
+    import numpy as np
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    from oracle import binding as orc
+    ctx = zk.Context(0)
+    uid = zk.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = zk.Comm(ctx, 0, 1, unique_id=uid)
+    rng = np.random.default_rng(5)
+    payload = np.frombuffer(rng.bytes(64 * 37 + 5), dtype=np.uint8)     # not a multiple of anything: ncclUint8 counts bytes
+    send, recv = ctx.to_device(payload), ctx.alloc(payload.nbytes)
+    comm.all_gather(send, recv, payload.nbytes)
+    ctx.sync()
+    assert np.array_equal(recv.download(dtype=np.uint8), payload)
+    n, n_cols = 1024, 3
+    bases = orc.g1_powers(orc.ints_to_mont([77])[0], orc.ints_to_mont([99])[0], n)
+    S = orc.ints_to_mont([int.from_bytes(rng.bytes(31), "little") for _ in range(n_cols * n)]).reshape(n_cols, n, 4)
+    basis = zk.Basis(ctx, bases)
+    assert np.array_equal(ctx.msm_sharded(comm, basis, S, 0), orc.msm(S, bases))
+    basis.destroy()
+    send.free(), recv.free()
+    comm.destroy()
+    ctx.close()

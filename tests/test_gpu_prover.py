@@ -69,33 +69,55 @@ def test_toy_proof_bytes_match_oracle(ctx, transcript):
     srs.destroy()
 
 
-def test_bfv_in_k13_proof_bytes_match_oracle(ctx):
-    """BASELINE config 2: the reference's data/bfv/bfv.in, k = 13, pinned configs/bfv.json layout."""
+_ORACLE_K13 = {}
+
+
+def oracle_k13():
+    """The CPU oracle's keygen + proof of the reference's bfv.in (seed b"seed-1"): ~40 s, made once per session."""
+    if not _ORACLE_K13:
+        cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+        hcfg = H.Config.from_pinning(cfgj)
+        bp = {"gate0": cfgj["break_points"]["gate"][0], "gate1": cfgj["break_points"]["gate"][1], "rlc": cfgj["break_points"]["rlc"]}
+        prm = C.BfvParams()
+        text_empty = open(os.path.join(G, "bfv_empty.in")).read()
+        text = open(os.path.join(G, "bfv.in")).read()
+        srs_o = H.make_srs(13)
+        pk_o, _ = H.keygen_circuit(hcfg, H.BfvCircuit(json.loads(text_empty), prm), srs_o, bp)
+        proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, H.BfvCircuit(json.loads(text), prm), b"seed-1")
+        _ORACLE_K13.update(cfgj=cfgj, bp=bp, prm=prm, text_empty=text_empty, text=text, srs_o=srs_o, pk_o=pk_o, proof_o=proof_o, inst_o=inst_o)
+    return _ORACLE_K13
+
+
+@pytest.mark.parametrize("table_gb", ["4", None])
+def test_bfv_in_k13_proof_bytes_match_oracle(ctx, monkeypatch, table_gb):
+    """BASELINE config 2: the reference's data/bfv/bfv.in, k = 13, pinned configs/bfv.json layout.  table_gb = None is the
+    library's DEFAULT table budget -- 13-bit digits, 86 GB of digit-multiple tables per SRS: the configuration bench.py and the
+    driver's BENCH line measure; "4" is the budget the rest of the suite runs on (9-bit digits)."""
     import zk_fhe_amd as zk
-    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
-    hcfg = H.Config.from_pinning(cfgj)
-    bp = {"gate0": cfgj["break_points"]["gate"][0], "gate1": cfgj["break_points"]["gate"][1], "rlc": cfgj["break_points"]["rlc"]}
-    prm = C.BfvParams()
-    text_empty = open(os.path.join(G, "bfv_empty.in")).read()
-    text = open(os.path.join(G, "bfv.in")).read()
+    if table_gb is None:
+        monkeypatch.delenv("ZKFHE_TABLE_GB", raising=False)
+        monkeypatch.delenv("ZKFHE_TABLE_BITS", raising=False)
+    else:
+        monkeypatch.setenv("ZKFHE_TABLE_GB", table_gb)
+    o = oracle_k13()
+    cfgj, prm, text_empty, text = o["cfgj"], o["prm"], o["text_empty"], o["text"]
     srs = zk.Srs(ctx, 13)
+    bits, wide = srs.table_bits()
+    assert wide and bits == (13 if table_gb is None else 9), (bits, wide)
     zcfg = zk.BfvConfig.from_pinning(cfgj)
     zcfg_nobp = zk.BfvConfig(zcfg.k, zcfg.n_gate0, zcfg.n_gate1, zcfg.n_lookup, zcfg.n_rlc, zcfg.unusable_rows, zcfg.lookup_bits)
     pk = zk.BfvProvingKey(ctx, srs, text_empty, (1024, prm.Q, prm.T, prm.B), zcfg_nobp)
     info = pk.info()
-    assert info["break_points"] == bp  # keygen recomputes the reference's 158 pinned break points
+    assert info["break_points"] == o["bp"]  # keygen recomputes the reference's 158 pinned break points
     proof, inst, tm = pk.prove(text, b"seed-1")
     print("GPU prove timings [witness, commit, quotient, open, total] ms:", tm)
     assert len(inst) == 5121
-    srs_o = H.make_srs(13)
-    pk_o, _ = H.keygen_circuit(hcfg, H.BfvCircuit(json.loads(text_empty), prm), srs_o, bp)
-    assert info["vk_digest"] == pk_o.vk_digest
-    assert H.verify(H.VerifyingKey(pk_o), srs_o, inst, proof), "oracle verifier (pairing check) rejects the GPU proof"
+    assert info["vk_digest"] == o["pk_o"].vk_digest
+    assert H.verify(H.VerifyingKey(o["pk_o"]), o["srs_o"], inst, proof), "oracle verifier (pairing check) rejects the GPU proof"
     ok, why = zk.bfv_verify(pk.export_vk(), inst, proof)   # the product's own C++ verifier (host CPU)
     assert ok, why
-    proof_o, inst_o = H.prove(hcfg, pk_o, srs_o, H.BfvCircuit(json.loads(text), prm), b"seed-1")
-    assert inst == inst_o
-    assert first_diff(proof, proof_o) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_o)
+    assert inst == o["inst_o"]
+    assert first_diff(proof, o["proof_o"]) is None, "first differing 32-byte item: %s" % first_diff(proof, o["proof_o"])
     pk.destroy()
     srs.destroy()
 

@@ -1,0 +1,74 @@
+"""The compressed-point layout of the proof byte stream has ONE definition per side (zk-fhe_amd/host/point_encoding.hpp,
+oracle/point_encoding.py); both are pinned here to tests/golden/point_encoding.json (halo2curves bn256 `to_bytes`: sign of y
+in bit 6 of byte 31, identity = 0x80 in byte 31).  CPU only: the transcript of the C ABI is host code."""
+import json
+import os
+
+import pytest
+
+from oracle import halo2_ref as H
+from oracle import point_encoding as PE
+from oracle import poseidon_ref as PR
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+V = json.load(open(os.path.join(HERE, "golden", "point_encoding.json")))
+
+
+def _pt(c):
+    return None if c["x"] is None else (int(c["x"], 16), int(c["y"], 16))
+
+
+def test_layout_constants():
+    assert PE.SIGN_BIT == 1 << V["layout"]["sign_bit"] and PE.IDENTITY_BIT == 1 << V["layout"]["identity_bit"]
+    assert PE.X_MASK == V["layout"]["x_mask_byte31"]
+    src = open(os.path.join(HERE, "..", "zk-fhe_amd", "host", "point_encoding.hpp")).read()
+    assert "SIGN_BIT = 0x%02x" % PE.SIGN_BIT in src and "IDENTITY_BIT = 0x%02x" % PE.IDENTITY_BIT in src and "X_MASK = 0x%02x" % PE.X_MASK in src
+    # nobody keeps a private copy of the layout
+    for f in ("transcript.hpp", "verifier.cpp"):
+        body = open(os.path.join(HERE, "..", "zk-fhe_amd", "host", f)).read()
+        assert "ptenc::" in body and "b[31] |= 0x" not in body and "b[31] &= 0x" not in body
+    assert H.point_compress is PE.point_compress and PR.point_compress is PE.point_compress
+    assert H.point_decompress is PE.point_decompress and PR.point_decompress is PE.point_decompress
+
+
+def test_oracle_codec_matches_golden():
+    for c in V["cases"]:
+        assert PE.point_compress(_pt(c)).hex() == c["bytes"]
+        assert PE.point_decompress(bytes.fromhex(c["bytes"])) == _pt(c)
+    with pytest.raises(AssertionError):
+        PE.point_decompress(bytes([1] + [0] * 30 + [0x80]))   # identity flag with a non-zero x
+
+
+@pytest.mark.parametrize("kind", ["poseidon", "blake2b"])
+def test_product_transcript_writes_golden_bytes(kind):
+    import zk_fhe_amd as zk
+    tr = zk.HostTranscript(kind)
+    want = b""
+    for c in V["cases"]:
+        P = _pt(c)
+        if P is None:
+            continue    # snark-verifier's Poseidon transcript refuses the identity; covered through the verifier below
+        tr.write_point(P)
+        want += bytes.fromhex(c["bytes"])
+    assert tr.stream() == want
+    tr.close()
+
+
+def test_product_verifier_reads_the_layout():
+    """In an oracle-made proof: flipping bit 6 of a point's last byte still decodes (to -P: the proof is then rejected by the
+    checks, not as malformed); setting bit 7 beside a non-zero x is refused as a malformed identity."""
+    import zk_fhe_amd as zk
+    from tests.test_host_verifier import make
+    vkb, inst, proof = make("poseidon")
+    assert zk.bfv_verify(vkb, inst, proof)[0]
+    first = PE.point_decompress(proof[:32])
+    assert first is not None and (proof[31] & 0x80) == 0
+    assert bool(proof[31] & 0x40) == bool(first[1] & 1)
+    flipped = bytearray(proof)
+    flipped[31] ^= PE.SIGN_BIT
+    ok, why = zk.bfv_verify(vkb, inst, bytes(flipped))
+    assert not ok and "identity" not in why and "curve" not in why and "reduced" not in why, why
+    bad = bytearray(proof)
+    bad[31] |= PE.IDENTITY_BIT
+    ok, why = zk.bfv_verify(vkb, inst, bytes(bad))
+    assert not ok and "identity" in why, why

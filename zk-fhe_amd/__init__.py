@@ -299,6 +299,18 @@ class Context:
         ds.free(), do.free()
         return out
 
+    def msm_sharded(self, comm, basis_slice, scalars, lo):
+        """zkfhe_msm_batch_sharded: `scalars` = the FULL columns (n_cols, n_full, 4); this rank's basis slice covers rows
+        lo .. lo + len(basis_slice).  Every rank gets the full commitments."""
+        s = self._fr(scalars)
+        n_cols, n_full = s.shape[0], s.shape[1]
+        ds, do = self.to_device(s), self.alloc(n_cols * 64)
+        self.lib.zkfhe_msm_batch_sharded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        self._check(self.lib.zkfhe_msm_batch_sharded(self.h, comm.h, basis_slice.h, ds.at(lo * 32), n_full, n_cols, do.ptr))
+        out = do.download(shape=(n_cols, 8))
+        ds.free(), do.free()
+        return out
+
     def g1_add(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 8)
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 8)
@@ -597,7 +609,7 @@ class Comm:
         self.ctx, self.rank, self.world = ctx, rank, world
         self.h = ctypes.c_void_p()
         lib.zkfhe_comm_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        if all_gather is not None or world == 1:
+        if unique_id is None:     # host transport (or, with world == 1 and no callback, no transport at all)
             def cb(_user, send, nbytes, recv):
                 try:
                     parts = all_gather(ctypes.string_at(send, nbytes))
@@ -623,6 +635,12 @@ class Comm:
         if rc != 0:
             raise ZkfheError("zkfhe_comm_unique_id failed (%d): is librccl.so available?" % rc)
         return buf.raw
+
+    def all_gather(self, send, recv, nbytes):
+        """zkfhe_comm_all_gather on the context's stream: DeviceBuffer send (nbytes) -> DeviceBuffer recv (world * nbytes)"""
+        lib = self.ctx.lib
+        lib.zkfhe_comm_all_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.ctx._check(lib.zkfhe_comm_all_gather(self.ctx.h, self.h, send.ptr, recv.ptr, nbytes))
 
     def point_range(self, n):
         lo, hi = ctypes.c_size_t(), ctypes.c_size_t()

@@ -17,26 +17,23 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "ctx.hpp"
 
 using namespace zk;
 
 namespace {
 
-// the slice of the RCCL API that is used (rccl.h is not needed at build time)
-typedef struct ncclComm *ncclComm_t;
-typedef struct {
-  char internal[128];
-} ncclUniqueId;
-typedef int ncclResult_t;
-enum { NCCL_UINT8 = 1 };   // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
+// The slice of the RCCL API that is used.  Types and prototypes come from the installed <rccl/rccl.h> (compile-time check of
+// every signature and of ncclUint8); the library itself is resolved with dlopen at zkfhe_comm_create, nothing is linked.
 struct Rccl {
   void *lib = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string err;
   bool load() {
     if (lib) return true;
@@ -60,6 +57,7 @@ struct Rccl {
     return true;
   }
 };
+static_assert(sizeof(ncclUniqueId) == 128, "zkfhe_comm_unique_id hands out 128 bytes");
 Rccl &rccl() {
   static Rccl r;
   return r;
@@ -91,7 +89,7 @@ int zkfhe_comm_unique_id(uint8_t id_out[128]) {
   if (!id_out) return ZKFHE_EINVAL;
   if (!rccl().load()) return ZKFHE_ENODEV;
   ncclUniqueId id;
-  if (rccl().GetUniqueId(&id) != 0) return ZKFHE_EHIP;
+  if (rccl().GetUniqueId(&id) != ncclSuccess) return ZKFHE_EHIP;
   memcpy(id_out, id.internal, 128);
   return ZKFHE_OK;
 }
@@ -103,8 +101,13 @@ int zkfhe_comm_create(zkfhe_ctx *ctx, int rank, int world, const uint8_t unique_
   zkfhe_comm *c = new zkfhe_comm();
   c->rank = rank;
   c->world = world;
-  if (world > 1) {
-    ZK_ARG(ctx, unique_id != nullptr);
+  // world == 1 with an id: a real one-rank RCCL communicator (every collective then goes through librccl: the smoke test of
+  // the dlopen'ed entry points on a single GPU); world == 1 without: no transport at all
+  if (world > 1 || unique_id != nullptr) {
+    if (!unique_id) {
+      delete c;
+      return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_comm_create: world > 1 needs the unique id of rank 0");
+    }
     if (!rccl().load()) {
       delete c;
       return zk_fail_msg(ctx, ZKFHE_ENODEV, rccl().err);
@@ -112,7 +115,7 @@ int zkfhe_comm_create(zkfhe_ctx *ctx, int rank, int world, const uint8_t unique_
     ncclUniqueId id;
     memcpy(id.internal, unique_id, 128);
     const ncclResult_t rc = rccl().CommInitRank(&c->nccl, world, id, rank);
-    if (rc != 0) {
+    if (rc != ncclSuccess) {
       delete c;
       return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("ncclCommInitRank failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
     }
@@ -157,19 +160,31 @@ void zkfhe_comm_point_range(const zkfhe_comm *comm, size_t n, size_t *lo, size_t
 int zkfhe_comm_all_gather(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, comm != nullptr && send_dev != nullptr && recv_dev != nullptr);
-  if (comm->world == 1) return zk_copy_d2d(ctx, recv_dev, send_dev, bytes);
   if (comm->nccl) {
-    const ncclResult_t rc = rccl().AllGather(send_dev, recv_dev, bytes, NCCL_UINT8, comm->nccl, ctx->stream);
-    if (rc != 0) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("ncclAllGather failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
+    const ncclResult_t rc = rccl().AllGather(send_dev, recv_dev, bytes, ncclUint8, comm->nccl, ctx->stream);
+    if (rc != ncclSuccess) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("ncclAllGather failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
     return ZKFHE_OK;
   }
+  if (comm->world == 1) return zk_copy_d2d(ctx, recv_dev, send_dev, bytes);
   // callback transport: through pinned host memory
   if (comm->host_cap < bytes * (size_t)comm->world) {
+    // the old buffers go first and the capacity is only recorded once both new ones exist: a failed allocation leaves the
+    // communicator with no staging (cap 0), never with dangling pointers
     if (comm->host_send) (void)hipHostFree(comm->host_send);
     if (comm->host_recv) (void)hipHostFree(comm->host_recv);
-    comm->host_cap = bytes * (size_t)comm->world;
-    ZK_HIP(ctx, hipHostMalloc((void **)&comm->host_send, comm->host_cap, hipHostMallocDefault));
-    ZK_HIP(ctx, hipHostMalloc((void **)&comm->host_recv, comm->host_cap, hipHostMallocDefault));
+    comm->host_send = comm->host_recv = nullptr;
+    comm->host_cap = 0;
+    const size_t cap = bytes * (size_t)comm->world;
+    uint8_t *a = nullptr, *b = nullptr;
+    ZK_HIP(ctx, hipHostMalloc((void **)&a, cap, hipHostMallocDefault));
+    const hipError_t e2 = hipHostMalloc((void **)&b, cap, hipHostMallocDefault);
+    if (e2 != hipSuccess) {
+      (void)hipHostFree(a);
+      ZK_HIP(ctx, e2);
+    }
+    comm->host_send = a;
+    comm->host_recv = b;
+    comm->host_cap = cap;
   }
   ZK_HIP(ctx, hipMemcpyAsync(comm->host_send, send_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, zk_wait(ctx));
@@ -183,7 +198,7 @@ int zkfhe_msm_batch_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis 
   ZK_ENTER(ctx);
   ZK_ARG(ctx, comm != nullptr && basis_slice != nullptr);
   if (!n_cols) return ZKFHE_OK;
-  if (comm->world == 1) return zk_msm_batch_strided(ctx, basis_slice, scalars_dev, col_stride, n_cols, out_dev);
+  if (comm->world == 1 && !comm->nccl) return zk_msm_batch_strided(ctx, basis_slice, scalars_dev, col_stride, n_cols, out_dev);
   // scratch slot 3: [my partials | everyone's partials]  (slots 0..2 belong to the MSM itself)
   void *p;
   int rc = zk_scratch(ctx, 3, (size_t)(comm->world + 1) * n_cols * sizeof(G1Affine) + 64, &p);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "fe.hpp"
+#include "point_encoding.hpp"
 #include "poseidon.hpp"
 
 namespace zkhost {
@@ -224,10 +225,10 @@ class Transcript {
   static void compress(const AffinePoint &p, uint8_t b[32]) {
     if (p.is_identity()) {
       memset(b, 0, 32);
-      b[31] |= 0x40;
+      b[31] |= ptenc::IDENTITY_BIT;
     } else {
       memcpy(b, p.x.l, 32);
-      if (p.y.l[0] & 1) b[31] |= 0x80;
+      if (p.y.l[0] & 1) b[31] |= ptenc::SIGN_BIT;
     }
   }
   size_t poseidon_permutations() const { return sp.n_perm; }

@@ -50,16 +50,16 @@ struct Reader {
     memcpy(b, p + pos, 32);
     pos += 32;
     AffinePoint a;
-    if (b[31] & 0x40) {
+    if (b[31] & ptenc::IDENTITY_BIT) {
       // the identity has exactly one encoding (halo2curves rejects anything else)
       for (int i = 0; i < 31; ++i)
         if (b[i]) throw std::runtime_error("non-canonical encoding of the identity");
-      if (b[31] != 0x40) throw std::runtime_error("non-canonical encoding of the identity");
+      if (b[31] != ptenc::IDENTITY_BIT) throw std::runtime_error("non-canonical encoding of the identity");
       a.x = fe::zero();
       a.y = fe::zero();
     } else {
-      const unsigned sign = b[31] >> 7;
-      b[31] &= 0x7f;
+      const unsigned sign = (b[31] & ptenc::SIGN_BIT) ? 1u : 0u;
+      b[31] &= ptenc::X_MASK;
       memcpy(a.x.l, b, 32);
       static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
       if (!(a.x < QMOD)) throw std::runtime_error("point x not reduced");
