@@ -1,0 +1,214 @@
+// Lazy radix-2^29 arithmetic over BN254 Fr with COMPILE-TIME bounds, for the butterflies of the NTT kernel (ntt13.hip).
+//
+// fr29.hip.hpp normalises the limbs after every addition and subtraction (9 adds + 24 carry operations, and a multiple of r
+// so that a difference stays positive) although the nine-limb product does not need normalised inputs.  Here a value is nine
+// SIGNED 32-bit limbs, value = sum l[i] 2^(29 i), of either sign:
+//   * addition and subtraction are nine v_add / v_sub, nothing else;
+//   * the Montgomery product takes a signed first operand (v_mad_i64_i32) and a canonical constant w 2^261 (a twiddle, limbs in
+//     [0, 2^29)): a column is nine a_j w_(k-j) below 2^30 2^29 in magnitude plus nine m_j r_(k-j) below 2^58, inside the signed
+//     64-bit accumulator; the result has limbs 0..7 in [0, 2^29) and a signed top limb, value in (-r, 2 r);
+//   * carries are propagated (24 operations) only where a bound below would otherwise be exceeded.
+// Lz<LO, HI, V>: -LO 2^29 < l[i] < HI 2^29 for i < 8 (LO = 0: non-negative) and |value| < V r; l[8] is whatever is left.
+// Every operation states its result bound in its return type and static_asserts what it needs, so a butterfly network that
+// compiles cannot overflow:
+//   add(a, b)      -> Lz<LOa + LOb, HIa + HIb, Va + Vb>     limbs must stay inside int32: LO, HI <= 4
+//   sub(a, b)      -> Lz<LOa + HIb, HIa + LOb, Va + Vb>
+//   mul(a, w)      -> Lz<0, 1, 2>               needs LO, HI <= 2 (limbs below 2^30 in magnitude), V <= 160
+//   mul2(a,w,b,v)  -> Lz<0, 1, 2>               (a w + b v) / 2^261 with one reduction; needs tight a, b
+//   norm(a)        -> Lz<0, 1, V>               carry propagation: limbs 0..7 back in [0, 2^29)
+//   weak(a)        -> Lz<0, 1, 2>               value into [0, 2 r): needs V <= 16
+// A twiddle is an Lw: nine canonical limbs of w * 2^261 mod r, kept UNPACKED in memory (48-byte entries: three dwordx4 loads
+// instead of two loads and 27 shift/mask operations per product).
+#pragma once
+#include "fr29.hip.hpp"
+
+namespace zk {
+
+template <int LO, int HI, int V>
+struct Lz {
+  int l[9];
+};
+using LzT = Lz<0, 1, 2>;   // what a product returns: tight limbs, value in (-r, 2 r)
+struct Lw {   // canonical constant operand (twiddle), limbs in [0, 2^29)
+  u32 l[9];
+};
+
+template <int V>
+ZK_HD Lz<0, 1, V> lz_from_f29(const F29 &a) {   // caller's promise: a has tight limbs and a value below V r
+  Lz<0, 1, V> r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = (int)a.l[i];
+  return r;
+}
+// a canonical column value (x * 2^256 < r, packed)
+ZK_HD Lz<0, 1, 1> lz_load(const Fr &w) { return lz_from_f29<1>(fr29_unpack(w)); }
+ZK_HD Lz<0, 1, 1> lz_zero() { return lz_from_f29<1>(f29_zero()); }
+
+template <int L1, int H1, int V1, int L2, int H2, int V2>
+ZK_HD Lz<L1 + L2, H1 + H2, V1 + V2> lz_add(const Lz<L1, H1, V1> &a, const Lz<L2, H2, V2> &b) {
+  static_assert(L1 + L2 <= 4 && H1 + H2 <= 4, "limb overflow");
+  Lz<L1 + L2, H1 + H2, V1 + V2> r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+template <int L1, int H1, int V1, int L2, int H2, int V2>
+ZK_HD Lz<L1 + H2, H1 + L2, V1 + V2> lz_sub(const Lz<L1, H1, V1> &a, const Lz<L2, H2, V2> &b) {
+  static_assert(L1 + H2 <= 4 && H1 + L2 <= 4, "limb overflow");
+  Lz<L1 + H2, H1 + L2, V1 + V2> r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
+  return r;
+}
+
+// A limb typed HI = h is a sum of h terms each at most 2^29 - 1, so l + carry (carry <= 3) stays inside int32 for h = 4;
+// likewise on the negative side.
+template <int LO, int HI, int V>
+ZK_HD Lz<0, 1, V> lz_norm(const Lz<LO, HI, V> &a) {
+  Lz<0, 1, V> r;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int v = a.l[i] + c;
+    r.l[i] = v & (int)q29::MASK;
+    c = v >> 29;                // arithmetic: floor
+  }
+  r.l[8] = a.l[8] + c;
+  return r;
+}
+
+// value (either sign, |v| < 16 r) -> the same residue in [0, 2 r) (in fact below 1.04 r), limbs normalised.
+// q = floor(floor((l[8] - LO) / 2^13) 169 / 2^16): the lower limbs sum to more than -LO 2^232, so (l[8] - LO) 2^232 <= v and
+// q under-estimates v / r (169 = floor(2^261 / r)) -- by less than 1.04.
+template <int LO, int HI, int V>
+ZK_HD LzT lz_weak(const Lz<LO, HI, V> &a) {
+  static_assert(V <= 16, "weak reduction: |value| below 16 r");
+  constexpr u32 P[9] = ZK_R29_P;
+  const int q = (((a.l[8] - LO) >> 13) * 169) >> 16;
+  LzT r;
+  long long c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long v = (long long)a.l[i] - (long long)q * (long long)P[i] + c;
+    r.l[i] = (int)((u32)v & q29::MASK);
+    c = v >> 29;
+  }
+  r.l[8] = (int)((long long)a.l[8] - (long long)q * (long long)P[8] + c);
+  return r;
+}
+
+// Montgomery product a * w / 2^261 mod r for |a w| < 2^261 r: value in (-r, 2 r).  Column k: nine |a_j| w_(k-j) < 2^30 2^29,
+// nine m_j r_(k-j) < 2^58 and the carry: magnitude below 9 2^59 + 9 2^58 + 2^35 < 2^63.
+template <int LO, int HI, int V>
+ZK_HD LzT lz_mul(const Lz<LO, HI, V> &a, const Lw &b) {
+  static_assert(LO <= 2 && HI <= 2, "product: limbs below 2^30 in magnitude");
+  static_assert(V <= 160, "product: |a w| < 2^261 r");
+  constexpr u32 P[9] = ZK_R29_P;
+  int m[9];
+  LzT r;
+  long long acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      acc += (long long)a.l[j] * (long long)(int)b.l[k - j];
+      acc += (long long)m[j] * (long long)(int)P[k - j];
+    }
+    acc += (long long)a.l[k] * (long long)(int)b.l[0];
+    m[k] = (int)(((u32)acc * r29::INV) & q29::MASK);
+    acc += (long long)m[k] * (long long)(int)P[0];
+    acc >>= 29;   // exact: the low 29 bits are zero
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int j = k - 8; j < 9; ++j) {
+      acc += (long long)a.l[j] * (long long)(int)b.l[k - j];
+      acc += (long long)m[j] * (long long)(int)P[k - j];
+    }
+    r.l[k - 9] = (int)((u32)acc & q29::MASK);
+    acc >>= 29;
+  }
+  r.l[8] = (int)acc;
+  return r;
+}
+
+// (a w + b v) / 2^261 mod r, one reduction: eighteen products below 2^29 2^29 per column
+template <int V, int V2>
+ZK_HD LzT lz_mul2(const Lz<0, 1, V> &a, const Lw &w, const Lz<0, 1, V2> &b, const Lw &v) {
+  static_assert(V + V2 <= 160, "two-product form: |a w + b v| < 2^261 r");
+  constexpr u32 P[9] = ZK_R29_P;
+  int m[9];
+  LzT r;
+  long long acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      acc += (long long)a.l[j] * (long long)(int)w.l[k - j];
+      acc += (long long)b.l[j] * (long long)(int)v.l[k - j];
+      acc += (long long)m[j] * (long long)(int)P[k - j];
+    }
+    acc += (long long)a.l[k] * (long long)(int)w.l[0];
+    acc += (long long)b.l[k] * (long long)(int)v.l[0];
+    m[k] = (int)(((u32)acc * r29::INV) & q29::MASK);
+    acc += (long long)m[k] * (long long)(int)P[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int j = k - 8; j < 9; ++j) {
+      acc += (long long)a.l[j] * (long long)(int)w.l[k - j];
+      acc += (long long)b.l[j] * (long long)(int)v.l[k - j];
+      acc += (long long)m[j] * (long long)(int)P[k - j];
+    }
+    r.l[k - 9] = (int)((u32)acc & q29::MASK);
+    acc >>= 29;
+  }
+  r.l[8] = (int)acc;
+  return r;
+}
+
+// canonical packed column value from a weakly reduced one (value in [0, 2 r), normalised limbs)
+ZK_HD Fr lz_store_weak(const LzT &a) {
+  constexpr u32 P[9] = ZK_R29_P;
+  int t[9], c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int v = a.l[i] - (int)P[i] + c;
+    t[i] = v & (int)q29::MASK;
+    c = v >> 29;
+  }
+  t[8] = a.l[8] - (int)P[8] + c;
+  F29 o;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.l[i] = (u32)(t[8] >= 0 ? t[i] : a.l[i]);   // a - r when that is not negative
+  return fr29_pack(o);
+}
+// any bounded value -> canonical packed
+template <int LO, int HI, int V>
+ZK_HD Fr lz_store(const Lz<LO, HI, V> &a) {
+  return lz_store_weak(lz_weak(a));
+}
+
+// twiddle entry in memory: 12 dwords (nine limbs + padding), 16-byte aligned
+struct alignas(16) LwMem {
+  u32 l[12];
+};
+ZK_HD Lw lw_load(const LwMem &e) {
+  Lw w;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w.l[i] = e.l[i];
+  return w;
+}
+ZK_HD LwMem lw_from_packed(const Fr &w29 /* canonical, 2^261 form */) {
+  const F29 u = fr29_unpack(w29);
+  LwMem e;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) e.l[i] = u.l[i];
+  e.l[9] = e.l[10] = e.l[11] = 0;
+  return e;
+}
+
+}  // namespace zk
