@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,6 +31,10 @@ struct zkfhe_ctx {
   std::string err;
   int num_cu = 0;
   std::map<int, NttDomain> domains;
+  // tables of the 2^13 tile kernel (ntt13.hip): unpacked twiddles per direction (keyed by the domain table they come from) and
+  // coset pre-multiplier tables (keyed by shift, extension and rows); device memory, freed with the context
+  std::map<const void *, void *> tw13;
+  std::map<std::array<uint64_t, 6>, void *> pre13;
   // grow-only scratch arenas (bytes)
   // profiling (zkfhe_prof_*): [0] = the summing kernel of a wide MSM call (k_msm_table / k_msm_accumulate), [1] = k_ntt_tile
   bool prof_on = false;
@@ -112,6 +117,7 @@ int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
 // stream-ordered device-to-device copy (own kernel for large blocks)
 int zk_copy_d2d(zkfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out);
+int zk_pre13(zkfhe_ctx *ctx, const zk::Fr &g, int lef, int rows, const void **out);
 // forward coset extension of the first `rows` cosets (ntt.hip)
 int zk_coset_ntt_rows(zkfhe_ctx *ctx, const zk::Fr *in_dev, zk::Fr *out_dev, size_t n_cols, int log_n, int lef, const zk::Fr &g, int rows);
 

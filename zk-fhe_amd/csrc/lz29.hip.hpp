@@ -202,6 +202,13 @@ ZK_HD Lw lw_load(const LwMem &e) {
   for (int i = 0; i < 9; ++i) w.l[i] = e.l[i];
   return w;
 }
+ZK_HD Lw lw_unpack(const Fr &w29 /* canonical, 2^261 form */) {
+  const F29 u = fr29_unpack(w29);
+  Lw w;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w.l[i] = u.l[i];
+  return w;
+}
 ZK_HD LwMem lw_from_packed(const Fr &w29 /* canonical, 2^261 form */) {
   const F29 u = fr29_unpack(w29);
   LwMem e;

@@ -349,12 +349,18 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   rc = zk_scratch(ctx, 1, nr * sizeof(Fr), &p);
   if (rc) return rc;
   Fr *pre = (Fr *)p;
-  Fr shift = g;
-  const Fr c32 = zk_fr_to_29(Fr::one());
-  for (int k1 = 0; k1 < rows; ++k1) {   // (g w_ext^k1)^i as constant operands of the nine-limb multiply (2^261 form)
-    k_pow_table_scaled<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(c32, shift, pre + (size_t)k1 * n, n);
-    ZK_LAUNCH_CHECK(ctx);
-    shift = shift * edom->omega;
+  const void *pre13 = nullptr;
+  if (log_n == 13) {   // the 2^13 tile keeps its own tables (coset powers times the first-stage twiddles), built once
+    rc = zk_pre13(ctx, g, lef, rows, &pre13);
+    if (rc) return rc;
+  } else {
+    Fr shift = g;
+    const Fr c32 = zk_fr_to_29(Fr::one());
+    for (int k1 = 0; k1 < rows; ++k1) {   // (g w_ext^k1)^i as constant operands of the nine-limb multiply (2^261 form)
+      k_pow_table_scaled<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(c32, shift, pre + (size_t)k1 * n, n);
+      ZK_LAUNCH_CHECK(ctx);
+      shift = shift * edom->omega;
+    }
   }
   if (log_n > MAX_TILE_LOG) {
     unsigned gr = zk_blocks(n_cols * nr, 256);
@@ -372,6 +378,7 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   a.col_stride_out = nr;
   a.tw = dom->fwd29;
   a.pre = pre;
+  a.pre13 = pre13;
   a.pre_tile_stride = n;
   a.post = nullptr;
   a.log_tiles = lef;
@@ -403,12 +410,18 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
     if (rc) return rc;
     Fr *pre = (Fr *)p;
-    Fr shift = g;
-    const Fr c32 = zk_fr_to_29(Fr::one());
-    for (int k1 = 0; k1 < E; ++k1) {
-      k_pow_table_scaled<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(c32, shift, pre + (size_t)k1 * n, n);
-      ZK_LAUNCH_CHECK(ctx);
-      shift = shift * edom->omega;
+    const void *pre13 = nullptr;
+    if (log_n == 13) {
+      rc = zk_pre13(ctx, g, lef, E, &pre13);
+      if (rc) return rc;
+    } else {
+      Fr shift = g;
+      const Fr c32 = zk_fr_to_29(Fr::one());
+      for (int k1 = 0; k1 < E; ++k1) {
+        k_pow_table_scaled<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>(c32, shift, pre + (size_t)k1 * n, n);
+        ZK_LAUNCH_CHECK(ctx);
+        shift = shift * edom->omega;
+      }
     }
     if (log_n > MAX_TILE_LOG) {
       // rows longer than one tile: pre-scale into the output rows, then a batched size-n NTT over all (column, k1) rows
@@ -427,6 +440,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     a.col_stride_out = ne;
     a.tw = dom->fwd29;
     a.pre = pre;
+    a.pre13 = pre13;
     a.pre_tile_stride = n;
     a.post = nullptr;
     a.log_tiles = lef;

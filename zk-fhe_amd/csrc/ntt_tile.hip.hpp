@@ -114,6 +114,7 @@ struct TileArgs {
   int log_tiles;       // tiles per column = 2^log_tiles; out_off(b) = bitrev(b), out_stride = 2^log_tiles
   int in_len;          // coefficients actually present per tile (rest read as zero)
   int out_natural_tiles;  // 1: out_off(b) = b*N, stride 1 (independent tiles)
+  const void *pre13;      // the 2^13 tile (ntt13.hip) reads its pre-multipliers from the tables of zk_pre13 instead of `pre`
 };
 
 // one pass over F29 registers (values below 2 r in and out).  EPT coefficients per thread (8, or 16 for the 2^13 tile: 512
