@@ -35,3 +35,17 @@ def test_radix29_field_and_point_arithmetic(tmp_path):
                     "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "native", "f29_check.hip"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "fq29: 0 bad" in out, out
+
+
+def test_lazy_signed_limb_arithmetic(tmp_path):
+    """csrc/lz29.hip.hpp (the arithmetic of the 2^13 NTT tile: signed lazy limbs with compile-time bounds, products against unpacked
+    twiddles, weak reduction of values of either sign, canonical store) against the standard 8 x 32-bit Fr arithmetic.  Host
+    instantiation of the same host+device code (no GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "lz29_check")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "zk-fhe_amd", "csrc"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "native", "lz29_check.hip"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "lz29: 0 bad" in out, out

@@ -117,7 +117,11 @@ int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
 // stream-ordered device-to-device copy (own kernel for large blocks)
 int zk_copy_d2d(zkfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out);
-int zk_pre13(zkfhe_ctx *ctx, const zk::Fr &g, int lef, int rows, const void **out);
+int zk_pre13(zkfhe_ctx *ctx, const zk::Fr &g, int lef, int rows, bool scaled, const void **out);
+// Lagrange columns -> the first `rows` cosets of the extended domain (lagrange_to_coeff + coeff_to_extended in one call): tmp_dev
+// receives the coefficient form (at n = 2^13: times n, the n^-1 lives in the coset tables), column c at c * 2^log_n; out as
+// zk_coset_ntt_rows
+int zk_extend_lagrange(zkfhe_ctx *ctx, const zk::Fr *lagr_dev, zk::Fr *tmp_dev, zk::Fr *out_dev, size_t n_cols, int log_n, int lef, const zk::Fr &g, int rows);
 // forward coset extension of the first `rows` cosets (ntt.hip)
 int zk_coset_ntt_rows(zkfhe_ctx *ctx, const zk::Fr *in_dev, zk::Fr *out_dev, size_t n_cols, int log_n, int lef, const zk::Fr &g, int rows);
 

@@ -78,13 +78,15 @@ ZK_HD Lz<0, 1, V> lz_norm(const Lz<LO, HI, V> &a) {
 }
 
 // value (either sign, |v| < 16 r) -> the same residue in [0, 2 r) (in fact below 1.04 r), limbs normalised.
-// q = floor(floor((l[8] - LO) / 2^13) 169 / 2^16): the lower limbs sum to more than -LO 2^232, so (l[8] - LO) 2^232 <= v and
-// q under-estimates v / r (169 = floor(2^261 / r)) -- by less than 1.04.
+// q = floor(t m / 2^16) with t = floor((l[8] - LO) / 2^13) and m = 169 for t >= 0, 170 for t < 0: the lower limbs sum to more than
+// -LO 2^232, so t 2^245 <= v, and 169 < 2^261 / r = 169.29.. < 170, so q never exceeds v / r (the multiplier is rounded towards
+// the side that makes the estimate smaller) and falls short of it by less than 1.1.
 template <int LO, int HI, int V>
 ZK_HD LzT lz_weak(const Lz<LO, HI, V> &a) {
   static_assert(V <= 16, "weak reduction: |value| below 16 r");
   constexpr u32 P[9] = ZK_R29_P;
-  const int q = (((a.l[8] - LO) >> 13) * 169) >> 16;
+  const int t = (a.l[8] - LO) >> 13;
+  const int q = (t * (169 - (t >> 31))) >> 16;
   LzT r;
   long long c = 0;
 #pragma unroll

@@ -351,7 +351,7 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   Fr *pre = (Fr *)p;
   const void *pre13 = nullptr;
   if (log_n == 13) {   // the 2^13 tile keeps its own tables (coset powers times the first-stage twiddles), built once
-    rc = zk_pre13(ctx, g, lef, rows, &pre13);
+    rc = zk_pre13(ctx, g, lef, rows, false, &pre13);
     if (rc) return rc;
   } else {
     Fr shift = g;
@@ -387,6 +387,51 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   return launch_tile_dyn(ctx, log_n, a, (unsigned)rows, (unsigned)n_cols);
 }
 
+// lagrange_to_coeff followed by coeff_to_extended on `rows` cosets, for the prover's extend step.  At n = 2^13 the inverse
+// transform runs out of place WITHOUT its final n^-1 (one product per coefficient less) and the coset tables carry the factor.
+extern "C++" int zk_extend_lagrange(zkfhe_ctx *ctx, const Fr *lagr_dev, Fr *tmp_dev, Fr *out_dev, size_t n_cols, int log_n, int lef, const Fr &g, int rows) {
+  if (!n_cols) return ZKFHE_OK;
+  const size_t n = (size_t)1 << log_n;
+  if (log_n != 13 || rows > (1 << lef)) {
+    int rc = zk_copy_d2d(ctx, tmp_dev, lagr_dev, n_cols * n * sizeof(Fr));
+    if (rc) return rc;
+    rc = zkfhe_ntt_batch(ctx, (zkfhe_fr *)tmp_dev, n_cols, log_n, 1);
+    if (rc) return rc;
+    return zk_coset_ntt_rows(ctx, tmp_dev, out_dev, n_cols, log_n, lef, g, rows);
+  }
+  const NttDomain *dom;
+  int rc = zk_domain(ctx, log_n, &dom);
+  if (rc) return rc;
+  const void *pre13 = nullptr;
+  rc = zk_pre13(ctx, g, lef, rows, true, &pre13);
+  if (rc) return rc;
+  TileArgs a{};
+  a.in = lagr_dev;
+  a.out = tmp_dev;
+  a.in_tile_stride = n;
+  a.col_stride_in = a.col_stride_out = n;
+  a.tw = dom->inv29;
+  a.log_tiles = 0;
+  a.in_len = (int)n;
+  a.out_natural_tiles = 1;
+  rc = launch_tile_dyn(ctx, log_n, a, 1, (unsigned)n_cols);
+  if (rc) return rc;
+  TileArgs b{};
+  b.in = tmp_dev;
+  b.out = out_dev;
+  b.in_tile_stride = 0;
+  b.col_stride_in = n;
+  b.col_stride_out = n * (size_t)rows;
+  b.tw = dom->fwd29;
+  b.pre = tmp_dev;   // not read: the tile takes its multipliers from pre13
+  b.pre13 = pre13;
+  b.pre_tile_stride = n;
+  b.log_tiles = lef;
+  b.in_len = (int)n;
+  b.out_natural_tiles = 1;
+  return launch_tile_dyn(ctx, log_n, b, (unsigned)rows, (unsigned)n_cols);
+}
+
 int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n,
                           int log_ext_factor, const zkfhe_fr *g_host, int inverse) {
   ZK_ENTER(ctx);
@@ -412,7 +457,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     Fr *pre = (Fr *)p;
     const void *pre13 = nullptr;
     if (log_n == 13) {
-      rc = zk_pre13(ctx, g, lef, E, &pre13);
+      rc = zk_pre13(ctx, g, lef, E, false, &pre13);
       if (rc) return rc;
     } else {
       Fr shift = g;

@@ -53,10 +53,11 @@ __global__ void __launch_bounds__(256) k_tw13_pack(const Fr *__restrict__ tw29 /
 // coset pre-multiplier tables of row k1 (shift h = g w_ext^k1), sub-tile 0 and 1, 8192 entries each:
 //   sub 0: [t] = h^t                                   (t < 8192)      x[t] h^t + x[t+4096] h^(t+4096)
 //   sub 1: [t] = h^t w^t, [t + 4096] = -h^(t+4096) w^t (t < 4096)      (x[t] h^t - x[t+4096] h^(t+4096)) w^t
-__global__ void __launch_bounds__(256) k_pre13_pack(Fr h, const Fr *__restrict__ fwd /* w^j, standard form */, LwMem *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_pre13_pack(Fr h, Fr start /* 32 c: the powers come out as c h^t in the 2^261 form */, const Fr *__restrict__ fwd /* w^j, standard form */,
+                                                    LwMem *__restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 8192) return;
-  Fr r = zk_fr_to_29(Fr::one());   // 32: the power comes out in the 2^261 form
+  Fr r = start;
   Fr b = h;
   for (int e = j; e; e >>= 1) {
     if (e & 1) r = r * b;
@@ -120,15 +121,20 @@ __device__ __forceinline__ Lw tw_at(const LwMem *__restrict__ p) { return lw_loa
 
 // radix-8 pass followed by the twiddles of the next level: x[s] <- y_s * tw[(s - 1) * stride]  (y_0: reduced only)
 __device__ __forceinline__ void pass8_tw(LzT (&x)[8], const Consts &K, const LwMem *__restrict__ tw, int stride) {
+  // the seven twiddles are requested before the butterfly (63 registers): their latency -- L2, mostly -- hides behind its nine
+  // products; loaded where they are used each product would wait a microsecond for its operand with two waves per SIMD
+  const Lw t1 = tw_at(tw), t2 = tw_at(tw + stride), t3 = tw_at(tw + 2 * stride), t4 = tw_at(tw + 3 * stride), t5 = tw_at(tw + 4 * stride),
+           t6 = tw_at(tw + 5 * stride), t7 = tw_at(tw + 6 * stride);
+  ZK_F
   ZK_DFT8_CORE(x, K)
   x[0] = lz_weak(y0); ZK_F
-  x[1] = mulw(y1, tw_at(tw));
-  x[2] = mulw(y2, tw_at(tw + stride));
-  x[3] = mulw(y3, tw_at(tw + 2 * stride));
-  x[4] = mulw(y4, tw_at(tw + 3 * stride));
-  x[5] = mulw(y5, tw_at(tw + 4 * stride));
-  x[6] = mulw(y6, tw_at(tw + 5 * stride));
-  x[7] = mulw(y7, tw_at(tw + 6 * stride));
+  x[1] = mulw(y1, t1);
+  x[2] = mulw(y2, t2);
+  x[3] = mulw(y3, t3);
+  x[4] = mulw(y4, t4);
+  x[5] = mulw(y5, t5);
+  x[6] = mulw(y6, t6);
+  x[7] = mulw(y7, t7);
 }
 
 // last radix-8 pass: canonical packed outputs, optionally times one constant (n^-1)
@@ -203,41 +209,47 @@ __global__ void __launch_bounds__(512, ZK_NTT13_WAVES) k_ntt13(Tile13Args A) {
   K.w83 = tw_at(tw + C_OFF + 2);
 
   // ---- load + radix 2 over m0 (this workgroup keeps the outputs k = sub mod 2) --------------------------------------------
-  // The index of iteration m is made to depend (empty asm) on the result of iteration m - 2: otherwise the compiler hoists the
-  // loads of all eight iterations to the top -- 320 registers of raw data.  Two iterations of loads are in flight, the other
-  // waves of the CU cover the rest of the latency.
+  // The inputs are requested four iterations ahead and the table entries of a product two: their index is made to depend
+  // (empty asm) on the result of an earlier iteration, otherwise the compiler hoists the loads of all eight iterations to the
+  // top -- 320 registers of raw data.
   LzT x[8];
+  Fr raw_lo[8], raw_hi[8];
+  auto fetch = [&](int m) {
+    int q = tid + 512 * m;
+    if (m >= 4) asm volatile("" : "+v"(q) : "v"(x[m - 4].l[8]));   // four iterations (64 registers) of raw inputs in flight
+    raw_lo[m] = q < a.in_len ? src[q] : Fr::zero();
+    raw_hi[m] = q + 4096 < a.in_len ? src[q + 4096] : Fr::zero();
+  };
+#pragma unroll
+  for (int m = 0; m < 4; ++m) fetch(m);
   if (A.pre) {
     const LwMem *__restrict__ pre = A.pre + ((size_t)b * 2 + sub) * 8192;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       int q = tid + 512 * m;
       if (m >= 2) asm volatile("" : "+v"(q) : "v"(x[m - 2].l[8]));
-      const auto lo = q < a.in_len ? lz_load(src[q]) : lz_zero();
-      const auto hi = q + 4096 < a.in_len ? lz_load(src[q + 4096]) : lz_zero();
       const Lw wa = tw_at(pre + q), wb = tw_at(pre + q + 4096);
+      const auto lo = lz_load(raw_lo[m]), hi = lz_load(raw_hi[m]);
       ZK_F
       x[m] = lz_mul2(lo, wa, hi, wb);
       ZK_F
+      if (m + 4 < 8) fetch(m + 4);
     }
   } else if (sub == 0) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      int q = tid + 512 * m;
-      if (m >= 4) asm volatile("" : "+v"(q) : "v"(x[m - 4].l[8]));
-      const auto lo = q < a.in_len ? lz_load(src[q]) : lz_zero();
-      const auto hi = q + 4096 < a.in_len ? lz_load(src[q + 4096]) : lz_zero();
-      x[m] = lz_norm(lz_add(lo, hi));   // (0,1), value < 2 r
+      x[m] = lz_norm(lz_add(lz_load(raw_lo[m]), lz_load(raw_hi[m])));   // (0,1), value < 2 r
+      ZK_F
+      if (m + 4 < 8) fetch(m + 4);
     }
   } else {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       int q = tid + 512 * m;
       if (m >= 2) asm volatile("" : "+v"(q) : "v"(x[m - 2].l[8]));
-      const auto lo = q < a.in_len ? lz_load(src[q]) : lz_zero();
-      const auto hi = q + 4096 < a.in_len ? lz_load(src[q + 4096]) : lz_zero();
       const Lw w = tw_at(tw + T0_OFF + q);
-      x[m] = mulw(lz_sub(lo, hi), w);
+      x[m] = mulw(lz_sub(lz_load(raw_lo[m]), lz_load(raw_hi[m])), w);
+      if (m + 4 < 8) fetch(m + 4);
     }
   }
 
@@ -315,10 +327,11 @@ __global__ void __launch_bounds__(512, ZK_NTT13_WAVES) k_ntt13(Tile13Args A) {
 }  // namespace
 
 // coset tables for coeff_to_extended at n = 2^13 (rows cosets g w_ext^k1 of the 2^(13+lef) domain), built once per context
-int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, const void **out) {
+// (scaled: every entry times 2^-13 -- for input that is an inverse transform WITHOUT its n^-1, see zk_extend_lagrange)
+int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const void **out) {
   std::array<uint64_t, 6> key;
   for (int i = 0; i < 4; ++i) key[i] = (uint64_t)g.l[2 * i] | ((uint64_t)g.l[2 * i + 1] << 32);
-  key[4] = (uint64_t)lef;
+  key[4] = (uint64_t)lef | (scaled ? 256u : 0u);
   key[5] = (uint64_t)rows;
   auto it = ctx->pre13.find(key);
   if (it == ctx->pre13.end()) {
@@ -330,8 +343,9 @@ int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, const void **out) {
     LwMem *p = nullptr;
     ZK_HIP(ctx, hipMalloc((void **)&p, (size_t)rows * 2 * 8192 * sizeof(LwMem)));
     Fr shift = g;
+    const Fr start = scaled ? dom->n_inv29 : zk_fr_to_29(Fr::one());
     for (int k1 = 0; k1 < rows; ++k1) {
-      k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, dom->fwd, p + (size_t)k1 * 2 * 8192);
+      k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, p + (size_t)k1 * 2 * 8192);
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * edom->omega;
     }

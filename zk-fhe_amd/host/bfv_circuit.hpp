@@ -258,9 +258,11 @@ struct CircuitConfig {  // configs/<name>.json "params"
   std::vector<uint32_t> bp_gate0, bp_gate1, bp_rlc;  // break points (replayed by the prover)
 
   size_t n() const { return (size_t)1 << k; }
-  unsigned bf() const { return unusable_rows - 3; }
-  size_t u() const { return n() - bf() - 1; }
-  size_t max_rows() const { return n() - unusable_rows; }
+  // row counts saturate at zero instead of wrapping: a configuration that has not been range-checked (3 < unusable_rows < 2^k)
+  // then yields empty ranges, not 2^64-sized ones
+  unsigned bf() const { return unusable_rows > 3 ? unusable_rows - 3 : 0; }
+  size_t u() const { return n() > (size_t)bf() + 1 ? n() - bf() - 1 : 0; }
+  size_t max_rows() const { return n() > unusable_rows ? n() - unusable_rows : 0; }
   unsigned n_gate() const { return n_gate0 + n_gate1; }
   unsigned n_advice() const { return n_gate() + n_lookup + n_rlc; }
   unsigned adv_lookup0() const { return n_gate(); }

@@ -179,7 +179,7 @@ int zkfhe_bfv_tables_poke_advice(zkfhe_bfv_tables *t, uint32_t column, uint32_t 
   return ZKFHE_OK;
 }
 
-int zkfhe_bfv_mock_check(const zkfhe_bfv_tables *t, const uint8_t gamma_le[32], uint64_t *n_failures, char *err, size_t err_len) {
+static int mock_check_impl(const zkfhe_bfv_tables *t, const uint8_t gamma_le[32], uint64_t *n_failures, char *err, size_t err_len) {
   if (!t || !gamma_le || !n_failures) return ZKFHE_EINVAL;
   const CircuitConfig &cfg = t->cfg;
   if (t->t.fixed.size() != cfg.n_fixed()) {
@@ -252,6 +252,17 @@ bool load_point(const uint8_t b[64], AffinePoint &p) {
 }
 }  // namespace
 
+int zkfhe_bfv_mock_check(const zkfhe_bfv_tables *t, const uint8_t gamma_le[32], uint64_t *n_failures, char *err, size_t err_len) {
+  try {   // strings and vectors are built on the way: nothing may propagate through the C ABI
+    return mock_check_impl(t, gamma_le, n_failures, err, err_len);
+  } catch (const std::bad_alloc &) {
+    return ZKFHE_ENOMEM;
+  } catch (const std::exception &e) {
+    if (err && err_len) snprintf(err, err_len, "%s", e.what());
+    return ZKFHE_EINVAL;
+  }
+}
+
 int zkfhe_transcript_create(uint32_t kind, zkfhe_transcript **out) {
   if (!out || (kind != ZKFHE_TRANSCRIPT_POSEIDON && kind != ZKFHE_TRANSCRIPT_BLAKE2B)) return ZKFHE_EINVAL;
   try {
@@ -309,12 +320,19 @@ int zkfhe_transcript_bytes(const zkfhe_transcript *t, uint8_t *out, size_t cap, 
 
 int zkfhe_host_poly_mul_u32(const uint64_t *a, const uint64_t *b, size_t n, uint64_t *lo, uint64_t *hi) {
   if (!a || !b || !lo || !hi) return ZKFHE_EINVAL;
-  const std::vector<uint64_t> va(a, a + n), vb(b, b + n);
-  if (!gl::fits(va, vb)) return ZKFHE_EINVAL;
-  std::vector<uint64_t> l, h;
-  gl::poly_mul_u32(va, vb, l, h);
-  memcpy(lo, l.data(), l.size() * 8);
-  memcpy(hi, h.data(), h.size() * 8);
+  if (n < 2 || n > 2048 || (n & (n - 1))) return ZKFHE_EINVAL;   // before a single element is read
+  try {
+    const std::vector<uint64_t> va(a, a + n), vb(b, b + n);
+    if (!gl::fits(va, vb)) return ZKFHE_EINVAL;
+    std::vector<uint64_t> l, h;
+    gl::poly_mul_u32(va, vb, l, h);
+    memcpy(lo, l.data(), l.size() * 8);
+    memcpy(hi, h.data(), h.size() * 8);
+  } catch (const std::bad_alloc &) {
+    return ZKFHE_ENOMEM;
+  } catch (const std::exception &) {
+    return ZKFHE_EINVAL;
+  }
   return ZKFHE_OK;
 }
 
@@ -333,7 +351,7 @@ int zkfhe_poseidon_permute(uint8_t state_le[96]) {
   }
   return ZKFHE_OK;
 }
-int zkfhe_poseidon_constants(uint8_t *rc_le, uint8_t *mds_le) {
+int zkfhe_poseidon_constants(uint8_t *rc_le, uint8_t *mds_le) try {
   const pos::Constants &c = pos::constants();
   for (int r = 0; r < pos::ROUNDS && rc_le; ++r)
     for (int i = 0; i < pos::T; ++i) {
@@ -346,6 +364,10 @@ int zkfhe_poseidon_constants(uint8_t *rc_le, uint8_t *mds_le) {
       memcpy(mds_le + 32 * (i * pos::T + j), v.l, 32);
     }
   return ZKFHE_OK;
+} catch (const std::bad_alloc &) {
+  return ZKFHE_ENOMEM;
+} catch (const std::exception &) {
+  return ZKFHE_EINVAL;
 }
 
 }  // extern "C"

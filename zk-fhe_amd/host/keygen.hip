@@ -68,6 +68,11 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int e
   CK(ws->points.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * 64 + 64));
   CK(ws->num.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
   CK(ws->den.alloc(ctx, std::max<size_t>(c.n_chunks(), c.n_lookup) * col));
+  // ws->small is carved up at fixed offsets (prove.hip): [0, 128 K) beta * delta^i per permutation column, [128 K, 256 K) chunk /
+  // lookup totals, 128 KB each for the quotient groups, y powers and inverses, then pointer / scalar / point lists, the SHPLONK
+  // sets (700 K), gadget arguments (768 K) and the early-commitment patch lists (900 K, 920 K): the widest lists must fit
+  if ((size_t)c.n_perm() > 4096 || (size_t)c.n_chunks() + c.n_lookup > 4096)
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, "configuration too wide for the prover workspace (more than 4096 permutation columns)");
   CK(ws->small.alloc(ctx, 1 << 20));
   const size_t max_items = (size_t)c.n_advice() + c.n_fixed() + 2 + c.n_perm() + c.n_chunks() + 3 * c.n_lookup;
   CK(ws->jobs.alloc(ctx, max_items * sizeof(zkp::EvalJob) + max_items * (sizeof(void *) + 32) + 256));
@@ -116,9 +121,8 @@ int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr,
   const int rows = pk->ext_rows;
   const size_t n = pk->cfg.n();
   const Fr g = mont_u64(COSET_G);
-  CK(zk_copy_d2d(ctx, ws->tmp_c.p, lagr, count * n * 32));
-  CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)ws->tmp_c.p, count, (int)pk->cfg.k, 1));
-  return zk_coset_ntt_rows(ctx, (const Fr *)ws->tmp_c.p, ext, count, (int)pk->cfg.k, 2, g, rows);
+  (void)n;
+  return zk_extend_lagrange(ctx, lagr, ws->tmp_c.fr(), ext, count, (int)pk->cfg.k, 2, g, rows);
 }
 
 // extended-coset evaluations of the fixed / sigma columns, l_0 / l_last / l_active and X on the coset: derived from the
@@ -432,6 +436,10 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
     cfg.k = hdr[0], cfg.n_gate0 = hdr[1], cfg.n_gate1 = hdr[2], cfg.n_lookup = hdr[3], cfg.n_rlc = hdr[4], cfg.unusable_rows = hdr[5], cfg.lookup_bits = hdr[6];
     cfg.transcript = hdr[7];
     if (!r.ok || cfg.transcript > TR_BLAKE2B || cfg.k < 3 || cfg.k > 20 || cfg.n_gate0 + cfg.n_gate1 > 4096 || cfg.n_lookup > 4096 || cfg.n_rlc > 4096) return fail("bad header");
+    // the same bounds as the verifier's parse_vk, BEFORE anything derives a row count from them: u() and max_rows() subtract
+    // unusable_rows from 2^k, and the lookup table has 2^lookup_bits rows
+    if (cfg.n_gate() == 0 || cfg.unusable_rows < 4 || cfg.unusable_rows >= cfg.n()) return fail("bad header (unusable_rows)");
+    if (cfg.lookup_bits == 0 || cfg.lookup_bits > 20 || ((size_t)1 << cfg.lookup_bits) > cfg.max_rows()) return fail("bad header (lookup_bits)");
     if (cfg.k != srs->k) return fail("proving key and SRS have different k");
     cfg.bp_gate0 = r.vec32(1 << 16), cfg.bp_gate1 = r.vec32(1 << 16), cfg.bp_rlc = r.vec32(1 << 16);
     pk->prm.N = r.u64(), pk->prm.Q = r.u64(), pk->prm.T = r.u64(), pk->prm.B = r.u64();
@@ -483,6 +491,20 @@ int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zk
     if ((rc = get_workspace(ctx, pk, &ws)) || (rc = build_resident_tables(ctx, pk, ws)) || (rc = zkfhe_sync(ctx))) {
       zkfhe_bfv_pk_destroy(ctx, pk);
       return rc;
+    }
+    // A key is bound to the SRS it was generated with: recommit the lookup-table column (the last fixed one, never zero) and
+    // the first permutation column against THIS SRS and compare with the stored commitments -- a key loaded against another
+    // seed / ceremony / world size would otherwise produce proofs that silently fail verification.
+    std::vector<AffinePoint> chk_f, chk_s;
+    if ((rc = commit_cols(ctx, srs, srs->g_lagrange, pk->fixed_l.fr() + (size_t)cfg.fix_table() * n, 1, (G1Affine *)ws->points.p, chk_f)) ||
+        (rc = commit_cols(ctx, srs, srs->g_lagrange, pk->sigma_l.fr(), 1, (G1Affine *)ws->points.p, chk_s))) {
+      zkfhe_bfv_pk_destroy(ctx, pk);
+      return rc;
+    }
+    if (!(chk_f[0].x == pk->fixed_commit[cfg.fix_table()].x) || !(chk_f[0].y == pk->fixed_commit[cfg.fix_table()].y) ||
+        !(chk_s[0].x == pk->sigma_commit[0].x) || !(chk_s[0].y == pk->sigma_commit[0].y)) {
+      zkfhe_bfv_pk_destroy(ctx, pk);
+      return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + ": proving key was generated with a different SRS");
     }
   } catch (const std::exception &e) {
     if (f) fclose(f);

@@ -577,6 +577,10 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       const bool sparse = !srs->sharded() && zkfhe_basis_has_multiples(srs->g_lagrange);
       CK(g1.patch(evals, plan, patch_cols, sparse ? &terms : nullptr));
       CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
+      // the corrections sit behind the early commitments in ws->points; the last slot of that buffer belongs to the random
+      // polynomial's commitment (auxiliary stream)
+      if ((n_adv1 + 2 * (size_t)cfg.n_lookup + np + cfg.n_rlc + 1) * sizeof(G1Affine) > ws->points.bytes)
+        return zk_fail_msg(ctx, ZKFHE_EINVAL, "early phase-1 commitment: correction points do not fit the workspace (set ZKFHE_EARLY_P1=0)");
       G1Affine *fix_dev = (G1Affine *)ws->points.p + n_adv1 + 2 * cfg.n_lookup;
       if (np && sparse) {
         // a dozen non-zero cells: one wave per correction column over the digit-multiple table
