@@ -103,6 +103,10 @@ int zkfhe_fq29_sqr_chain(zkfhe_ctx *ctx, const zkfhe_fq *a_dev, zkfhe_fq *out_de
  * this log_n (= ROOT_OF_UNITY^(2^(28-log_n)));  inverse = 1: w^-1 and a final multiplication by
  * n^-1 (lagrange_to_coeff).  1 <= log_n <= 26. */
 int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse);
+/* The same transform out of place (in_dev and out_dev distinct, not overlapping): EvaluationDomain::lagrange_to_coeff /
+ * coeff_to_lagrange consume one Polynomial and return another.  This is the form the kernels run natively at n = 2^13 (two
+ * workgroups per column, each reading all of it): the in-place call above goes through a scratch copy there. */
+int zkfhe_ntt_batch_to(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n, int inverse);
 
 /* coeff_to_extended (inverse = 0): column c holds 2^log_n coefficients at in_dev + c*2^log_n; writes
  * the 2^(log_n+log_ext_factor) evaluations over the coset g*<w_ext> to out_dev + c*2^(log_n+lef) in

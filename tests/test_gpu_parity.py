@@ -116,6 +116,23 @@ def test_ntt_vs_oracle(ctx, log_n):
     assert np.array_equal(ctx.ntt(fwd, log_n, True), a)
 
 
+@pytest.mark.parametrize("log_n,n_cols", [(5, 3), (12, 4), (13, 1), (13, 37), (14, 2)])
+def test_ntt_out_of_place(ctx, log_n, n_cols):
+    """zkfhe_ntt_batch_to: the input buffer is left untouched, the output equals the oracle.  At 2^13 this is the kernel's native
+    form (two workgroups per column, placed in groups of eight columns: 37 columns leave the last group ragged)."""
+    rng = np.random.default_rng(900 + log_n + n_cols)
+    n = 1 << log_n
+    a = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    for inv in (False, True):
+        src, dst = ctx.to_device(a), ctx.alloc(n_cols * n * 32)
+        ctx.ntt_to_dev(src, dst, n_cols, log_n, inverse=inv)
+        got = dst.download(shape=(n_cols, n, 4))
+        assert np.array_equal(src.download(shape=(n_cols, n, 4)), a)
+        want = orc.ntt(a, log_n, inv)
+        assert np.array_equal(got, want)
+        src.free(), dst.free()
+
+
 def test_ntt_golden(ctx, vec):
     for t in vec["ntt"]:
         a = orc.ints_to_mont(hx(t["in"]))

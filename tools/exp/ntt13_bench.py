@@ -24,15 +24,22 @@ def main():
         want = orc.ntt(raw[:3], log_n, inv)
         print("ntt inverse=%s matches oracle:" % inv, bool(np.array_equal(got, want)), flush=True)
     d = ctx.to_device(raw)
+    d2 = ctx.alloc(n_cols * n * 32)
     for inv in (False, True):
         for _ in range(3):
-            ctx.ntt_dev(d, n_cols, log_n, inverse=inv)
+            ctx.ntt_to_dev(d, d2, n_cols, log_n, inverse=inv)
         ts = []
         for _ in range(20):
             ctx.timer_start()
-            ctx.ntt_dev(d, n_cols, log_n, inverse=inv)
+            ctx.ntt_to_dev(d, d2, n_cols, log_n, inverse=inv)
             ts.append(ctx.timer_stop_ms())
-        print("2^13 x %d inverse=%s: median %.4f ms, min %.4f ms" % (n_cols, inv, float(np.median(ts)), min(ts)), flush=True)
+        print("2^13 x %d inverse=%s out of place: median %.4f ms, min %.4f ms" % (n_cols, inv, float(np.median(ts)), min(ts)), flush=True)
+    ts = []
+    for _ in range(10):
+        ctx.timer_start()
+        ctx.ntt_dev(d, n_cols, log_n, inverse=False)
+        ts.append(ctx.timer_stop_ms())
+    print("2^13 x %d in place (through scratch): median %.4f ms" % (n_cols, float(np.median(ts))), flush=True)
     g = orc.ints_to_mont([7])[0]
     o = ctx.alloc(n_cols * n * 4 * 32)
     for _ in range(3):

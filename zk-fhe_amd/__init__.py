@@ -22,7 +22,7 @@ EXPORTS = [
     "zkfhe_timer_start", "zkfhe_timer_stop_ms", "zkfhe_prof_enable", "zkfhe_prof_reset", "zkfhe_prof_read", "zkfhe_prof_read_ops",
     "zkfhe_fr_add", "zkfhe_fr_sub", "zkfhe_fr_mul", "zkfhe_fr_scale", "zkfhe_fr_to_mont", "zkfhe_fr_from_mont",
     "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain", "zkfhe_fq29_sqr_chain",
-    "zkfhe_ntt_batch", "zkfhe_coset_ntt_batch",
+    "zkfhe_ntt_batch", "zkfhe_ntt_batch_to", "zkfhe_coset_ntt_batch",
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
     "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_basis_has_multiples", "zkfhe_basis_table_bits", "zkfhe_srs_table_bits",
     "zkfhe_comm_unique_id", "zkfhe_comm_create", "zkfhe_comm_create_with_transport", "zkfhe_comm_destroy", "zkfhe_comm_rank", "zkfhe_comm_world",
@@ -227,6 +227,10 @@ class Context:
 
     def ntt_dev(self, cols, n_cols, log_n, inverse=False):
         self._check(self.lib.zkfhe_ntt_batch(self.h, self._p(cols), n_cols, log_n, int(bool(inverse))))
+
+    def ntt_to_dev(self, src, dst, n_cols, log_n, inverse=False):
+        self.lib.zkfhe_ntt_batch_to.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+        self._check(self.lib.zkfhe_ntt_batch_to(self.h, self._p(src), self._p(dst), n_cols, log_n, int(bool(inverse))))
 
     def coset_ntt_dev(self, src, dst, n_cols, log_n, log_ext_factor, g, inverse=False):
         g = np.ascontiguousarray(g, dtype=np.uint64)

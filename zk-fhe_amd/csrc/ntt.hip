@@ -229,15 +229,27 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
 
 #define MAX_TILE_LOG 13
 
+int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse);
+
 extern "C" {
 
-int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse) {
+int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse) { return zk_ntt_impl(ctx, nullptr, cols_dev, n_cols, log_n, inverse); }
+
+int zkfhe_ntt_batch_to(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n, int inverse) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, in_dev != nullptr && (const void *)in_dev != (const void *)out_dev);
+  return zk_ntt_impl(ctx, in_dev, out_dev, n_cols, log_n, inverse);
+}
+
+// src == nullptr: in place on cols_dev
+extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, log_n >= 1 && log_n <= 26);
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, cols_dev != nullptr);
   ZK_ARG(ctx, n_cols < 65536);
   Fr *data = (Fr *)cols_dev;
+  const Fr *src = (const Fr *)src_dev;
   const size_t n = (size_t)1 << log_n;
   const NttDomain *dom;
   int rc = zk_domain(ctx, log_n, &dom);
@@ -250,6 +262,10 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
     if (rc) return rc;
     ninv_dev = (Fr *)p;
     ZK_HIP(ctx, hipMemcpyAsync(ninv_dev, &dom->n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (log_n < 3 && src) {
+    rc = zk_copy_d2d(ctx, data, src, n_cols * n * sizeof(Fr));
+    if (rc) return rc;
   }
   if (log_n < 3) {
     // tiny transforms: DIF stages then a bit-reversed gather is overkill; do log_n DIF stages and fix order on 2/4 points
@@ -282,7 +298,7 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
   }
   if (log_n <= MAX_TILE_LOG) {
     TileArgs a{};
-    a.in = data;
+    a.in = src ? src : data;
     a.out = data;
     a.in_tile_stride = n;
     a.col_stride_in = a.col_stride_out = n;
@@ -292,7 +308,21 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
     a.log_tiles = 0;
     a.in_len = (int)n;
     a.out_natural_tiles = 1;
+    if (log_n == 13 && a.in == a.out) {
+      // the 2^13 tile cuts a column into two workgroups that both read all of it: in place it goes through scratch
+      void *p;
+      rc = zk_scratch(ctx, 0, n_cols * n * sizeof(Fr), &p);
+      if (rc) return rc;
+      a.out = (Fr *)p;
+      rc = launch_tile_dyn(ctx, log_n, a, 1, (unsigned)n_cols);
+      if (rc) return rc;
+      return zk_copy_d2d(ctx, data, p, n_cols * n * sizeof(Fr));
+    }
     return launch_tile_dyn(ctx, log_n, a, 1, (unsigned)n_cols);
+  }
+  if (src) {
+    rc = zk_copy_d2d(ctx, data, src, n_cols * n * sizeof(Fr));
+    if (rc) return rc;
   }
   // large: DIF stages down to 2^13 blocks, then tile NTT per block with bit-reversed strided scatter
   const int log_tiles = log_n - MAX_TILE_LOG;

@@ -357,6 +357,8 @@ int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const 
 
 int zk_launch_tile_13(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsigned cols) {
   if (a.pre && !a.pre13) return zk_fail_msg(ctx, ZKFHE_EINVAL, "2^13 tile: coset tables missing (zk_pre13)");
+  // the two workgroups of a column both read all of it and write interleaved halves: never in place
+  if ((const void *)a.in == (const void *)a.out) return zk_fail_msg(ctx, ZKFHE_EINVAL, "2^13 tile: input and output must be different buffers");
   auto it = ctx->tw13.find((const void *)a.tw);
   if (it == ctx->tw13.end()) {
     LwMem *p = nullptr;

@@ -288,7 +288,16 @@ static __global__ void __launch_bounds__(64) k_patch_cells(const PatchCell *__re
   if (i >= count) return;
   const Fr v = values[cells[i].value];
   *cells[i].dst_adv = v;
-  *cells[i].dst_patch = v;
+  if (cells[i].dst_patch) *cells[i].dst_patch = v;
+}
+// up to four runs of four reserved cells back to zero (one launch instead of four fills)
+struct ZeroRuns {
+  Fr *at[4];
+  unsigned count;
+};
+static __global__ void __launch_bounds__(64) k_zero_runs(ZeroRuns z) {
+  const unsigned i = threadIdx.x >> 2, j = threadIdx.x & 3;
+  if (i < z.count) z.at[i][j] = Fr::zero();
 }
 // lookup advice columns: the k-th looked-up cell goes to column k / max_rows, row k % max_rows
 static __global__ void __launch_bounds__(256) k_place_lookups(const Fr *__restrict__ stream, const unsigned *__restrict__ src_off, size_t n_lookups,
@@ -327,7 +336,7 @@ static __global__ void __launch_bounds__(1024) k_lookup_permute(const Fr *__rest
   for (unsigned i = t; i < u; i += T) {
     const Fr v = zk::fp_from_mont<FrP>(col[i]);
     if (v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7] || v.l[0] > 255u) {
-      atomicExch(err, 1);
+      *(volatile int *)err = 1;   // a plain store: the flag may live in pinned host memory (every writer stores the same value)
       continue;
     }
     atomicAdd(&cnt[v.l[0]], 1u);

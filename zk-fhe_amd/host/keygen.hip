@@ -88,7 +88,7 @@ void free_workspace(Workspace *ws) {
   (void)hipSetDevice(ws->all_l.device);
   for (DevBuf *b : ws->all()) b->release();
   for (void *h : {(void *)ws->host_adv, (void *)ws->host_blind, (void *)ws->host_pool, (void *)ws->host_poly, (void *)ws->host_pts, (void *)ws->ring, (void *)ws->host_rand_pt,
-                  (void *)ws->host_early, (void *)ws->host_early_err})
+                  (void *)ws->host_early, (void *)ws->host_early_err, (void *)ws->host_out})
     if (h) (void)hipHostFree(h);
   if (ws->ev_pts) (void)hipEventDestroy(ws->ev_pts);
   if (ws->ev_rand) (void)hipEventDestroy(ws->ev_rand);

@@ -18,6 +18,17 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_poly, ws->host_poly_len * 32, hipHostMallocDefault));
   CK(ws->wblind.alloc(ctx, 256));   // the lookup-permutation error flag
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->ring, Workspace::RING_BYTES, hipHostMallocDefault));
+  CK(ws->dev_ring.alloc(ctx, Workspace::RING_BYTES));
+  {
+    const CircuitConfig &c = pk->cfg;
+    const size_t max_items = (size_t)c.n_advice() + c.n_fixed() + 2 + c.n_perm() + c.n_chunks() + 3 * c.n_lookup;
+    ws->out_pts_cap = std::max<size_t>(ws->n_all, c.n_perm()) + 16;
+    ws->out_ev_off = ws->out_pts_cap * sizeof(G1Affine);
+    ws->out_ev_cap = max_items * 4;
+    ws->out_flag_off = ws->out_ev_off + ws->out_ev_cap * 32;
+    ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_out, ws->out_flag_off + 256, hipHostMallocDefault));
+    memset(ws->host_out, 0, ws->out_flag_off + 256);
+  }
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming | hipEventBlockingSync));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_rand, hipEventDisableTiming | hipEventBlockingSync));
@@ -160,7 +171,11 @@ class GpuPhase1 {
   // stream, then stream -> gate columns (break points) and lookup columns.  The columns can be committed from here on;
   // patch() supplies the missing cells and the correction columns.
   int place_early() {
-    for (unsigned i = 0; i < n_mg; ++i) ZK_HIP(ctx, hipMemsetAsync(stream + mg_off[i], 0, 4 * 32, ctx->stream));
+    zkw::ZeroRuns z{};
+    z.count = n_mg;
+    for (unsigned i = 0; i < n_mg; ++i) z.at[i] = stream + mg_off[i];
+    zkw::k_zero_runs<<<1, 64, 0, ctx->stream>>>(z);
+    ZK_LAUNCH_CHECK(ctx);
     return place();
   }
   // (gate column, row) of every reserved cell -- twice for a cell on a break point, whose value is repeated at the top of the
@@ -224,15 +239,14 @@ class GpuPhase1 {
     for (size_t t = 0; t < cells.size(); ++t) {
       const auto &c = plan.cells[t];
       cells[t].dst_adv = ws->adv_l.fr() + ((size_t)cfg.n_gate0 + plan.columns[c.col_slot]) * n + c.row;
-      cells[t].dst_patch = patch_cols + (size_t)c.col_slot * n + c.row;
+      cells[t].dst_patch = terms ? nullptr : patch_cols + (size_t)c.col_slot * n + c.row;   // dense correction columns only without the sparse MSM
       cells[t].value = c.value;
     }
     if (cells.size() > 64) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many challenge-dependent gate cells");
-    Fr *vals_dev = ws->pool.fr() + mg_slot;
-    zkw::PatchCell *cells_dev = (zkw::PatchCell *)((char *)ws->small.p + 900 * 1024);
-    CK(up(ctx, ws, vals_dev, mg, sizeof(mg)));
-    CK(up(ctx, ws, cells_dev, cells.data(), cells.size() * sizeof(zkw::PatchCell)));
-    ZK_HIP(ctx, hipMemsetAsync(patch_cols, 0, plan.columns.size() * n * 32, ctx->stream));
+    STAGE(vals_dev, Fr, ws, mg, sizeof(mg));
+    STAGE(cells_dev, zkw::PatchCell, ws, cells.data(), cells.size() * sizeof(zkw::PatchCell));
+    CK(flush_staged(ctx, ws));
+    if (!terms) ZK_HIP(ctx, hipMemsetAsync(patch_cols, 0, plan.columns.size() * n * 32, ctx->stream));
     zkw::k_patch_cells<<<1, 64, 0, ctx->stream>>>(cells_dev, (unsigned)cells.size(), vals_dev);
     ZK_LAUNCH_CHECK(ctx);
     return ZKFHE_OK;
@@ -340,9 +354,8 @@ class GpuPhase1 {
         if (call_level[i] == l) ordered.push_back(calls[i]);
     }
     first[max_level + 1] = ordered.size();
-    zkw::GadgetArgs *dev = (zkw::GadgetArgs *)((char *)ws->small.p + 768 * 1024);
-    if (ordered.size() * sizeof(zkw::GadgetArgs) > 128 * 1024) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many gadget calls");
-    CK(up(ctx, ws, dev, ordered.data(), ordered.size() * sizeof(zkw::GadgetArgs)));
+    STAGE(dev, zkw::GadgetArgs, ws, ordered.data(), ordered.size() * sizeof(zkw::GadgetArgs));
+    CK(flush_staged(ctx, ws));
     for (int l = 0; l <= max_level; ++l) {
       size_t longest = 0;
       for (size_t i = first[l]; i < first[l + 1]; ++i) longest = std::max(longest, ordered[i].count);
@@ -458,7 +471,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // queued: drain the stream before the buffers are rewritten (free when the stream is idle)
   CK(zkfhe_sync(ctx));
   CK(alloc_witness_buffers(ctx, pk, ws));
-  ws->ring_off = 0;
+  ws->ring_off = ws->ring_flushed = 0;
   trace.mark("setup (workspace)");
   // random polynomial, early: its coefficients (the tail of the blinding stream) depend on no challenge, so they are drawn and
   // committed on the auxiliary stream beside the phase-0 / witness work.  The main stream is idle here (synchronised above)
@@ -470,9 +483,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     Fr *rand_dev = ws->misc.fr() + 8 * n;
     G1Affine *pt_dev = (G1Affine *)ws->points.p + std::max<size_t>(ws->n_all, cfg.n_perm());
     CK(rng_fill(aux->stream, ctr_rand, 0, rand_dev, n, n, 1));
-    if (int rc = zkfhe_msm_batch(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_affine *)pt_dev))
+    (void)pt_dev;   // the commitment is stored by the MSM's last kernel into pinned memory: no copy command
+    if (int rc = zkfhe_msm_batch(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_affine *)ws->host_rand_pt))
       return zk_fail_msg(ctx, rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(aux));
-    ZK_HIP(ctx, hipMemcpyAsync(ws->host_rand_pt, pt_dev, sizeof(G1Affine), hipMemcpyDeviceToHost, aux->stream));
     ZK_HIP(ctx, hipEventRecord(ws->ev_rand, aux->stream));
   }
   const CircuitInput in = CircuitInput::parse_json(input_json);
@@ -517,8 +530,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   } else {
     // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
     CK(alloc_witness_buffers(ctx, pk, ws));
-    CK(srs_msm(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, (G1Affine *)ws->points.p));
-    ZK_HIP(ctx, hipMemcpyAsync(ws->host_pts, ws->points.p, cfg.n_gate0 * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+    CK(srs_msm(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, ws->host_pts));   // stored into pinned memory by the MSM itself
     ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
     CK(g1.launch(st));
     if (early_p1) {
@@ -531,16 +543,13 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       CK(g1.place_early());
       CK(rng_fill(ctx->stream, ctr_adv + (uint64_t)cfg.n_gate0 * nbl0, nbl0, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n + u, nbl0, n, cfg.adv_rlc0() - cfg.n_gate0));
       ZK_HIP(ctx, hipMemsetAsync(ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, 0, (size_t)cfg.n_rlc * n * 32, ctx->stream));
-      int *err_dev = (int *)ws->wblind.p;
-      ZK_HIP(ctx, hipMemsetAsync(err_dev, 0, 4, ctx->stream));
+      int *err_dev = ws->host_early_err;   // pinned: written by the kernel, read by the host after ev_early
+      *err_dev = 0;
       zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), err_dev);
       ZK_LAUNCH_CHECK(ctx);
       CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl0, ws->la_l.fr() + u, nbl0, n, cfg.n_lookup));
       CK(rng_fill(ctx->stream, ctr_lk + nbl0, 2 * nbl0, ws->ls_l.fr() + u, nbl0, n, cfg.n_lookup));
-      G1Affine *early_dev = (G1Affine *)ws->points.p;   // the phase-0 points above are copied out in stream order before this
-      CK(srs_msm(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, early_dev));
-      ZK_HIP(ctx, hipMemcpyAsync(ws->host_early, early_dev, n_early * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
-      ZK_HIP(ctx, hipMemcpyAsync(ws->host_early_err, err_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+      CK(srs_msm(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, ws->host_early));
       ZK_HIP(ctx, hipEventRecord(ws->ev_early, ctx->stream));
     }
     ZK_HIP(ctx, hipEventSynchronize(ws->ev_pts));
@@ -579,21 +588,21 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       CK(blind_and_upload(cfg.adv_rlc0(), cfg.n_advice()));
       // the corrections sit behind the early commitments in ws->points; the last slot of that buffer belongs to the random
       // polynomial's commitment (auxiliary stream)
-      if ((n_adv1 + 2 * (size_t)cfg.n_lookup + np + cfg.n_rlc + 1) * sizeof(G1Affine) > ws->points.bytes)
+      if (np + cfg.n_rlc > ws->out_pts_cap)
         return zk_fail_msg(ctx, ZKFHE_EINVAL, "early phase-1 commitment: correction points do not fit the workspace (set ZKFHE_EARLY_P1=0)");
-      G1Affine *fix_dev = (G1Affine *)ws->points.p + n_adv1 + 2 * cfg.n_lookup;
+      (void)n_adv1;
+      G1Affine *fix_dev = ws->out_pts();   // pinned: the correction points are read by the host right below
       if (np && sparse) {
         // a dozen non-zero cells: one wave per correction column over the digit-multiple table
-        zkfhe_sparse_term *terms_dev = (zkfhe_sparse_term *)((char *)ws->small.p + 920 * 1024);
-        CK(up(ctx, ws, terms_dev, terms.data(), terms.size() * sizeof(zkfhe_sparse_term)));
+        STAGE(terms_dev, zkfhe_sparse_term, ws, terms.data(), terms.size() * sizeof(zkfhe_sparse_term));
+        CK(flush_staged(ctx, ws));
         CK(zkfhe_msm_sparse(ctx, srs->g_lagrange, terms_dev, terms.size(), np, (zkfhe_g1_affine *)fix_dev));
       } else if (np) {
         CK(srs_msm(ctx, srs, srs->g_lagrange, patch_cols, np, fix_dev));
       }
       if (cfg.n_rlc) CK(srs_msm(ctx, srs, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, cfg.n_rlc, fix_dev + np));
-      std::vector<G1Affine> fix(np + cfg.n_rlc);
-      if (!fix.empty()) CK(zkfhe_download(ctx, fix.data(), fix_dev, fix.size() * sizeof(G1Affine)));
-      ZK_HIP(ctx, hipEventSynchronize(ws->ev_early));
+      ZK_HIP(ctx, zk_wait(ctx));   // everything queued so far, the early commitment (ev_early) included
+      const G1Affine *fix = fix_dev;
       if (*ws->host_early_err) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
       for (size_t t = 0; t < np; ++t) {   // early commitment + correction, on the host (at most a handful of additions)
         G1Affine &e = ws->host_early[plan.columns[t]];
@@ -634,23 +643,21 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     // hashed: one MSM call over [phase-1 advice | la | ls] (contiguous in all_l) instead of two, same points, same
     // transcript order, same draw order of the blinding values.
     if (cfg.lookup_bits != 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "the device lookup permutation is built for lookup_bits = 8");
-    lookup_err = (int *)ws->wblind.p;
-    ZK_HIP(ctx, hipMemsetAsync(lookup_err, 0, 4, ctx->stream));
+    lookup_err = ws->out_flags() + 2;   // pinned
+    *lookup_err = 0;
     zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
     ZK_LAUNCH_CHECK(ctx);
     // blinding rows: la_i then ls_i, lookup by lookup -- two interleaved runs of the stream
     CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl, ws->la_l.fr() + u, nbl, n, cfg.n_lookup));
     CK(rng_fill(ctx->stream, ctr_lk + nbl, 2 * nbl, ws->ls_l.fr() + u, nbl, n, cfg.n_lookup));
     const size_t n_adv1 = cfg.n_advice() - cfg.n_gate0;
-    CK(commit_cols(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_adv1 + 2 * cfg.n_lookup, (G1Affine *)ws->points.p, pts));
-    int e = 0;
-    CK(zkfhe_download(ctx, &e, lookup_err, 4));
-    if (e) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
+    CK(commit_cols_out(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_adv1 + 2 * cfg.n_lookup, ws, pts));
+    if (*lookup_err) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
     la_commit.assign(pts.begin() + n_adv1, pts.begin() + n_adv1 + cfg.n_lookup);
     ls_commit.assign(pts.begin() + n_adv1 + cfg.n_lookup, pts.end());
     pts.resize(n_adv1);
   } else {
-    CK(commit_cols(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, (G1Affine *)ws->points.p, pts));
+    CK(commit_cols_out(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, ws, pts));
   }
   trace.mark("commit phase 1 (GPU)");
   for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
@@ -671,7 +678,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)ws->la_l.p, (zkfhe_fr *)ws->la_l.p, 2 * (size_t)cfg.n_lookup * n));
       CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl, ws->la_l.fr() + u, nbl, n, cfg.n_lookup));
       CK(rng_fill(ctx->stream, ctr_lk + nbl, 2 * nbl, ws->ls_l.fr() + u, nbl, n, cfg.n_lookup));
-      CK(commit_cols(ctx, srs, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, (G1Affine *)ws->points.p, la_commit));  // la | ls contiguous
+      CK(commit_cols_out(ctx, srs, small_basis, ws->la_l.fr(), 2 * cfg.n_lookup, ws, la_commit));  // la | ls contiguous
       ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
       la_commit.resize(cfg.n_lookup);
     }
@@ -716,16 +723,12 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Fr *totals_dev = (Fr *)ws->small.p + 4096;
   zkp::k_prefix_product<<<(unsigned)nch, 1024, 0, ctx->stream>>>(ws->num.fr(), ws->pz_l.fr(), totals_dev, n, (unsigned)u);
   ZK_LAUNCH_CHECK(ctx);
+  int *const closes = ws->out_flags();   // pinned: [0] permutation, [1] lookups -- read after the commitment of the products below
+  closes[0] = closes[1] = 1;
   {
-    std::vector<Fr> totals(nch), carry(nch);
-    CK(zkfhe_download(ctx, totals.data(), totals_dev, nch * 32));
-    Fr acc = Fr::one();
-    for (size_t j = 0; j < nch; ++j) {
-      carry[j] = acc;
-      acc = acc * totals[j];
-    }
-    if (!(acc == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "permutation argument does not close: a copy constraint is violated");
-    CK(up(ctx, ws, totals_dev, carry.data(), nch * 32));
+    // chunk j starts where chunk j - 1 ended: the carries are the running product of the chunk totals, formed on the device
+    zkp::k_chunk_carry<<<1, 1024, 0, ctx->stream>>>(totals_dev, (unsigned)nch, 0, closes);
+    ZK_LAUNCH_CHECK(ctx);
     zkp::k_scale_rows<<<grid_for(ctx, nch * (u + 1)), 256, 0, ctx->stream>>>(ws->pz_l.fr(), totals_dev, n, (unsigned)(u + 1), (unsigned)nch);
     ZK_LAUNCH_CHECK(ctx);
     // blinding rows u+1 .. n-1 (drawn per chunk, in order)
@@ -743,15 +746,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)ws->num.p, (const zkfhe_fr *)ws->den.p, (zkfhe_fr *)ws->num.p, nl * n));
     zkp::k_prefix_product<<<(unsigned)nl, 1024, 0, ctx->stream>>>(ws->num.fr(), ws->lz_l.fr(), totals_dev, n, (unsigned)u);
     ZK_LAUNCH_CHECK(ctx);
-    std::vector<Fr> totals(nl);
-    CK(zkfhe_download(ctx, totals.data(), totals_dev, nl * 32));
-    for (size_t i = 0; i < nl; ++i)
-      if (!(totals[i] == Fr::one())) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup argument does not close");
+    zkp::k_chunk_carry<<<1, 1024, 0, ctx->stream>>>(totals_dev, (unsigned)nl, 1, closes + 1);
+    ZK_LAUNCH_CHECK(ctx);
     const size_t nb = n - u - 1;
     CK(rng_fill(ctx->stream, ctr_lz, nb, ws->lz_l.fr() + (u + 1), nb, n, nl));
   }
   std::vector<AffinePoint> pz_commit, lz_commit;
-  CK(commit_cols(ctx, srs, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, (G1Affine *)ws->points.p, pz_commit));  // pz | lz contiguous
+  CK(commit_cols_out(ctx, srs, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, ws, pz_commit));  // pz | lz contiguous
+  if (!closes[0]) return zk_fail_msg(ctx, ZKFHE_EINVAL, "permutation argument does not close: a copy constraint is violated");
+  if (!closes[1]) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup argument does not close");
   lz_commit.assign(pz_commit.begin() + nch, pz_commit.end());
   pz_commit.resize(nch);
   for (const auto &p : pz_commit) tr.write_point(p);
@@ -766,7 +769,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   } else {
     CK(rng_fill(ctx->stream, ctr_rand, 0, rand_c, n, n, 1));
     std::vector<AffinePoint> rand_commit;
-    CK(commit_cols(ctx, srs, srs->g, rand_c, 1, (G1Affine *)ws->points.p, rand_commit));
+    CK(commit_cols_out(ctx, srs, srs->g, rand_c, 1, ws, rand_commit));
     tr.write_point(rand_commit[0]);
   }
   const Fr y = mont(tr.squeeze());
@@ -801,11 +804,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     if (G > 96) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
     std::vector<Fr> ypow(G);
     for (size_t g = 0; g < G; ++g) ypow[g] = fr_pow(y, E - 1 - last_e[g]);
-    zkp::QGroup *groups_dev = (zkp::QGroup *)((char *)ws->small.p + 256 * 1024);
-    Fr *ypow_dev = (Fr *)((char *)ws->small.p + 384 * 1024);
-    Fr *zinv_dev = (Fr *)((char *)ws->small.p + 512 * 1024);
-    CK(up(ctx, ws, groups_dev, groups.data(), G * sizeof(zkp::QGroup)));
-    CK(up(ctx, ws, ypow_dev, ypow.data(), G * 32));
+    STAGE(groups_dev, zkp::QGroup, ws, groups.data(), G * sizeof(zkp::QGroup));
+    STAGE(ypow_dev, Fr, ws, ypow.data(), G * 32);
     const Fr wext = zk_fr_root_of_unity((int)k + 2);
     const Fr gn = fr_pow(mont_u64(COSET_G), n), i4 = fr_pow(wext, n);
     Fr zinv[4], cur = gn;
@@ -813,7 +813,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       zinv[t] = fr_inv(cur - Fr::one());
       cur = cur * i4;
     }
-    CK(up(ctx, ws, zinv_dev, zinv, 4 * 32));
+    STAGE(zinv_dev, Fr, ws, zinv, 4 * 32);
+    CK(flush_staged(ctx, ws));
     zkp::QArgs qa;
     qa.adv = ws->adv_ext.fr();
     qa.fix = pk->fixed_ext.fr();
@@ -859,8 +860,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       // three size-n inverse transforms, then the 3x3 Vandermonde solve per coefficient (prover_kernels.hip.hpp: k_ext3_combine)
       Fr *rows3 = ws->partials.fr();            // the partials are dead after the combine; 3n values
       Fr *pw = rows3 + 4 * n;                    // 3n values
-      CK(zk_copy_d2d(ctx, rows3, ws->h_ext.p, 3 * n * 32));
-      CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)rows3, 3, (int)k, 1));
+      CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)rows3, 3, (int)k, 1));
       Fr gk[3], c[3];
       gk[0] = g;
       gk[1] = g * wext;
@@ -887,7 +887,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     }
   }
   std::vector<AffinePoint> h_commit;
-  CK(commit_cols(ctx, srs, srs->g, ws->h_c.fr(), 3, (G1Affine *)ws->points.p, h_commit));
+  CK(commit_cols_out(ctx, srs, srs->g, ws->h_c.fr(), 3, ws, h_commit));
   if (q_rows == 4) {
     // the quotient must have degree < 3n: a non-zero top quarter means a violated constraint
     std::vector<U256> top(8);
@@ -902,21 +902,6 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   trace.mark("quotient");
   // ------------------------------------------------------------ evaluations at x * w^rot (barycentric, Lagrange form)
   const Fr xn = fr_pow(x, n);
-  {
-    // H(X) = h0 + x^n h1 + x^2n h2, and the random polynomial, in Lagrange form
-    const Fr sc[3] = {Fr::one(), xn, xn * xn};
-    const Fr *ptrs[3] = {ws->h_c.fr(), ws->h_c.fr() + n, ws->h_c.fr() + 2 * n};
-    const Fr **ptrs_dev = (const Fr **)((char *)ws->small.p + 640 * 1024);
-    Fr *sc_dev = (Fr *)((char *)ws->small.p + 648 * 1024);
-    CK(up(ctx, ws, ptrs_dev, ptrs, sizeof(ptrs)));
-    CK(up(ctx, ws, sc_dev, sc, sizeof(sc)));
-    zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
-    ZK_LAUNCH_CHECK(ctx);
-    CK(zk_copy_d2d(ctx, H_l, H_c, n * 32));
-    CK(zk_copy_d2d(ctx, rand_l, rand_c, n * 32));
-    CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)H_l, 1, (int)k, 0));
-    CK(zkfhe_ntt_batch(ctx, (zkfhe_fr *)rand_l, 1, (int)k, 0));
-  }
   // rotation ids: 0,1,2,3 -> w^r ; 4 -> w^u ("last") ; 5 -> w^-1
   Fr pts_rot[6];
   {
@@ -928,10 +913,23 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     pts_rot[4] = x * fr_pow(w, u);
     pts_rot[5] = x * dom->omega_inv;
   }
+  Fr *pts_dev = nullptr;
+  {
+    // H(X) = h0 + x^n h1 + x^2n h2, and the random polynomial, in Lagrange form
+    const Fr sc[3] = {Fr::one(), xn, xn * xn};
+    const Fr *ptrs[3] = {ws->h_c.fr(), ws->h_c.fr() + n, ws->h_c.fr() + 2 * n};
+    STAGE(ptrs_dev, const Fr *, ws, ptrs, sizeof(ptrs));
+    STAGE(sc_dev, Fr, ws, sc, sizeof(sc));
+    STAGE(pts_stage, Fr, ws, pts_rot, sizeof(pts_rot));   // the six evaluation points go up with the same copy
+    pts_dev = pts_stage;
+    CK(flush_staged(ctx, ws));
+    zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
+    ZK_LAUNCH_CHECK(ctx);
+    CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)H_c, (zkfhe_fr *)H_l, 1, (int)k, 0));
+    CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)rand_c, (zkfhe_fr *)rand_l, 1, (int)k, 0));
+  }
   Fr *bw = ws->misc.fr();  // [6][n] barycentric weights
   {
-    Fr *pts_dev = (Fr *)((char *)ws->small.p + 656 * 1024);
-    CK(up(ctx, ws, pts_dev, pts_rot, sizeof(pts_rot)));
     zkp::k_bary_den<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, pts_dev, 6, n, bw);
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)bw, 6 * n));
@@ -974,8 +972,10 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       jobs[i].n_rot = items[i].n_rot;
       for (int r = 0; r < 4; ++r) jobs[i].rot[r] = r < items[i].n_rot ? items[i].rot[r] : 0;
     }
-    DevBuf &jd = ws->jobs, &od = ws->evout;
-    CK(up(ctx, ws, jd.p, jobs.data(), jobs.size() * sizeof(zkp::EvalJob)));
+    DevBuf &od = ws->evout;
+    STAGE(jobs_dev, zkp::EvalJob, ws, jobs.data(), jobs.size() * sizeof(zkp::EvalJob));
+    CK(flush_staged(ctx, ws));
+    struct { const void *p; } jd{jobs_dev};
     // long columns: 16 row slices per job (partial sums in the dead quotient buffer), then one small reduction
     const unsigned slices = (n > 32768 && (size_t)16 * jobs.size() * 4 * 32 <= ws->partials.bytes) ? 16u : 1u;
     if (slices == 1) {
@@ -986,9 +986,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       zkp::k_sum_rows<<<grid_for(ctx, jobs.size() * 4), 256, 0, ctx->stream>>>(ws->partials.fr(), slices, jobs.size() * 4, od.fr());
     }
     ZK_LAUNCH_CHECK(ctx);
-    CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)od.p, (zkfhe_fr *)od.p, jobs.size() * 4));
-    std::vector<U256> ev(jobs.size() * 4);
-    CK(zkfhe_download(ctx, ev.data(), od.p, ev.size() * 32));
+    if (jobs.size() * 4 > ws->out_ev_cap) return zk_fail_msg(ctx, ZKFHE_EINVAL, "more evaluations than the result block holds");
+    // canonical values straight into pinned memory (the conversion kernel stores them there): no copy command
+    CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)od.p, (zkfhe_fr *)ws->out_ev(), jobs.size() * 4));
+    ZK_HIP(ctx, zk_wait(ctx));
+    const U256 *ev = ws->out_ev();
     for (size_t i = 0; i < items.size(); ++i)
       for (int r = 0; r < items[i].n_rot; ++r) items[i].ev[r] = ev[i * 4 + r];
   }
@@ -1007,10 +1009,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   if (ns > 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many rotation sets");
   std::vector<zkp::ShSet> shsets(ns);
   {
-    // pointer and scalar tables live behind the eval-job table, one slice per set (no host round trip between the sets)
-    char *const ptab = (char *)ws->jobs.p + items.size() * sizeof(zkp::EvalJob);
-    char *const stab = ptab + ((items.size() * sizeof(void *) + 31) / 32) * 32;
-    size_t tab_off = 0;
+    // pointer and scalar tables of every set are staged first and go up with one copy; then the launches
+    std::vector<const Fr *const *> set_ptrs(ns);
+    std::vector<const Fr *> set_pw(ns);
     for (size_t j = 0; j < ns; ++j) {
       const auto &mem = sets[j].members;
       std::vector<const Fr *> ptrs(mem.size());
@@ -1024,22 +1025,10 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         for (size_t t = 0; t < np; ++t) comb[t] = comb[t] + cur * mont(items[mem[m]].ev[layout.eval_slot(mem[m], sets[j].rots[t])]);
         cur = cur * yq;
       }
-      struct { void *p; } pd, sd;
-      pd.p = ptab + tab_off * sizeof(void *);
-      sd.p = stab + tab_off * 32;
-      tab_off += mem.size();
-      CK(up(ctx, ws, pd.p, ptrs.data(), mem.size() * sizeof(void *)));
-      CK(up(ctx, ws, sd.p, pw.data(), mem.size() * 32));
-      const unsigned per = 48, chunks = (unsigned)((mem.size() + per - 1) / per);
-      if (chunks > 1 && (size_t)chunks * n * 32 <= ws->partials.bytes) {
-        dim3 lg(grid_for(ctx, n), chunks);
-        zkp::k_lincomb_ptrs_chunked<<<lg, 256, 0, ctx->stream>>>((const Fr *const *)pd.p, (const Fr *)sd.p, (unsigned)mem.size(), per, n, ws->partials.fr());
-        ZK_LAUNCH_CHECK(ctx);
-        zkp::k_sum_rows<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ws->partials.fr(), chunks, n, F + j * n);
-      } else {
-        zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>((const Fr *const *)pd.p, (const Fr *)sd.p, (unsigned)mem.size(), n, F + j * n);
-      }
-      ZK_LAUNCH_CHECK(ctx);
+      STAGE(pd, const Fr *, ws, ptrs.data(), mem.size() * sizeof(void *));
+      STAGE(sd, Fr, ws, pw.data(), mem.size() * 32);
+      set_ptrs[j] = pd;
+      set_pw[j] = sd;
       // r_j: interpolation through (pts, comb), ascending coefficients
       zkp::ShSet &S = shsets[j];
       for (int t = 0; t < 4; ++t) S.rc[t] = S.pts[t] = Fr::zero();
@@ -1062,6 +1051,20 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         for (size_t q = 0; q < num.size(); ++q) S.rc[q] = S.rc[q] + num[q] * scl;
       }
     }
+    CK(flush_staged(ctx, ws));
+    for (size_t j = 0; j < ns; ++j) {
+      const unsigned msz = (unsigned)sets[j].members.size();
+      const unsigned per = 48, chunks = (msz + per - 1) / per;
+      if (chunks > 1 && (size_t)chunks * n * 32 <= ws->partials.bytes) {
+        dim3 lg(grid_for(ctx, n), chunks);
+        zkp::k_lincomb_ptrs_chunked<<<lg, 256, 0, ctx->stream>>>(set_ptrs[j], set_pw[j], msz, per, n, ws->partials.fr());
+        ZK_LAUNCH_CHECK(ctx);
+        zkp::k_sum_rows<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ws->partials.fr(), chunks, n, F + j * n);
+      } else {
+        zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(set_ptrs[j], set_pw[j], msz, n, F + j * n);
+      }
+      ZK_LAUNCH_CHECK(ctx);
+    }
   }
   const Fr v = mont(tr.squeeze());
   {
@@ -1073,19 +1076,20 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       cur = cur * v;
     }
   }
-  zkp::ShSet *sets_dev = (zkp::ShSet *)((char *)ws->small.p + 700 * 1024);
+
   Fr *zs = ws->misc.fr() + 20 * n;   // [ns][n]
   Fr *hq = ws->misc.fr() + 28 * n;   // [n]
   Fr *Wq = ws->misc.fr() + 29 * n;   // [n]
   Fr *dinv = ws->misc.fr() + 30 * n; // [n]
-  CK(up(ctx, ws, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
+  STAGE(sets_dev, zkp::ShSet, ws, shsets.data(), ns * sizeof(zkp::ShSet));
+  CK(flush_staged(ctx, ws));
   zkp::k_sh_zs<<<grid_for(ctx, ns * n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, dom->fwd, n, zs);
   ZK_LAUNCH_CHECK(ctx);
   CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)zs, ns * n));
   zkp::k_sh_h<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, zs, dom->fwd, n, hq);
   ZK_LAUNCH_CHECK(ctx);
   std::vector<AffinePoint> hq_commit, w_commit;
-  CK(commit_cols(ctx, srs, srs->g_lagrange, hq, 1, (G1Affine *)ws->points.p, hq_commit));
+  CK(commit_cols_out(ctx, srs, srs->g_lagrange, hq, 1, ws, hq_commit));
   tr.write_point(hq_commit[0]);
   const Fr uu = mont(tr.squeeze());
   {
@@ -1107,14 +1111,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       shsets[j].r_u = ru;
     }
     ztu = ztu * z0_diff_inv;
-    CK(up(ctx, ws, sets_dev, shsets.data(), ns * sizeof(zkp::ShSet)));
+    STAGE(sets2_dev, zkp::ShSet, ws, shsets.data(), ns * sizeof(zkp::ShSet));
+    CK(flush_staged(ctx, ws));
     zkp::k_sh_den<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(dom->fwd, uu, n, dinv);
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)dinv, n));
-    zkp::k_sh_w<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets_dev, (unsigned)ns, F, hq, ztu, dinv, n, Wq);
+    zkp::k_sh_w<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(sets2_dev, (unsigned)ns, F, hq, ztu, dinv, n, Wq);
     ZK_LAUNCH_CHECK(ctx);
   }
-  CK(commit_cols(ctx, srs, srs->g_lagrange, Wq, 1, (G1Affine *)ws->points.p, w_commit));
+  CK(commit_cols_out(ctx, srs, srs->g_lagrange, Wq, 1, ws, w_commit));
   tr.write_point(w_commit[0]);
   proof = tr.out;
   const double t_end = now_ms();

@@ -94,6 +94,18 @@ struct Workspace {
   uint8_t *ring = nullptr;      // pinned bump arena for the small tables of one proof: uploads from it need no host wait
   size_t ring_off = 0;
   static constexpr size_t RING_BYTES = (size_t)4 << 20;
+  // device mirror of the ring: stage() places a table in the ring and returns its address in the mirror, flush_staged() moves
+  // everything staged since the last flush with ONE copy (a Fiat-Shamir round has a dozen small tables: expression groups,
+  // powers, pointer / scalar lists, rotation sets ...)
+  DevBuf dev_ring;
+  size_t ring_flushed = 0;
+  // results that the host reads (commitments, evaluations, check flags) are WRITTEN by the kernels into this pinned,
+  // device-visible block -- no device-to-host copy commands: [points | evaluations | flags]
+  uint8_t *host_out = nullptr;
+  size_t out_pts_cap = 0, out_ev_off = 0, out_ev_cap = 0, out_flag_off = 0;
+  G1Affine *out_pts() const { return (G1Affine *)host_out; }
+  U256 *out_ev() const { return (U256 *)(host_out + out_ev_off); }
+  int *out_flags() const { return (int *)(host_out + out_flag_off); }   // [0] permutation closes, [1] lookups close, [2] lookup input in table
   G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
   hipEvent_t ev_pts = nullptr;
   // the random polynomial of the vanishing argument depends on no challenge: it is uploaded and committed at the start of
@@ -108,7 +120,7 @@ struct Workspace {
   DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
   std::vector<DevBuf *> all() {
-    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio, &stream, &pool, &invtmp, &wblind};
+    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio, &stream, &pool, &invtmp, &wblind, &dev_ring};
   }
 };
 
@@ -163,6 +175,31 @@ static inline int upload_canon(zkfhe_ctx *ctx, Fr *dst, const U256 *src, size_t 
 // arena and copied without waiting -- the arena is only recycled at the start of the next proof, after a stream sync.
 
 
+// A small host table of the proof in flight -> device: copied into the pinned ring now, visible on the device (at the returned
+// address) after the next flush_staged().  nullptr when the ring is full.
+static inline void *stage_table(Workspace *ws, const void *src, size_t bytes) {
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (!ws->ring || !ws->dev_ring.p || ws->ring_off + need > Workspace::RING_BYTES) return nullptr;
+  uint8_t *slot = ws->ring + ws->ring_off;
+  memcpy(slot, src, bytes);
+  void *dev = (char *)ws->dev_ring.p + ws->ring_off;
+  ws->ring_off += need;
+  return dev;
+}
+static inline int flush_staged(zkfhe_ctx *ctx, Workspace *ws) {
+  if (ws->ring_off > ws->ring_flushed) {
+    ZK_HIP(ctx, hipMemcpyAsync((char *)ws->dev_ring.p + ws->ring_flushed, ws->ring + ws->ring_flushed, ws->ring_off - ws->ring_flushed, hipMemcpyHostToDevice, ctx->stream));
+    ws->ring_flushed = ws->ring_off;
+  }
+  return ZKFHE_OK;
+}
+#define STAGE(var, type, ws, src, bytes)                                                             \
+  type *var = (type *)::stage_table((ws), (src), (bytes));                                                   \
+  if (!var) return zk_fail_msg(ctx, ZKFHE_ENOMEM, "the proof's small tables do not fit the staging ring")
+
+// commit `n_cols` columns straight into the pinned result block (the last MSM kernel stores its affine points there) and wait
+static inline int commit_cols_out(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, Workspace *ws, std::vector<AffinePoint> &out);
+
 // commit `n_cols` columns (device, Montgomery) and return canonical affine points
 static inline int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
   CK(srs_msm(ctx, srs, basis, cols, n_cols, dev_out));
@@ -170,6 +207,15 @@ static inline int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_
   CK(zkfhe_download(ctx, h.data(), dev_out, n_cols * sizeof(G1Affine)));
   out.resize(n_cols);
   for (size_t i = 0; i < n_cols; ++i) out[i] = point_canon(h[i]);
+  return ZKFHE_OK;
+}
+
+static inline int commit_cols_out(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, Workspace *ws, std::vector<AffinePoint> &out) {
+  if (!ws->host_out || n_cols > ws->out_pts_cap) return commit_cols(ctx, srs, basis, cols, n_cols, (G1Affine *)ws->points.p, out);
+  CK(srs_msm(ctx, srs, basis, cols, n_cols, ws->out_pts()));
+  ZK_HIP(ctx, zk_wait(ctx));
+  out.resize(n_cols);
+  for (size_t i = 0; i < n_cols; ++i) out[i] = point_canon(ws->out_pts()[i]);
   return ZKFHE_OK;
 }
 

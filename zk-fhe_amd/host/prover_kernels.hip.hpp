@@ -210,6 +210,46 @@ static __global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__rest
   }
   if (threadIdx.x == 1023) total[col] = sh[1023];
 }
+// Chunk carries of the permutation argument on the device (was: download the totals, multiply on the host, upload):
+// carry[j] = prod_{i < j} total[i] in place, *closes = (the product of all of them == 1).  With check_ones every total itself
+// has to be one (the lookup products) and the array is left alone.  One workgroup of 1024 threads; count <= 4096.
+static __global__ void __launch_bounds__(1024) k_chunk_carry(Fr *__restrict__ total, unsigned count, int check_ones, int *__restrict__ closes) {
+  __shared__ Fr sh[1024];
+  __shared__ int bad;
+  const unsigned t = threadIdx.x;
+  if (t == 0) bad = 0;
+  __syncthreads();
+  const unsigned per = (count + 1023) / 1024, lo = t * per;
+  if (check_ones) {
+    const Fr one = Fr::one();
+    for (unsigned k = 0; k < per; ++k)
+      if (lo + k < count && !(total[lo + k] == one)) bad = 1;
+    __syncthreads();
+    if (t == 0) *closes = bad ? 0 : 1;
+    return;
+  }
+  Fr vals[4];
+  Fr local = Fr::one();
+  for (unsigned k = 0; k < per; ++k) {
+    vals[k] = lo + k < count ? total[lo + k] : Fr::one();
+    local = local * vals[k];
+  }
+  sh[t] = local;
+  __syncthreads();
+  for (unsigned d = 1; d < 1024; d <<= 1) {
+    const Fr v = sh[t];
+    const Fr other = t >= d ? sh[t - d] : Fr::one();
+    __syncthreads();
+    if (t >= d) sh[t] = other * v;
+    __syncthreads();
+  }
+  Fr acc = t ? sh[t - 1] : Fr::one();
+  for (unsigned k = 0; k < per; ++k) {
+    if (lo + k < count) total[lo + k] = acc;
+    acc = acc * vals[k];
+  }
+  if (t == 1023) *closes = (sh[1023] == Fr::one()) ? 1 : 0;
+}
 // z[col][0..u] *= carry[col]
 static __global__ void __launch_bounds__(256) k_scale_rows(Fr *__restrict__ z, const Fr *__restrict__ carry, size_t n, unsigned rows, unsigned n_cols) {
   const size_t total = (size_t)n_cols * rows;
