@@ -127,6 +127,12 @@ def _circuit(which):
         inp = json.dumps(synth_input(8, prm.Q, prm.T, prm.B, 1))
         cfg = zk.bfv_auto_config(inp, (8, prm.Q, prm.T, prm.B), 9, unusable_rows=9)
         return inp, inp, (8, prm.Q, prm.T, prm.B), cfg, 9
+    if which == "k14":   # rows longer than one NTT tile: the long-row transforms on every rank's column share
+        from tests.test_proof_oracle import synth_input
+        prm = C.BfvParams(N=16)
+        inp = json.dumps(synth_input(16, prm.Q, prm.T, prm.B, 5))
+        cfg = zk.bfv_auto_config(inp, (16, prm.Q, prm.T, prm.B), 14, unusable_rows=109)
+        return inp, inp, (16, prm.Q, prm.T, prm.B), cfg, 14
     prm = C.BfvParams()
     cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
     return (open(os.path.join(G, "bfv_empty.in")).read(), open(os.path.join(G, "bfv.in")).read(), (1024, prm.Q, prm.T, prm.B),
@@ -184,14 +190,16 @@ def _run_ranks(target, world, *args, timeout=900):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,world", [("toy", 2), ("bfv13", 2), ("bfv13", 4)])
+@pytest.mark.parametrize("which,world", [("toy", 2), ("toy", 3), ("bfv13", 2), ("bfv13", 4), ("k14", 2)])
 def test_sharded_prover_ranks_share_one_gpu_same_bytes(which, world):
     """zkfhe_srs_create_sharded + zkfhe_bfv_keygen / zkfhe_bfv_prove over a W-rank communicator: every commitment is the sum of
-    W point-range partials gathered across processes; verifying key and proof must equal the single-GPU ones.  "bfv13" is the
+    W point-range partials gathered across processes, and the coset extension + quotient are sharded by column (each rank
+    extends and evaluates only the columns of its permutation chunks; the W partial quotients are gathered and summed);
+    verifying key and proof must equal the single-GPU ones.  Three ranks: ragged chunk ranges.  "bfv13" is the
     reference's bfv.in at k = 13: each rank's SRS slice takes the digit-multiple table path (k_msm_table) with its own,
     wider digits (a slice of 2^13 / W points fits more bits into the same budget than the whole basis)."""
     got = _run_ranks(_sharded_worker, world, which)
-    n = 512 if which == "toy" else 8192
+    n = {"toy": 512, "bfv13": 8192, "k14": 16384}[which]
     assert [g["range"] for g in got] == [(n * r // world, n * (r + 1) // world) for r in range(world)]
     for g in got[1:]:
         assert g["proof"] == got[0]["proof"] and g["inst"] == got[0]["inst"] and g["vk"] == got[0]["vk"]   # all ranks hold the same proof

@@ -783,23 +783,64 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // (Extending the challenge-independent columns -- 264 of 402 -- right after the early commitment, on the main or on the
   // auxiliary stream, was measured and dropped: 165-172 proofs/s on a wave of 20 against 172-177 without, 185-192 in steady
   // state against 192-203; the smaller NTT batches and the extra launches cost more than the idle time they fill.)
-  CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr()));
+  // One proof over several GPUs (srs->sharded()): besides the commitments (point ranges, comm.hip) the extension to the coset
+  // domain and the quotient are sharded BY COLUMN.  Rank r owns the permutation chunks [nch r / W, nch (r+1) / W), hence the
+  // advice columns of those chunks, their gates / RLC gates / lookups and the chunks' permutation terms; it extends only those
+  // columns (plus the grand product of the chunk before its first one, which the chaining term reads), evaluates only the
+  // expression groups that belong to them, and the W partial quotients (rows * n values each) are all-gathered and summed on
+  // every rank.  With W = 1 everything is owned: the same code.
+  const unsigned W_sh = srs->sharded() ? (unsigned)zkfhe_comm_world(srs->comm) : 1u, r_sh = srs->sharded() ? (unsigned)zkfhe_comm_rank(srs->comm) : 0u;
+  const size_t c_lo = nch * r_sh / W_sh, c_hi = nch * (r_sh + 1) / W_sh;
+  auto owns_chunk = [&](size_t j) { return j >= c_lo && j < c_hi; };
+  auto owns_col = [&](size_t perm_col) { return owns_chunk(perm_col / cfg.chunk()); };
+  if (W_sh == 1) {
+    CK(extend_cols(ctx, pk, ws, ws->all_l.fr(), ws->n_all, ws->all_ext.fr()));
+  } else {
+    const size_t ecol = n * (size_t)q_rows;
+    auto ext_range = [&](const View &l, const View &e, size_t lo, size_t hi) -> int {
+      if (hi <= lo) return ZKFHE_OK;
+      return extend_cols(ctx, pk, ws, l.fr() + lo * n, hi - lo, e.fr() + lo * ecol);
+    };
+    const size_t a_lo = std::min<size_t>(c_lo * cfg.chunk(), cfg.n_advice()), a_hi = std::min<size_t>(c_hi * cfg.chunk(), cfg.n_advice());
+    CK(ext_range(ws->adv_l, ws->adv_ext, a_lo, a_hi));
+    const size_t l_lo = a_lo > cfg.adv_lookup0() ? std::min<size_t>(a_lo - cfg.adv_lookup0(), cfg.n_lookup) : 0;
+    const size_t l_hi = a_hi > cfg.adv_lookup0() ? std::min<size_t>(a_hi - cfg.adv_lookup0(), cfg.n_lookup) : 0;
+    CK(ext_range(ws->la_l, ws->la_ext, l_lo, l_hi));
+    CK(ext_range(ws->ls_l, ws->ls_ext, l_lo, l_hi));
+    CK(ext_range(ws->lz_l, ws->lz_ext, l_lo, l_hi));
+    CK(ext_range(ws->pz_l, ws->pz_ext, c_lo ? c_lo - 1 : 0, c_hi));
+    if (owns_col(cfg.perm_inst())) CK(ext_range(ws->inst_l, ws->inst_ext, 0, 1));
+  }
   {
-    // expression groups, in the folding order of oracle/halo2_ref.py expressions_at
+    // expression groups, in the folding order of oracle/halo2_ref.py expressions_at: the expressions are numbered globally (the
+    // power of y of a group is fixed by the number of its last expression); a group is a run of owned, consecutive units of one
+    // kind, cut at the kernel's group sizes
     std::vector<zkp::QGroup> groups;
     std::vector<size_t> last_e;  // global index of the last expression of each group
     size_t e = 0;
-    auto push = [&](int type, int first, int count, size_t n_expr) {
-      groups.push_back(zkp::QGroup{type, first, count, 0});
-      e += n_expr;
-      last_e.push_back(e - 1);
+    auto run = [&](int type, size_t first, size_t count, size_t max_group, size_t expr_per_unit, const std::function<bool(size_t)> &owned) {
+      size_t j = first;
+      while (j < first + count) {
+        if (!owned(j)) {
+          e += expr_per_unit;
+          ++j;
+          continue;
+        }
+        size_t len = 0;
+        while (j + len < first + count && len < max_group && owned(j + len)) ++len;
+        groups.push_back(zkp::QGroup{type, (int)j, (int)len, 0});
+        e += len * expr_per_unit;
+        last_e.push_back(e - 1);
+        j += len;
+      }
     };
-    for (unsigned j = 0; j < cfg.n_gate(); j += 8) push(zkp::QG_GATE, (int)j, (int)std::min(8u, cfg.n_gate() - j), std::min(8u, cfg.n_gate() - j));
-    if (cfg.n_rlc) push(zkp::QG_RLC, 0, (int)cfg.n_rlc, cfg.n_rlc);
-    push(zkp::QG_PERM_HEAD, 0, 2, 2);
-    for (unsigned j = 1; j < nch; j += 32) push(zkp::QG_PERM_C, (int)j, (int)std::min<size_t>(32, nch - j), std::min<size_t>(32, nch - j));
-    for (unsigned j = 0; j < nch; j += 4) push(zkp::QG_PERM_D, (int)j, (int)std::min<size_t>(4, nch - j), std::min<size_t>(4, nch - j));
-    for (unsigned i = 0; i < cfg.n_lookup; i += 3) push(zkp::QG_LOOKUP, (int)i, (int)std::min(3u, cfg.n_lookup - i), 5 * std::min(3u, cfg.n_lookup - i));
+    run(zkp::QG_GATE, 0, cfg.n_gate(), 8, 1, [&](size_t j) { return owns_col(j); });
+    run(zkp::QG_RLC, 0, cfg.n_rlc, cfg.n_rlc ? cfg.n_rlc : 1, 1, [&](size_t j) { return owns_col(cfg.adv_rlc0() + j); });
+    run(zkp::QG_PERM_FIRST, 0, 1, 1, 1, [&](size_t) { return owns_chunk(0); });
+    run(zkp::QG_PERM_LAST, 0, 1, 1, 1, [&](size_t) { return owns_chunk(nch - 1); });
+    run(zkp::QG_PERM_C, 1, nch - 1, 32, 1, [&](size_t j) { return owns_chunk(j); });
+    run(zkp::QG_PERM_D, 0, nch, 4, 1, [&](size_t j) { return owns_chunk(j); });
+    run(zkp::QG_LOOKUP, 0, cfg.n_lookup, 3, 5, [&](size_t i) { return owns_col(cfg.adv_lookup0() + i); });
     const size_t E = e, G = groups.size();
     if (G > 96) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
     std::vector<Fr> ypow(G);
@@ -853,6 +894,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_LAUNCH_CHECK(ctx);
     zkp::k_quotient_combine<<<(unsigned)((npts + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, ws->h_ext.fr());
     ZK_LAUNCH_CHECK(ctx);
+    if (W_sh > 1) {
+      // h_ext holds this rank's share of the quotient (the sum over ITS expression groups): gather the W shares (the group
+      // partials are dead, their buffer receives them) and add them up -- field addition is not an RCCL reduction either
+      if ((size_t)W_sh * npts * 32 > ws->partials.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many ranks for the quotient gather buffer");
+      CK(zkfhe_comm_all_gather(ctx, srs->comm, ws->h_ext.p, ws->partials.p, npts * 32));
+      zkp::k_sum_rows<<<grid_for(ctx, npts), 256, 0, ctx->stream>>>(ws->partials.fr(), W_sh, npts, ws->h_ext.fr());
+      ZK_LAUNCH_CHECK(ctx);
+    }
     const Fr g = mont_u64(COSET_G);
     if (q_rows == 4) {
       CK(zkfhe_coset_ntt_batch(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)ws->h_c.p, 1, (int)k, 2, (const zkfhe_fr *)&g, 1));

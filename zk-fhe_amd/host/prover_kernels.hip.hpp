@@ -262,7 +262,7 @@ static __global__ void __launch_bounds__(256) k_scale_rows(Fr *__restrict__ z, c
 }
 
 // ------------------------------------------------------------------------------------------- quotient
-enum { QG_GATE = 0, QG_RLC = 1, QG_PERM_HEAD = 2, QG_PERM_C = 3, QG_PERM_D = 4, QG_LOOKUP = 5 };
+enum { QG_GATE = 0, QG_RLC = 1, QG_PERM_HEAD = 2, QG_PERM_C = 3, QG_PERM_D = 4, QG_LOOKUP = 5, QG_PERM_FIRST = 6, QG_PERM_LAST = 7 };
 struct QGroup {
   int type, first, count, pad;
 };
@@ -308,6 +308,14 @@ static __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
       const Fr z0 = at(a.pz, 0, 0), zm = at(a.pz, a.n_chunks - 1, 0);
       acc = l0 * (one - z0);
       horner(ll, zm * zm - zm);
+      break;
+    }
+    case QG_PERM_FIRST:   // the two expressions of QG_PERM_HEAD as groups of their own (they belong to different ranks when the
+      acc = a.lext[p] * (one - at(a.pz, 0, 0));   // quotient is sharded by column)
+      break;
+    case QG_PERM_LAST: {
+      const Fr zm = at(a.pz, a.n_chunks - 1, 0);
+      acc = a.lext[ne + p] * (zm * zm - zm);
       break;
     }
     case QG_PERM_C: {
