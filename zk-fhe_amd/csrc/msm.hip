@@ -678,36 +678,29 @@ __device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [128] */) {
 // as it is -- 256 partials per visit and no butterfly (eight dependent point additions with most lanes idle cost as much as
 // eleven useful ones), and no point-addition code besides the loop's in the kernel: 160 registers, three waves per SIMD,
 // nothing spilled.  k_msm_table_fold sums the lists.
-// A draw takes one chunk, or TABLE_GMAX chunks at once after a chunk that turned out sparse (at most two non-zero digits per
-// scalar: witness columns of 0/1 cells and 8-bit limbs -- 0.5 to 3 digits against the 20 of a full-width scalar): the scalars of
-// the drawn chunks are loaded and taken apart side by side (four independent loads and Montgomery reductions per thread), one
-// prefix sum and one entry list serve all of them, and the additions run four times as long between two list builds.  A
-// sparse chunk used to cost 40 us of load / reduce / scan / gather latency for 5 us of additions.
-constexpr unsigned TABLE_GMAX = 4;
 template <bool TREE>
 __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__restrict__ scalars, size_t col_stride, size_t n, const G1Affine *__restrict__ T, int c, int W, BiasArg B,
                                                    unsigned P, unsigned cpc /* chunks per column */, unsigned n_cols, unsigned max_part,
                                                    G1X *__restrict__ partials /* [n_cols][max_part][TREE ? 1 : 256] */,
                                                    unsigned *__restrict__ n_part /* [n_cols] visits recorded, zero on entry */,
                                                    unsigned *__restrict__ col_next /* [n_cols] next chunk, zero on entry */,
-                                                   unsigned *__restrict__ lists /* [gridDim.x][TABLE_GMAX * P * W] */, unsigned long long *__restrict__ adds) {
+                                                   unsigned *__restrict__ lists /* [gridDim.x][P * W] */, unsigned long long *__restrict__ adds) {
   // the entry list of the chunk in flight: in global memory (written and read by this workgroup only: it stays in this CU's
   // L1 / this XCD's L2), not in LDS -- with no LDS to its name the kernel shares a CU with the NTT tile kernel (147 KB of the
   // 160), whose waves wait on LDS while these issue multiply-adds
-  unsigned *__restrict__ lst = lists + (size_t)blockIdx.x * TABLE_GMAX * P * (unsigned)W;
+  unsigned *__restrict__ lst = lists + (size_t)blockIdx.x * P * (unsigned)W;
   __shared__ G1X sh[TREE ? 128 : 1];
   __shared__ unsigned wave_cnt[4], item_sh;
   const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int half = 1 << (c - 1);
   G1X29 acc = G1X29::identity();
-  unsigned col = (unsigned)(((unsigned long long)blockIdx.x * n_cols) / gridDim.x), done = 0, total = 0, g = 1;
+  unsigned col = (unsigned)(((unsigned long long)blockIdx.x * n_cols) / gridDim.x), done = 0, total = 0;
   for (;;) {
     __syncthreads();   // the previous chunk's list is consumed
-    if (threadIdx.x == 0) item_sh = atomicAdd(&col_next[col], g);   // may overshoot cpc by up to g - 1: readers compare with cpc
+    if (threadIdx.x == 0) item_sh = atomicAdd(&col_next[col], 1u);
     __syncthreads();
     const unsigned chunk = item_sh;
     if (chunk >= cpc) {
-      g = 1;
       // this column has no chunks left: hand over what was summed, then look for the next column that has some
       if (done) {
         if (TREE) acc = block_sum_256(acc, sh);
@@ -740,27 +733,21 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
       col = found & 4095u;
       continue;
     }
-    const unsigned got = min(g, cpc - chunk);   // chunks of this draw
-    done += got;
+    ++done;
     {
-      // first the digit masks of every drawn chunk (only those stay live: the biased scalars are formed again below -- a
-      // Montgomery reduction per scalar, against ten products per addition -- instead of holding four of them in registers)
-      unsigned long long mask[TABLE_GMAX];
-      unsigned mine = 0;
-#pragma unroll
-      for (unsigned j = 0; j < TABLE_GMAX; ++j) {
-        mask[j] = 0;
-        const size_t i = (size_t)(chunk + j) * P + threadIdx.x;
-        if (j < got && threadIdx.x < P && i < n) {
-          u32 sb[9];
-          int bits;
-          (void)biased_scalar(scalars[(size_t)col * col_stride + i], B, sb, bits);
-          const int wtop = min(W, bits / c + 2);
-          for (int w = 0; w < wtop; ++w)
-            if ((int)bits_at(sb, w * c, c) != half) mask[j] |= 1ull << w;
-        }
-        mine += (unsigned)__popcll(mask[j]);
+      const size_t i = (size_t)chunk * P + threadIdx.x;
+      const bool valid = threadIdx.x < P && i < n;
+      u32 sb[9];
+      bool neg = false;
+      unsigned long long mask = 0;
+      if (valid) {
+        int bits;
+        neg = biased_scalar(scalars[(size_t)col * col_stride + i], B, sb, bits);
+        const int wtop = min(W, bits / c + 2);
+        for (int w = 0; w < wtop; ++w)
+          if ((int)bits_at(sb, w * c, c) != half) mask |= 1ull << w;
       }
+      const unsigned mine = (unsigned)__popcll(mask);
       unsigned incl = mine;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -771,27 +758,17 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
       __syncthreads();
       unsigned off = incl - mine;
       for (unsigned v = 0; v < wv; ++v) off += wave_cnt[v];
-#pragma unroll
-      for (unsigned j = 0; j < TABLE_GMAX; ++j) {
-        unsigned long long mk = mask[j];
-        if (!mk) continue;
-        const size_t i = (size_t)(chunk + j) * P + threadIdx.x;
-        const unsigned row0 = (unsigned)i * (unsigned)W;
-        u32 sb[9];
-        int bits;
-        const bool neg = biased_scalar(scalars[(size_t)col * col_stride + i], B, sb, bits);
-        while (mk) {
-          const int w = __builtin_ctzll(mk);
-          mk &= mk - 1;
-          const int d = (int)bits_at(sb, w * c, c) - half;
-          lst[off++] = (((row0 + (unsigned)w) << (c - 1)) + (unsigned)(d < 0 ? -d : d) - 1u) | ((neg != (d < 0)) ? 0x80000000u : 0u);
-        }
+      const unsigned row0 = (unsigned)i * (unsigned)W;
+      while (mask) {
+        const int w = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int d = (int)bits_at(sb, w * c, c) - half;
+        lst[off++] = (((row0 + (unsigned)w) << (c - 1)) + (unsigned)(d < 0 ? -d : d) - 1u) | ((neg != (d < 0)) ? 0x80000000u : 0u);
       }
     }
     __syncthreads();
     const unsigned M = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     total += M;
-    g = (M <= 2u * P * got) ? TABLE_GMAX : 1u;   // sparse: draw four chunks next time
     // software pipeline: the entry two steps ahead and the table point one step ahead are in flight during an addition
     unsigned e = threadIdx.x, en = 0, en2 = 0;
     G1Affine p;
@@ -956,7 +933,7 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
   void *p0, *p1;
   int rc = zk_scratch(ctx, 0, n_cols * max_part * L * sizeof(G1X), &p0);
   if (rc) return rc;
-  rc = zk_scratch(ctx, 1, grid * TABLE_GMAX * P * (size_t)W * 4, &p1);
+  rc = zk_scratch(ctx, 1, grid * P * (size_t)W * 4, &p1);
   if (rc) return rc;
   const bool big = n_cols * n > ((size_t)1 << 16);
   const int slot = big ? 0 : 2;
