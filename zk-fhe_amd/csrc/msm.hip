@@ -793,20 +793,55 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
   if (adds && threadIdx.x == 0 && total) atomicAdd(adds, (unsigned long long)total);
 }
 
-// out[col] = sum of the column's partial list (n_part[col] * L entries), normalised; the counters go back to zero
-__global__ void __launch_bounds__(256) k_msm_table_fold(const G1X *__restrict__ partials, unsigned max_part, unsigned L, unsigned *__restrict__ n_part,
+// out[col] = sum of the column's partial list (n_part[col] * L entries), normalised; the counters go back to zero.
+// 512 threads: with L = 256 (one accumulator per thread and visit) the two halves of the workgroup take the even and the odd
+// visits -- a column of the wide calls collects 25 to 30 visits (every workgroup that drew a chunk of it), and the visits are
+// the sequential part of this kernel: visits / 2 + 9 dependent point additions instead of visits + 8.  The next partial is in
+// flight during an addition.
+__global__ void __launch_bounds__(512) k_msm_table_fold(const G1X *__restrict__ partials, unsigned max_part, unsigned L, unsigned *__restrict__ n_part,
                                                         unsigned *__restrict__ col_next, G1Affine *__restrict__ out) {
-  __shared__ G1X sh[128];
-  const unsigned col = blockIdx.x;
+  __shared__ G1X sh[256];
+  const unsigned col = blockIdx.x, t = threadIdx.x & 255u, q = threadIdx.x >> 8;
   const unsigned np = n_part[col] * L;
   const G1X *mine = partials + (size_t)col * max_part * L;
   G1X29 f = G1X29::identity();
-  for (unsigned b = threadIdx.x; b < np; b += 256) g1x29_add(f, g1x29_load(mine[b]));
-  f = block_sum_256(f, sh);
-  if (threadIdx.x == 0) {
-    out[col] = g1x_to_affine(g1x29_to_std(f));
-    n_part[col] = 0;
-    col_next[col] = 0;
+  {
+    // L = 256: entry v * 256 + t, v = q, q + 2, ...; L = 1: entries threadIdx.x, threadIdx.x + 512, ...
+    const unsigned first = L == 256 ? q * 256u + t : threadIdx.x, step = 512u;
+    unsigned b = first;
+    G1X cur;
+    if (b < np) cur = mine[b];
+    while (b < np) {
+      const unsigned nb = b + step;
+      G1X nxt;
+      if (nb < np) nxt = mine[nb];
+      g1x29_add(f, g1x29_load(cur));
+      cur = nxt;
+      b = nb;
+    }
+  }
+  // 512 -> 256 -> 128 -> 64 through LDS, then a butterfly in the first wave
+  if (q == 1) sh[t] = g1x29_store(f);
+  __syncthreads();
+  if (q == 0) g1x29_add(f, g1x29_load(sh[t]));
+  __syncthreads();
+  if (q == 0 && t >= 128) sh[t - 128] = g1x29_store(f);
+  __syncthreads();
+  if (q == 0 && t < 128) g1x29_add(f, g1x29_load(sh[t]));
+  __syncthreads();
+  if (q == 0 && t >= 64 && t < 128) sh[t - 64] = g1x29_store(f);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    g1x29_add(f, g1x29_load(sh[t]));
+    for (int m = 1; m < 64; m <<= 1) {
+      const G1X29 other = g1x_shfl_xor(f, m);
+      g1x29_add(f, other);
+    }
+    if (threadIdx.x == 0) {
+      out[col] = g1x_to_affine(g1x29_to_std(f));
+      n_part[col] = 0;
+      col_next[col] = 0;
+    }
   }
 }
 
@@ -947,7 +982,7 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
                                                               (unsigned)max_part, (G1X *)p0, n_part, col_next, (unsigned *)p1, ctx->prof_on ? adds : nullptr);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, slot, 96.0 * (double)n * (double)n_cols);
-  k_msm_table_fold<<<(unsigned)n_cols, 256, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
+  k_msm_table_fold<<<(unsigned)n_cols, 512, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
   ZK_LAUNCH_CHECK(ctx);
   if (ctx->prof_on) {
     unsigned long long h = 0;

@@ -42,7 +42,7 @@ namespace {
 
 // one radix-2 DIF stage over vectors of length n (all columns): pairs (j, j+half) inside blocks of 2*half
 //   a' = a + b ; b' = (a - b) * omega_n^(j * n/(2*half)),  j = index inside the half
-__global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t n_cols, int log_n, int log_half,
+__global__ void __launch_bounds__(256) k_dif_stage(const Fr *src, Fr *data, size_t n_cols, int log_n, int log_half,
                                                    const Fr *__restrict__ tw_n /* omega_n^j, j < n/2, 2^261 form */) {
   const size_t half = (size_t)1 << log_half;
   const size_t per_col = (size_t)1 << (log_n - 1);
@@ -52,8 +52,9 @@ __global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t
     const size_t i = g & (per_col - 1);
     const size_t j = i & (half - 1);
     const size_t blk = i >> log_half;
-    Fr *p = data + (c << log_n) + (blk << (log_half + 1)) + j;
-    Fr x = p[0], y = p[half];
+    const size_t o = (c << log_n) + (blk << (log_half + 1)) + j;
+    Fr *p = data + o;
+    Fr x = src[o], y = src[o + half];   // src == data: in place
     Fr s = x + y, d = x - y;
     const size_t e = j << (log_n - 1 - log_half);
     p[0] = s;
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) k_dif_stage(Fr *__restrict__ data, size_t
 // 2^S elements base + m * 2^(log_half - S + 1) of one block of 2^(log_half + 1) and runs the S butterfly levels in
 // registers.  Long rows (k = 16 .. 19) used to make one full read+write of every column per stage.
 template <int S>
-__global__ void __launch_bounds__(256) k_dif_fused(Fr *__restrict__ data, size_t n_cols, int log_n, int log_half, const Fr *__restrict__ tw_n) {
+__global__ void __launch_bounds__(256) k_dif_fused(const Fr *src, Fr *data, size_t n_cols, int log_n, int log_half, const Fr *__restrict__ tw_n) {
   constexpr int R = 1 << S;
   const int log_q = log_half - S + 1;            // distance between the elements of a thread
   const size_t q = (size_t)1 << log_q;
@@ -76,10 +77,12 @@ __global__ void __launch_bounds__(256) k_dif_fused(Fr *__restrict__ data, size_t
     const size_t i = g & (per_col - 1);
     const size_t j0 = i & (q - 1);
     const size_t blk = i >> log_q;
-    Fr *p = data + (c << log_n) + (blk << (log_half + 1)) + j0;
+    const size_t o = (c << log_n) + (blk << (log_half + 1)) + j0;
+    Fr *p = data + o;
+    const Fr *ps = src + o;   // src == data: in place; otherwise the first pass of an out-of-place transform
     Fr x[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) x[m] = p[(size_t)m << log_q];
+    for (int m = 0; m < R; ++m) x[m] = ps[(size_t)m << log_q];
 #pragma unroll
     for (int t = 0; t < S; ++t) {
       constexpr int dummy = 0;
@@ -272,7 +275,7 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
     // n = 2: one stage is the whole transform (bitrev of 1 bit is identity).  n = 4: outputs 1 and 2 swapped.
     const Fr *tw = inverse ? dom->inv29 : dom->fwd29;
     for (int s = log_n - 1; s >= 0; --s) {
-      k_dif_stage<<<zk_blocks(n_cols * (n / 2), 256), 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+      k_dif_stage<<<zk_blocks(n_cols * (n / 2), 256), 256, 0, ctx->stream>>>(data, data, n_cols, log_n, s, tw);
       ZK_LAUNCH_CHECK(ctx);
     }
     if (log_n == 2 || inverse) {
@@ -320,35 +323,36 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
     }
     return launch_tile_dyn(ctx, log_n, a, 1, (unsigned)n_cols);
   }
-  if (src) {
-    rc = zk_copy_d2d(ctx, data, src, n_cols * n * sizeof(Fr));
-    if (rc) return rc;
-  }
-  // large: DIF stages down to 2^13 blocks, then tile NTT per block with bit-reversed strided scatter
+  // large: DIF stages down to 2^13 blocks, then tile NTT per block with bit-reversed strided scatter.
+  // Out of place (src given): the first pass reads src and writes the scratch arena, the later passes run in place there and the
+  // tile kernel scatters into the destination -- no copy anywhere.  In place: passes on the data, tiles into scratch, one copy back.
+  void *p;
+  rc = zk_scratch(ctx, 0, n_cols * n * sizeof(Fr), &p);
+  if (rc) return rc;
+  Fr *work = src ? (Fr *)p : data;
+  const Fr *pass_in = src ? src : data;
   const int log_tiles = log_n - MAX_TILE_LOG;
   const Fr *tw = inverse ? dom->inv29 : dom->fwd29;
   for (int s = log_n - 1; s >= MAX_TILE_LOG;) {
     const int left = s - MAX_TILE_LOG + 1;
     const int S = left >= 3 ? 3 : left;       // fuse up to three stages per pass over memory
-    size_t work = n_cols * (n >> S);
-    unsigned grid = zk_blocks(work, 256);
+    size_t wk = n_cols * (n >> S);
+    unsigned grid = zk_blocks(wk, 256);
     unsigned cap = (unsigned)ctx->num_cu * 16;
     if (grid > cap) grid = cap;
-    if (S == 3) k_dif_fused<3><<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
-    else if (S == 2) k_dif_fused<2><<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
-    else k_dif_stage<<<grid, 256, 0, ctx->stream>>>(data, n_cols, log_n, s, tw);
+    if (S == 3) k_dif_fused<3><<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw);
+    else if (S == 2) k_dif_fused<2><<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw);
+    else k_dif_stage<<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw);
     ZK_LAUNCH_CHECK(ctx);
+    pass_in = work;
     s -= S;
   }
   const NttDomain *tdom;
   rc = zk_domain(ctx, MAX_TILE_LOG, &tdom);
   if (rc) return rc;
-  void *p;
-  rc = zk_scratch(ctx, 0, n_cols * n * sizeof(Fr), &p);
-  if (rc) return rc;
   TileArgs a{};
-  a.in = data;
-  a.out = (Fr *)p;
+  a.in = work;
+  a.out = src ? data : (Fr *)p;
   a.in_tile_stride = (size_t)1 << MAX_TILE_LOG;
   a.col_stride_in = a.col_stride_out = n;
   a.tw = inverse ? tdom->inv29 : tdom->fwd29;
@@ -358,8 +362,10 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
   a.out_natural_tiles = 0;
   rc = launch_tile_dyn(ctx, MAX_TILE_LOG, a, 1u << log_tiles, (unsigned)n_cols);
   if (rc) return rc;
-  rc = zk_copy_d2d(ctx, data, p, n_cols * n * sizeof(Fr));
-  if (rc) return rc;
+  if (!src) {
+    rc = zk_copy_d2d(ctx, data, p, n_cols * n * sizeof(Fr));
+    if (rc) return rc;
+  }
   return ZKFHE_OK;
 }
 
@@ -396,9 +402,13 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
     unsigned gr = zk_blocks(n_cols * nr, 256);
     const unsigned capg = (unsigned)ctx->num_cu * 16;
     if (gr > capg) gr = capg;
-    k_coset_prescale<<<gr, 256, 0, ctx->stream>>>(in_dev, pre, out_dev, n_cols, log_n, rows);
+    // pre-scaled rows into a scratch arena, then one out-of-place transform of all of them into the destination
+    void *ps;
+    rc = zk_scratch(ctx, 2, n_cols * nr * sizeof(Fr), &ps);
+    if (rc) return rc;
+    k_coset_prescale<<<gr, 256, 0, ctx->stream>>>(in_dev, pre, (Fr *)ps, n_cols, log_n, rows);
     ZK_LAUNCH_CHECK(ctx);
-    return zkfhe_ntt_batch(ctx, (zkfhe_fr *)out_dev, n_cols * (size_t)rows, log_n, 0);
+    return zk_ntt_impl(ctx, (const zkfhe_fr *)ps, (zkfhe_fr *)out_dev, n_cols * (size_t)rows, log_n, 0);
   }
   TileArgs a{};
   a.in = in_dev;
@@ -423,9 +433,7 @@ extern "C++" int zk_extend_lagrange(zkfhe_ctx *ctx, const Fr *lagr_dev, Fr *tmp_
   if (!n_cols) return ZKFHE_OK;
   const size_t n = (size_t)1 << log_n;
   if (log_n != 13 || rows > (1 << lef)) {
-    int rc = zk_copy_d2d(ctx, tmp_dev, lagr_dev, n_cols * n * sizeof(Fr));
-    if (rc) return rc;
-    rc = zkfhe_ntt_batch(ctx, (zkfhe_fr *)tmp_dev, n_cols, log_n, 1);
+    int rc = zk_ntt_impl(ctx, (const zkfhe_fr *)lagr_dev, (zkfhe_fr *)tmp_dev, n_cols, log_n, 1);   // out of place: no copy
     if (rc) return rc;
     return zk_coset_ntt_rows(ctx, tmp_dev, out_dev, n_cols, log_n, lef, g, rows);
   }
@@ -503,9 +511,12 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
       unsigned gr = zk_blocks(n_cols * ne, 256);
       const unsigned capg = (unsigned)ctx->num_cu * 16;
       if (gr > capg) gr = capg;
-      k_coset_prescale<<<gr, 256, 0, ctx->stream>>>((const Fr *)in_dev, pre, (Fr *)out_dev, n_cols, log_n, E);
+      void *ps;
+      rc = zk_scratch(ctx, 2, n_cols * ne * sizeof(Fr), &ps);
+      if (rc) return rc;
+      k_coset_prescale<<<gr, 256, 0, ctx->stream>>>((const Fr *)in_dev, pre, (Fr *)ps, n_cols, log_n, E);
       ZK_LAUNCH_CHECK(ctx);
-      return zkfhe_ntt_batch(ctx, out_dev, n_cols * E, log_n, 0);
+      return zk_ntt_impl(ctx, (const zkfhe_fr *)ps, out_dev, n_cols * E, log_n, 0);
     }
     TileArgs a{};
     a.in = (const Fr *)in_dev;
@@ -525,16 +536,11 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
   }
   // inverse: rows iNTT (size n, scaled by n^-1) into scratch, then combine across k1
   if (log_n > MAX_TILE_LOG) {
-    // zkfhe_ntt_batch uses scratch slot 0 itself for long rows: stage the rows in the OUTPUT buffer, transform them
-    // there, then combine through slot 2
-    rc = zk_copy_d2d(ctx, out_dev, in_dev, n_cols * ne * sizeof(Fr));
-    if (rc) return rc;
-    rc = zkfhe_ntt_batch(ctx, out_dev, n_cols * E, log_n, 1);
-    if (rc) return rc;
+    // rows transformed out of place straight into scratch slot 2 (the transform's own work arena is slot 0), combined from there
     rc = zk_scratch(ctx, 2, n_cols * ne * sizeof(Fr), &p);
     if (rc) return rc;
     Fr *rows2 = (Fr *)p;
-    rc = zk_copy_d2d(ctx, rows2, out_dev, n_cols * ne * sizeof(Fr));
+    rc = zk_ntt_impl(ctx, in_dev, (zkfhe_fr *)rows2, n_cols * E, log_n, 1);
     if (rc) return rc;
     rc = zk_scratch(ctx, 1, ne * sizeof(Fr), &p);
     if (rc) return rc;
