@@ -184,7 +184,12 @@ def main():
 
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, rocprofv3 --pmc)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r2b_pmc_traffic.json")))["bytes_per_launch"] if (not big and table_wide) else None
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))["bytes_per_launch"] if (not big and table_wide) else None
+    except Exception:  # noqa: BLE001
+        pass
+    ntt_traffic = None
+    try:  # the same for the 2^13 NTT tile (second kernel of every configuration)
+        ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))["ntt13"] if not big else None
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
@@ -219,7 +224,9 @@ def main():
                        "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
                        "steady_state_proofs_per_s": steady,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
-                       "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 (different hardware)"},
+                       "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 -- DIFFERENT HARDWARE and a LARGER constraint system "
+                                           "(axiom-eth always configures a Keccak sub-circuit whose columns this prover does not have, DESIGN.md 6.1); "
+                                           "a batch rate against a single-proof latency: not a like-for-like speed-up"},
             "roofline": {"bound": "hbm", "kernel": msm_kernel, "table_digit_bits": table_bits, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
                          "launches_per_proof": msm["launches"] / 2,
@@ -229,7 +236,7 @@ def main():
                                      "unit": "G modmul/s", "frac": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G,
                                      "mixed_additions_per_proof": msm["ops"] / 2},
                          "msm_few_columns": {"avg_launch_ms": direct["total_ms"] / max(1, direct["launches"]), "launches_per_proof": direct["launches"] / 2},
-                         "ntt_tile": {"achieved": ntt_ach, "int_alu_frac": (ntt["ops"] / (ntt["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G) if ntt["launches"] else None, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
+                         "ntt_tile": {"kernel": "k_ntt13", "traffic": ntt_traffic, "achieved": ntt_ach, "int_alu_frac": (ntt["ops"] / (ntt["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G) if ntt["launches"] else None, "avg_launch_ms": ntt["total_ms"] / max(1, ntt["launches"]), "launches_per_proof": ntt["launches"] / 2}},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -199,7 +199,8 @@ typedef struct zkfhe_transcript zkfhe_transcript;
 int zkfhe_transcript_create(uint32_t kind, zkfhe_transcript **out);
 void zkfhe_transcript_destroy(zkfhe_transcript *t);
 /* scalars: canonical 32-byte little-endian Fr; points: canonical affine x || y (64 bytes, little-endian Fq each).
- * common_* only absorb; write_* also append the 32-byte encoding (compressed point / scalar) to the byte stream. */
+ * common_* only absorb; write_* also append the 32-byte encoding to the byte stream: a scalar as it is, a point as halo2curves'
+ * bn256 G1Affine::to_bytes -- x little-endian, (y & 1) << 6 in byte 31, the identity as 0x80 in byte 31 and zeros. */
 int zkfhe_transcript_common_scalar(zkfhe_transcript *t, const uint8_t s_le[32]);
 int zkfhe_transcript_write_scalar(zkfhe_transcript *t, const uint8_t s_le[32]);
 int zkfhe_transcript_common_point(zkfhe_transcript *t, const uint8_t xy_le[64]);

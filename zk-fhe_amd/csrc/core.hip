@@ -133,6 +133,7 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
     hipFree(kv.second.inv);
     hipFree(kv.second.fwd29);
     hipFree(kv.second.inv29);
+    hipFree(kv.second.n_inv29_dev);
   }
   for (auto &kv : ctx->tw13) hipFree(kv.second);
   for (auto &kv : ctx->pre13) hipFree(kv.second);

@@ -20,6 +20,7 @@ struct NttDomain {
   // Montgomery form): what the NTT kernels read
   zk::Fr *fwd29 = nullptr, *inv29 = nullptr;
   zk::Fr n_inv29;
+  zk::Fr *n_inv29_dev = nullptr;   // the same constant resident on the device (the inverse transforms read it: no upload per call)
 };
 
 struct zkfhe_ctx {

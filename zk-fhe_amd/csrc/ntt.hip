@@ -224,6 +224,9 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
     ZK_LAUNCH_CHECK(ctx);
     k_pow_table_scaled<<<grid, 256, 0, ctx->stream>>>(c32, d.omega_inv, d.inv29, n);
     ZK_LAUNCH_CHECK(ctx);
+    ZK_HIP(ctx, hipMalloc((void **)&d.n_inv29_dev, 64));
+    ZK_HIP(ctx, hipMemcpyAsync(d.n_inv29_dev, &d.n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the source is a local of this function
     it = ctx->domains.emplace(log_n, d).first;
   }
   *out = &it->second;
@@ -258,14 +261,7 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
   int rc = zk_domain(ctx, log_n, &dom);
   if (rc) return rc;
   // n^-1 lives in device memory next to nothing else: keep a tiny scratch copy per call
-  Fr *ninv_dev = nullptr;
-  if (inverse) {
-    void *p;
-    rc = zk_scratch(ctx, 3, 64, &p);
-    if (rc) return rc;
-    ninv_dev = (Fr *)p;
-    ZK_HIP(ctx, hipMemcpyAsync(ninv_dev, &dom->n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-  }
+  const Fr *ninv_dev = inverse ? dom->n_inv29_dev : nullptr;
   if (log_n < 3 && src) {
     rc = zk_copy_d2d(ctx, data, src, n_cols * n * sizeof(Fr));
     if (rc) return rc;
@@ -559,10 +555,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
   rc = zk_scratch(ctx, 0, n_cols * ne * sizeof(Fr), &p);
   if (rc) return rc;
   Fr *rows = (Fr *)p;
-  void *q;
-  rc = zk_scratch(ctx, 3, 64, &q);
-  if (rc) return rc;
-  ZK_HIP(ctx, hipMemcpyAsync(q, &dom->n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  const void *q = dom->n_inv29_dev;
   TileArgs a{};
   a.in = (const Fr *)in_dev;
   a.out = rows;
