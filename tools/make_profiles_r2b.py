@@ -85,7 +85,7 @@ two `k_msm_table` launches + two folds; the five calls of 1-3 columns (`k_msm_di
 %s```
 """ % (b['ms_per_step'], bs['ms_per_step'], bp['ms_per_step'], lp, rd('b_single_timeline.txt')))
 
-for tag, name, cfgn in (('c_k16', 'k16', 'BASELINE configs[3]): N = 4096, Q = 2^60 - 93'), ('d_k19', 'k19', 'BASELINE configs[4]): N = 32768, Q = 2^60 - 93')):
+for tag, name, cfgn in (('c_k16', 'k16', 'BASELINE configs[3]): N = 4096, Q = 2^60 - 93'), ('d_k19', 'k19', 'BASELINE configs[4]): N = 16384, Q = 2^60 - 93')):
     d = jl(tag + '_bench.json')
     note = ("Calls of many columns take the bucket pipeline here (a 48 GB table allows 9-bit digits at n = 2^16: 29 windows against the "
             "pipeline's 19); calls of <= 8 columns take `k_msm_table`.") if name == 'k16' else \

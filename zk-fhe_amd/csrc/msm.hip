@@ -676,8 +676,9 @@ __device__ __forceinline__ G1X29 block_sum_256(G1X29 v, G1X *sh /* [128] */) {
 // Leaving a column, the workgroup appends to that column's partial list: with TREE one butterfly and one partial (calls of a
 // few columns: thousands of short visits per column, the fold must stay short); without, every thread stores its accumulator
 // as it is -- 256 partials per visit and no butterfly (eight dependent point additions with most lanes idle cost as much as
-// eleven useful ones), and no point-addition code besides the loop's in the kernel: 160 registers, three waves per SIMD,
-// nothing spilled.  k_msm_table_fold sums the lists.
+// eleven useful ones), and no point-addition code besides the loop's in the kernel: 167 VGPRs (three waves per SIMD; rocprof
+// shows the arch / accumulation halves of the unified file), 12 bytes of scratch -- two values of the digit extraction that
+// live across the addition loop.  k_msm_table_fold sums the lists.
 template <bool TREE>
 __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__restrict__ scalars, size_t col_stride, size_t n, const G1Affine *__restrict__ T, int c, int W, BiasArg B,
                                                    unsigned P, unsigned cpc /* chunks per column */, unsigned n_cols, unsigned max_part,

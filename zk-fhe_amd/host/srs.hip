@@ -19,14 +19,26 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
   const Fr s = mont(from_bytes_wide(d));
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
-  DevBuf sc, pts;
+  // everything this function owns until it succeeds: released on every early return (an error code of a later step used
+  // to leak the two buffers and the half-built SRS with its bases)
+  struct Guard {
+    zkfhe_ctx *ctx;
+    DevBuf sc, pts;
+    zkfhe_srs *srs = nullptr;
+    ~Guard() {
+      sc.release();
+      pts.release();
+      if (srs) zkfhe_srs_destroy(ctx, srs);
+    }
+  } guard{ctx};
+  DevBuf &sc = guard.sc, &pts = guard.pts;
   CK(sc.alloc(ctx, nl * 32));
   CK(pts.alloc(ctx, nl * 64));
   G1Affine gen;
   gen.x = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 1; return t; }());
   gen.y = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 2; return t; }());
   std::vector<G1Affine> host(nl);
-  zkfhe_srs *srs = new zkfhe_srs();
+  zkfhe_srs *srs = guard.srs = new zkfhe_srs();
   srs->k = k;
   srs->comm = comm;
   srs->lo = lo;
@@ -57,8 +69,7 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
       if (small_c > 0 && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, small_c, &srs->g_lagrange_small));
     }
   }
-  sc.release();
-  pts.release();
+  guard.srs = nullptr;   // success: the caller owns it (the buffers go with the guard)
   *out = srs;
   return ZKFHE_OK;
 }
