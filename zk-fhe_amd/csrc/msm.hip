@@ -35,6 +35,7 @@
 // thirteen.  Same additions as the bucket pipeline's accumulation, none of the rest: 0.9x the VALU instructions on full-width
 // columns, 0.75x on witness columns, and 0.2 ms instead of 0.54 for a lone column (profiles/r2b_msm_table.md).  The bucket
 // pipeline stays for bases whose table would not fit (n >= 2^18) or would force so many more windows that it loses.
+#include <cstdio>
 #include <vector>
 #include <cstring>
 
@@ -722,10 +723,15 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
       __syncthreads();
       if (threadIdx.x == 0) item_sh = 0;
       __syncthreads();
+      // A column is joined only while it has at least MIN_JOIN chunks left (or has not been started): the last chunks of a
+      // column stay with the workgroups that are on it.  Without the floor every idle workgroup of the call's tail jumped onto
+      // the last busy columns for ONE chunk each -- up to 32 visits on a column of 32 chunks, and the fold's duration is that
+      // of its longest column (measured: visits per column 6 on average, 30 at the maximum; 320 - 360 us per wide fold).
+      const unsigned MIN_JOIN = cpc < 4u ? cpc : 4u;
       unsigned best = 0;   // (chunks left << 12) | column, n_cols <= 4096
       for (unsigned j = threadIdx.x; j < n_cols; j += 256) {
         const unsigned nx = __hip_atomic_load(&col_next[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nx < cpc) best = max(best, ((cpc - nx) << 12) | j);
+        if (nx < cpc && (nx == 0 || cpc - nx >= MIN_JOIN)) best = max(best, ((cpc - nx) << 12) | j);
       }
       if (best) atomicMax(&item_sh, best);
       __syncthreads();
@@ -983,6 +989,20 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
                                                               (unsigned)max_part, (G1X *)p0, n_part, col_next, (unsigned *)p1, ctx->prof_on ? adds : nullptr);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, slot, 96.0 * (double)n * (double)n_cols);
+  {
+    static const bool dbg = getenv("ZKFHE_DEBUG_NPART") != nullptr;   // visits per column (the fold's work), for tools/exp
+    if (dbg) {
+      std::vector<unsigned> np(n_cols);
+      ZK_HIP(ctx, hipMemcpy(np.data(), n_part, n_cols * sizeof(unsigned), hipMemcpyDeviceToHost));
+      unsigned long long sum = 0;
+      unsigned mx = 0;
+      for (unsigned v : np) {
+        sum += v;
+        mx = v > mx ? v : mx;
+      }
+      fprintf(stderr, "[msm_table] cols %zu  chunks/col %zu  grid %zu  visits/col avg %.1f max %u\n", n_cols, cpc, grid, (double)sum / n_cols, mx);
+    }
+  }
   k_msm_table_fold<<<(unsigned)n_cols, 512, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
   ZK_LAUNCH_CHECK(ctx);
   if (ctx->prof_on) {
