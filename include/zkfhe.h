@@ -70,14 +70,14 @@ int zkfhe_timer_start(zkfhe_ctx *ctx);
 int zkfhe_timer_stop_ms(zkfhe_ctx *ctx, float *ms);   /* waits for the stop event */
 
 /* Per-kernel profiling with HIP events on the context's stream.  While enabled, zkfhe_msm_batch and
- * zkfhe_ntt_batch bracket their dominant kernel (which 0: the summing kernel of a wide MSM call -- k_msm_table or k_msm_accumulate --, 1: k_ntt_tile,
+ * zkfhe_ntt_batch bracket their dominant kernel (which 0: the summing kernel of a wide MSM call -- k_msm_table or k_msm_accumulate --, 1: the NTT tile kernel (k_ntt13 at n >= 2^13),
  * 2: k_msm_table of a call of a few columns) with an event pair
  * and wait for it, accumulating duration, launch count and ALGORITHMIC bytes (MSM: 96 B per term, NTT: 64 B per
  * point -- BASELINE.md).  Meant for a separate, untimed pass (it serialises the stream). */
 int zkfhe_prof_enable(zkfhe_ctx *ctx, int on);
 int zkfhe_prof_reset(zkfhe_ctx *ctx);
 int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launches, double *algorithmic_bytes);
-/* arithmetic units of the profiled launches: which = 0 -> mixed point additions (k_msm_accumulate), 1 -> butterflies (k_ntt_tile) */
+/* arithmetic units of the profiled launches: which = 0 -> mixed point additions (k_msm_accumulate), 1 -> butterflies (NTT tile kernel) */
 int zkfhe_prof_read_ops(zkfhe_ctx *ctx, int which, double *ops);
 
 /* ---- coefficient-wise Fr arithmetic (device buffers, out may alias a or b) ----------------- */

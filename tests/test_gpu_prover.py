@@ -309,6 +309,20 @@ def test_proving_key_save_and_load(ctx, tmp_path):
     with pytest.raises(zk.ZkfheError):
         zk.BfvProvingKey.load(ctx, srs2, path, 1024)
     srs2.destroy()
+    # a key is bound to the SRS it was generated with: the same k from another seed is refused (two of its commitments are
+    # recomputed against the SRS it is loaded with), not accepted to produce proofs that never verify
+    srs3 = zk.Srs(ctx, 13, seed=b"another-ceremony")
+    with pytest.raises(zk.ZkfheError, match="different SRS"):
+        zk.BfvProvingKey.load(ctx, srs3, path, 1024)
+    srs3.destroy()
+    # header fields that size buffers: unusable_rows (u32 at byte 28) and lookup_bits (byte 32) out of range
+    for off_b, val in ((8 + 5 * 4, 2), (8 + 5 * 4, 1 << 20), (8 + 6 * 4, 0), (8 + 6 * 4, 31)):
+        bad = bytearray(raw)
+        bad[off_b:off_b + 4] = int(val).to_bytes(4, "little")
+        p3 = str(tmp_path / "bad_hdr.pk")
+        open(p3, "wb").write(bytes(bad))
+        with pytest.raises(zk.ZkfheError, match="header"):
+            zk.BfvProvingKey.load(ctx, srs, p3, 1024)
     srs.destroy()
 
 

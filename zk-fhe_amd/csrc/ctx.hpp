@@ -37,7 +37,7 @@ struct zkfhe_ctx {
   std::map<const void *, void *> tw13;
   std::map<std::array<uint64_t, 6>, void *> pre13;
   // grow-only scratch arenas (bytes)
-  // profiling (zkfhe_prof_*): [0] = the summing kernel of a wide MSM call (k_msm_table / k_msm_accumulate), [1] = k_ntt_tile
+  // profiling (zkfhe_prof_*): [0] = the summing kernel of a wide MSM call (k_msm_table / k_msm_accumulate), [1] = the NTT tile kernel (k_ntt13 / k_ntt_tile)
   bool prof_on = false;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: host waits sleep instead of spinning (zk_wait)

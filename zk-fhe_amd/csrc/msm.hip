@@ -727,11 +727,17 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
       // column stay with the workgroups that are on it.  Without the floor every idle workgroup of the call's tail jumped onto
       // the last busy columns for ONE chunk each -- up to 32 visits on a column of 32 chunks, and the fold's duration is that
       // of its longest column (measured: visits per column 6 on average, 30 at the maximum; 320 - 360 us per wide fold).
+      // ... and among the columns that qualify every workgroup has its own order of preference (a hash of column and
+      // workgroup): choosing "the column with the most chunks left" sent all workgroups that went idle at the same moment to the
+      // same column.
       const unsigned MIN_JOIN = cpc < 4u ? cpc : 4u;
-      unsigned best = 0;   // (chunks left << 12) | column, n_cols <= 4096
+      unsigned best = 0;   // (preference << 12) | column, n_cols <= 4096
       for (unsigned j = threadIdx.x; j < n_cols; j += 256) {
         const unsigned nx = __hip_atomic_load(&col_next[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nx < cpc && (nx == 0 || cpc - nx >= MIN_JOIN)) best = max(best, ((cpc - nx) << 12) | j);
+        if (nx < cpc && (nx == 0 || cpc - nx >= MIN_JOIN)) {
+          const unsigned h = ((j * 2654435761u) ^ (blockIdx.x * 40503u + 12345u) * 2246822519u) >> 13;   // 19 bits, never zero with the +1 below
+          best = max(best, (((h & 0x7ffffu) + 1u) << 12) | j);
+        }
       }
       if (best) atomicMax(&item_sh, best);
       __syncthreads();
