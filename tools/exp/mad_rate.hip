@@ -18,6 +18,11 @@ __global__ void k(u64 *out, u32 a, u32 b, int iters) {
         if (MODE == 1) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc[i]), "+v"(top[i]) : "v"(x), "v"(y) : "vcc");
         if (MODE == 2) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(top[i]) : "v"(x), "v"(top[i]));
         if (MODE == 3) asm volatile("v_add_co_u32 %0, vcc, %1, %0\n\tv_addc_co_u32 %0, vcc, %1, %0, vcc" : "+v"(top[i]) : "v"(x) : "vcc");
+        if (MODE == 5) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y) : "vcc");
+        if (MODE == 6) asm volatile("v_ashrrev_i64 %0, 29, %0" : "+v"(acc[i]));
+        if (MODE == 7) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[i]) : "v"(acc[(i + 1) & 7]));
+        if (MODE == 8) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(top[i]));
+        if (MODE == 9) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(x), "v"(y) : "vcc");   // one dependent chain
         if (MODE == 4) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_add_u32 %1, %1, %2" : "+v"(acc[i]), "+v"(top[i]) : "v"(x), "v"(y) : "vcc");
       }
   }
@@ -53,5 +58,10 @@ int main() {
   run<2>("v_mul_lo_u32", 1);
   run<3>("add_co + addc_co", 2);
   run<4>("mad + v_add_u32", 2);
+  run<5>("v_mad_i64_i32", 1);
+  run<6>("v_ashrrev_i64", 1);
+  run<7>("v_lshl_add_u64", 1);
+  run<8>("v_and_b32", 1);
+  run<9>("v_mad_i64_i32 dependent", 1);
   return 0;
 }
