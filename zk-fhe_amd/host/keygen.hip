@@ -76,7 +76,7 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int e
   CK(ws->small.alloc(ctx, 1 << 20));
   const size_t max_items = (size_t)c.n_advice() + c.n_fixed() + 2 + c.n_perm() + c.n_chunks() + 3 * c.n_lookup;
   CK(ws->jobs.alloc(ctx, max_items * sizeof(zkp::EvalJob) + max_items * (sizeof(void *) + 32) + 256));
-  CK(ws->evout.alloc(ctx, max_items * 4 * 32));
+  CK(ws->evout.alloc(ctx, (max_items + 64) * 4 * 32));   // + the padding of the sharded evaluations' all-gather (equal slices per rank)
   CK(ws->polyio.alloc(ctx, 4 * c.n() * 32));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_adv, (size_t)c.n_advice() * col, hipHostMallocDefault));
   memset(ws->host_adv, 0, (size_t)c.n_advice() * col);

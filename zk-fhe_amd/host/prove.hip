@@ -1025,16 +1025,30 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     STAGE(jobs_dev, zkp::EvalJob, ws, jobs.data(), jobs.size() * sizeof(zkp::EvalJob));
     CK(flush_staged(ctx, ws));
     struct { const void *p; } jd{jobs_dev};
+    // One proof over several GPUs, long rows (k >= 14): the evaluation jobs are sharded by index -- rank r takes jobs
+    // [per r, per (r + 1)) with per = ceil(J / W), every Lagrange column being present on every rank -- and the scalars are
+    // all-gathered (per * 128 bytes per rank).  Short rows are not worth a collective.
+    const bool shard_open = W_sh > 1 && k >= 14;
+    const size_t per_rank = shard_open ? (jobs.size() + W_sh - 1) / W_sh : jobs.size();
+    const size_t j_lo = shard_open ? std::min(jobs.size(), per_rank * r_sh) : 0, j_hi = shard_open ? std::min(jobs.size(), j_lo + per_rank) : jobs.size();
+    if (shard_open && (per_rank * W_sh * 4 * 32 > od.bytes || per_rank * (W_sh + 1) * 4 * 32 > ws->h_ext.bytes))
+      return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many ranks for the evaluation gather buffers");
+    Fr *ev_dst = shard_open ? ws->h_ext.fr() : od.fr();   // my slice first (the quotient's extended values are dead by now)
     // long columns: 16 row slices per job (partial sums in the dead quotient buffer), then one small reduction
     const unsigned slices = (n > 32768 && (size_t)16 * jobs.size() * 4 * 32 <= ws->partials.bytes) ? 16u : 1u;
-    if (slices == 1) {
-      zkp::k_eval_jobs<<<(unsigned)jobs.size(), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, od.fr());
-    } else {
-      zkp::k_eval_jobs<<<dim3((unsigned)jobs.size(), slices), 256, 0, ctx->stream>>>((const zkp::EvalJob *)jd.p, bw, n, ws->partials.fr());
+    if (j_hi > j_lo) {
+      const zkp::EvalJob *jp = (const zkp::EvalJob *)jd.p + j_lo;
+      const unsigned nj = (unsigned)(j_hi - j_lo);
+      if (slices == 1) {
+        zkp::k_eval_jobs<<<nj, 256, 0, ctx->stream>>>(jp, bw, n, ev_dst + (shard_open ? 0 : j_lo * 4));
+      } else {
+        zkp::k_eval_jobs<<<dim3(nj, slices), 256, 0, ctx->stream>>>(jp, bw, n, ws->partials.fr());
+        ZK_LAUNCH_CHECK(ctx);
+        zkp::k_sum_rows<<<grid_for(ctx, (size_t)nj * 4), 256, 0, ctx->stream>>>(ws->partials.fr(), slices, (size_t)nj * 4, ev_dst + (shard_open ? 0 : j_lo * 4));
+      }
       ZK_LAUNCH_CHECK(ctx);
-      zkp::k_sum_rows<<<grid_for(ctx, jobs.size() * 4), 256, 0, ctx->stream>>>(ws->partials.fr(), slices, jobs.size() * 4, od.fr());
     }
-    ZK_LAUNCH_CHECK(ctx);
+    if (shard_open) CK(zkfhe_comm_all_gather(ctx, srs->comm, ev_dst, od.p, per_rank * 4 * 32));   // rank-major = job order
     if (jobs.size() * 4 > ws->out_ev_cap) return zk_fail_msg(ctx, ZKFHE_EINVAL, "more evaluations than the result block holds");
     // canonical values straight into pinned memory (the conversion kernel stores them there): no copy command
     CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)od.p, (zkfhe_fr *)ws->out_ev(), jobs.size() * 4));
@@ -1101,17 +1115,30 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       }
     }
     CK(flush_staged(ctx, ws));
+    // One proof over several GPUs, long rows: every rank sums its share of a set's members (a k_lincomb_ptrs over zero members
+    // writes zeros), the W partial combinations of all sets are all-gathered (ns n values per rank) and added up.
+    const bool shard_sets = W_sh > 1 && k >= 14;
+    if (shard_sets && (size_t)W_sh * ns * n * 32 > ws->partials.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many ranks for the SHPLONK gather buffer");
     for (size_t j = 0; j < ns; ++j) {
-      const unsigned msz = (unsigned)sets[j].members.size();
+      const size_t all = sets[j].members.size();
+      const size_t m_lo = shard_sets ? all * r_sh / W_sh : 0, m_hi = shard_sets ? all * (r_sh + 1) / W_sh : all;
+      const unsigned msz = (unsigned)(m_hi - m_lo);
+      const Fr *const *pp = set_ptrs[j] + m_lo;
+      const Fr *pw = set_pw[j] + m_lo;
       const unsigned per = 48, chunks = (msz + per - 1) / per;
       if (chunks > 1 && (size_t)chunks * n * 32 <= ws->partials.bytes) {
         dim3 lg(grid_for(ctx, n), chunks);
-        zkp::k_lincomb_ptrs_chunked<<<lg, 256, 0, ctx->stream>>>(set_ptrs[j], set_pw[j], msz, per, n, ws->partials.fr());
+        zkp::k_lincomb_ptrs_chunked<<<lg, 256, 0, ctx->stream>>>(pp, pw, msz, per, n, ws->partials.fr());
         ZK_LAUNCH_CHECK(ctx);
         zkp::k_sum_rows<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ws->partials.fr(), chunks, n, F + j * n);
       } else {
-        zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(set_ptrs[j], set_pw[j], msz, n, F + j * n);
+        zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(pp, pw, msz, n, F + j * n);
       }
+      ZK_LAUNCH_CHECK(ctx);
+    }
+    if (shard_sets) {
+      CK(zkfhe_comm_all_gather(ctx, srs->comm, F, ws->partials.p, ns * n * 32));
+      zkp::k_sum_rows<<<grid_for(ctx, ns * n), 256, 0, ctx->stream>>>(ws->partials.fr(), W_sh, ns * n, F);
       ZK_LAUNCH_CHECK(ctx);
     }
   }
