@@ -124,6 +124,25 @@ def test_bfv_in_k13_proof_bytes_match_oracle(ctx, monkeypatch, table_gb):
     srs.destroy()
 
 
+def test_native_cpu_prover_k13_bytes_match_oracle_and_gpu(ctx):
+    """bench.py's cpu_baseline leg (oracle/cpu_prover.cpp) on the reference's bfv.in at the pinned k = 13 layout: the same bytes
+    as the oracle prover and as the GPU prover."""
+    from oracle import cpu_prover as CP
+    o = oracle_k13()
+    hcfg = H.Config.from_pinning(o["cfgj"])
+    cp = CP.CpuProver(hcfg, o["pk_o"], o["srs_o"], o["prm"])
+    proof_c = cp.prove(o["text"], b"seed-1")
+    cp.close()
+    assert proof_c == o["proof_o"]
+    import zk_fhe_amd as zk
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, o["text_empty"], (1024, o["prm"].Q, o["prm"].T, o["prm"].B), zk.BfvConfig.from_pinning(o["cfgj"]))
+    proof, _, _ = pk.prove(o["text"], b"seed-1")
+    assert proof == proof_c
+    pk.destroy()
+    srs.destroy()
+
+
 def test_gpu_gate_stream_matches_oracle_cell_for_cell(ctx):
     """SURVEY.md 8a rows A8-A14 directly: the 1 231 992 phase-1 gate cells the GPU gadget kernels emit for the reference's
     data/bfv/bfv.in equal the oracle's restatement of src/poly_chip.rs + halo2-base (oracle/circuit_ref.py), for a fixed gamma."""
