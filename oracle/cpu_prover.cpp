@@ -32,7 +32,38 @@ namespace {
 
 typedef fe_t F;
 
-inline F fmul(const F &a, const F &b) { F r; fe_mul(&FR, &r, &a, &b); return r; }
+// Montgomery product, CIOS on four 64-bit limbs, fully unrolled (the modulus is below 2^254, so the running value fits
+// four limbs plus the carry word).  oracle/bn254_ref.h's fe_mul (product, then a separate reduction) stays the reference
+// formulation; this one is checked against it by the byte-identity of whole proofs.
+typedef unsigned __int128 u128;
+template <const field_t *Fd>
+inline void mul_cios(fe_t *r, const fe_t *a, const fe_t *b) {
+  const uint64_t *p = Fd->p;
+  const uint64_t inv = Fd->inv;
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 c;
+    const uint64_t bi = b->l[i];
+    c = (u128)a->l[0] * bi + t0; t0 = (uint64_t)c;
+    c = (u128)a->l[1] * bi + t1 + (uint64_t)(c >> 64); t1 = (uint64_t)c;
+    c = (u128)a->l[2] * bi + t2 + (uint64_t)(c >> 64); t2 = (uint64_t)c;
+    c = (u128)a->l[3] * bi + t3 + (uint64_t)(c >> 64); t3 = (uint64_t)c;
+    t4 = (uint64_t)(c >> 64);
+    const uint64_t m = t0 * inv;
+    c = (u128)m * p[0] + t0;
+    c = (u128)m * p[1] + t1 + (uint64_t)(c >> 64); t0 = (uint64_t)c;
+    c = (u128)m * p[2] + t2 + (uint64_t)(c >> 64); t1 = (uint64_t)c;
+    c = (u128)m * p[3] + t3 + (uint64_t)(c >> 64); t2 = (uint64_t)c;
+    c = (u128)t4 + (uint64_t)(c >> 64); t3 = (uint64_t)c;
+  }
+  uint64_t t[4] = {t0, t1, t2, t3};
+  if (limbs_geq(t, p)) limbs_sub(t, t, p);
+  memcpy(r->l, t, 32);
+}
+inline void qmul(fe_t *r, const fe_t *a, const fe_t *b) { mul_cios<&FQ>(r, a, b); }
+inline void qsqr(fe_t *r, const fe_t *a) { mul_cios<&FQ>(r, a, a); }
+
+inline F fmul(const F &a, const F &b) { F r; mul_cios<&FR>(&r, &a, &b); return r; }
 inline F fadd(const F &a, const F &b) { F r; fe_add(&FR, &r, &a, &b); return r; }
 inline F fsub(const F &a, const F &b) { F r; fe_sub(&FR, &r, &a, &b); return r; }
 inline F fneg(const F &a) { F r; fe_neg(&FR, &r, &a); return r; }
@@ -104,28 +135,94 @@ struct Domain {
   }
 };
 
+// Big per-proof arrays live in the key object and are reused from proof to proof (no page faults after the first one);
+// nothing here is value-initialised on one thread: every element is written by the parallel loop that produces it.
+struct Buf {
+  F *p = nullptr;
+  size_t cap = 0;
+  F *get(size_t count) {
+    if (count > cap) {
+      free(p);
+      p = (F *)aligned_alloc(64, (count * sizeof(F) + 63) / 64 * 64);
+      if (!p) throw std::bad_alloc();
+      cap = count;
+    }
+    return p;
+  }
+  ~Buf() { free(p); }
+};
+struct Workspace {
+  Buf adv, la, ls, pz, lz, adv_e, la_e, ls_e, pz_e, lz_e, inst_e, h_e, msm_k, gp;
+  std::vector<U256> advice_table;  // the Assigner's canonical cells: the fixed layout rewrites every used cell, the rest stays zero
+  std::vector<g1j_t> msm_win;
+  size_t cells[3] = {0, 0, 0}, sels[3] = {0, 0, 0}, lookups = 0;  // stream lengths of the previous proof (same circuit): reserved up front
+};
+
 // ------------------------------------------------------------------------------------------------ MSM
-// madd-2007-bl, exceptional cases handled (Jacobian x = X/Z^2, y = Y/Z^3 as in bn254_ref.h)
-inline void g1j_madd(g1j_t *r, const g1j_t *p, const g1a_t *q) {
+// Jacobian x = X/Z^2, y = Y/Z^3 as in bn254_ref.h (whose g1j_* are the reference formulation); same formulas on the CIOS product
+inline void jdbl(g1j_t *r, const g1j_t *p) {  // dbl-2009-l
+  if (g1j_is_identity(p)) { *r = *p; return; }
+  fe_t a, b, c, d, e, f, t, x3, y3, z3;
+  qsqr(&a, &p->x);
+  qsqr(&b, &p->y);
+  qsqr(&c, &b);
+  fe_add(&FQ, &t, &p->x, &b); qsqr(&t, &t); fe_sub(&FQ, &t, &t, &a); fe_sub(&FQ, &t, &t, &c);
+  fe_add(&FQ, &d, &t, &t);
+  fe_add(&FQ, &e, &a, &a); fe_add(&FQ, &e, &e, &a);
+  qsqr(&f, &e);
+  fe_sub(&FQ, &x3, &f, &d); fe_sub(&FQ, &x3, &x3, &d);
+  qmul(&z3, &p->y, &p->z); fe_add(&FQ, &z3, &z3, &z3);
+  fe_sub(&FQ, &t, &d, &x3); qmul(&y3, &e, &t);
+  fe_add(&FQ, &c, &c, &c); fe_add(&FQ, &c, &c, &c); fe_add(&FQ, &c, &c, &c);
+  fe_sub(&FQ, &y3, &y3, &c);
+  r->x = x3; r->y = y3; r->z = z3;
+}
+inline void jadd(g1j_t *r, const g1j_t *p, const g1j_t *q) {  // add-2007-bl
+  if (g1j_is_identity(p)) { *r = *q; return; }
+  if (g1j_is_identity(q)) { *r = *p; return; }
+  fe_t z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t, x3, y3, z3;
+  qsqr(&z1z1, &p->z);
+  qsqr(&z2z2, &q->z);
+  qmul(&u1, &p->x, &z2z2);
+  qmul(&u2, &q->x, &z1z1);
+  qmul(&s1, &p->y, &q->z); qmul(&s1, &s1, &z2z2);
+  qmul(&s2, &q->y, &p->z); qmul(&s2, &s2, &z1z1);
+  if (fe_eq(&u1, &u2)) {
+    if (fe_eq(&s1, &s2)) { jdbl(r, p); return; }
+    g1j_set_identity(r); return;
+  }
+  fe_sub(&FQ, &h, &u2, &u1);
+  fe_add(&FQ, &i, &h, &h); qsqr(&i, &i);
+  qmul(&j, &h, &i);
+  fe_sub(&FQ, &rr, &s2, &s1); fe_add(&FQ, &rr, &rr, &rr);
+  qmul(&v, &u1, &i);
+  qsqr(&x3, &rr); fe_sub(&FQ, &x3, &x3, &j); fe_sub(&FQ, &x3, &x3, &v); fe_sub(&FQ, &x3, &x3, &v);
+  fe_sub(&FQ, &t, &v, &x3); qmul(&y3, &rr, &t);
+  qmul(&t, &s1, &j); fe_add(&FQ, &t, &t, &t); fe_sub(&FQ, &y3, &y3, &t);
+  fe_add(&FQ, &z3, &p->z, &q->z); qsqr(&z3, &z3); fe_sub(&FQ, &z3, &z3, &z1z1); fe_sub(&FQ, &z3, &z3, &z2z2);
+  qmul(&z3, &z3, &h);
+  r->x = x3; r->y = y3; r->z = z3;
+}
+inline void g1j_madd(g1j_t *r, const g1j_t *p, const g1a_t *q) {  // madd-2007-bl
   if (g1j_is_identity(p)) { g1j_from_affine(r, q); return; }
   fe_t z1z1, u2, s2, h, hh, i, j, rr, v, t, x3, y3, z3;
-  fe_sqr(&FQ, &z1z1, &p->z);
-  fe_mul(&FQ, &u2, &q->x, &z1z1);
-  fe_mul(&FQ, &s2, &q->y, &p->z); fe_mul(&FQ, &s2, &s2, &z1z1);
+  qsqr(&z1z1, &p->z);
+  qmul(&u2, &q->x, &z1z1);
+  qmul(&s2, &q->y, &p->z); qmul(&s2, &s2, &z1z1);
   if (fe_eq(&u2, &p->x)) {
-    if (fe_eq(&s2, &p->y)) { g1j_dbl(r, p); return; }
+    if (fe_eq(&s2, &p->y)) { jdbl(r, p); return; }
     g1j_set_identity(r); return;
   }
   fe_sub(&FQ, &h, &u2, &p->x);
-  fe_sqr(&FQ, &hh, &h);
+  qsqr(&hh, &h);
   fe_add(&FQ, &i, &hh, &hh); fe_add(&FQ, &i, &i, &i);
-  fe_mul(&FQ, &j, &h, &i);
+  qmul(&j, &h, &i);
   fe_sub(&FQ, &rr, &s2, &p->y); fe_add(&FQ, &rr, &rr, &rr);
-  fe_mul(&FQ, &v, &p->x, &i);
-  fe_sqr(&FQ, &x3, &rr); fe_sub(&FQ, &x3, &x3, &j); fe_sub(&FQ, &x3, &x3, &v); fe_sub(&FQ, &x3, &x3, &v);
-  fe_sub(&FQ, &t, &v, &x3); fe_mul(&FQ, &y3, &rr, &t);
-  fe_mul(&FQ, &t, &p->y, &j); fe_add(&FQ, &t, &t, &t); fe_sub(&FQ, &y3, &y3, &t);
-  fe_add(&FQ, &z3, &p->z, &h); fe_sqr(&FQ, &z3, &z3); fe_sub(&FQ, &z3, &z3, &z1z1); fe_sub(&FQ, &z3, &z3, &hh);
+  qmul(&v, &p->x, &i);
+  qsqr(&x3, &rr); fe_sub(&FQ, &x3, &x3, &j); fe_sub(&FQ, &x3, &x3, &v); fe_sub(&FQ, &x3, &x3, &v);
+  fe_sub(&FQ, &t, &v, &x3); qmul(&y3, &rr, &t);
+  qmul(&t, &p->y, &j); fe_add(&FQ, &t, &t, &t); fe_sub(&FQ, &y3, &y3, &t);
+  fe_add(&FQ, &z3, &p->z, &h); qsqr(&z3, &z3); fe_sub(&FQ, &z3, &z3, &z1z1); fe_sub(&FQ, &z3, &z3, &hh);
   r->x = x3; r->y = y3; r->z = z3;
 }
 
@@ -139,15 +236,17 @@ inline unsigned window_of(const uint64_t k[4], unsigned lo, unsigned c) {
 
 // n_cols MSMs over one basis (halo2 `best_multiexp` per column): Pippenger with unsigned c-bit windows; the
 // (column, window) bucket passes run in parallel, so a call of ONE column still uses every core.
-void msm_cols(const F *scalars, size_t n_cols, const g1a_t *bases, size_t n, AffinePoint *out) {
+void msm_cols(Workspace &ws, const F *scalars, size_t n_cols, const g1a_t *bases, size_t n, AffinePoint *out) {
   if (!n_cols) return;
   const unsigned c = n < 32 ? 3 : n < 1024 ? 7 : n < 65536 ? 10 : 13;
   const unsigned nwin = (254 + c - 1) / c;
   const size_t nb = ((size_t)1 << c) - 1;
-  std::vector<U256> k(n_cols * n);
+  static_assert(sizeof(U256) == sizeof(F), "canonical and Montgomery values share a buffer type");
+  U256 *k = (U256 *)ws.msm_k.get(n_cols * n);
 #pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n_cols * n; ++i) k[i] = from_m(scalars[i]);
-  std::vector<g1j_t> win(n_cols * nwin);
+  if (ws.msm_win.size() < n_cols * nwin) ws.msm_win.resize(n_cols * nwin);
+  g1j_t *win = ws.msm_win.data();
 #pragma omp parallel
   {
     std::vector<g1j_t> buckets(nb);
@@ -155,7 +254,7 @@ void msm_cols(const F *scalars, size_t n_cols, const g1a_t *bases, size_t n, Aff
     for (size_t task = 0; task < n_cols * nwin; ++task) {
       const size_t col = task / nwin;
       const unsigned w = (unsigned)(task % nwin);
-      const U256 *kc = k.data() + col * n;
+      const U256 *kc = k + col * n;
       bool any = false;
       for (size_t b = 0; b < nb; ++b) g1j_set_identity(&buckets[b]);
       for (size_t i = 0; i < n; ++i) {
@@ -170,8 +269,8 @@ void msm_cols(const F *scalars, size_t n_cols, const g1a_t *bases, size_t n, Aff
       g1j_set_identity(&sum);
       if (any)
         for (size_t b = nb; b-- > 0;) {
-          g1j_add(&run, &run, &buckets[b]);
-          g1j_add(&sum, &sum, &run);
+          jadd(&run, &run, &buckets[b]);
+          jadd(&sum, &sum, &run);
         }
       win[task] = sum;
     }
@@ -181,8 +280,8 @@ void msm_cols(const F *scalars, size_t n_cols, const g1a_t *bases, size_t n, Aff
     g1j_t total;
     g1j_set_identity(&total);
     for (unsigned w = nwin; w-- > 0;) {
-      for (unsigned d = 0; d < c; ++d) g1j_dbl(&total, &total);
-      g1j_add(&total, &total, &win[col * nwin + w]);
+      for (unsigned d = 0; d < c; ++d) jdbl(&total, &total);
+      jadd(&total, &total, &win[col * nwin + w]);
     }
     g1a_t a;
     g1j_to_affine(&a, &total);
@@ -282,6 +381,7 @@ void permute_lookup(const U256 *a_vals, const std::vector<U256> &table, size_t u
 }  // namespace
 
 struct cpu_pk {
+  mutable Workspace ws;
   CircuitConfig cfg;
   BfvParams prm;
   U256 vk_digest;
@@ -346,15 +446,13 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   Rng rng(seed32);
   Transcript tr(cfg.transcript);
   Timer tm(ms);
-  auto take = [&](F *dst, size_t cnt) {
-    std::vector<U256> v(cnt);
-    for (size_t i = 0; i < cnt; ++i) v[i] = rng.next();
-#pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < cnt; ++i) dst[i] = to_m(v[i]);
+  auto take = [&](F *dst, size_t cnt) {  // the blinding stream is sequential by construction
+    for (size_t i = 0; i < cnt; ++i) dst[i] = to_m(rng.next());
   };
+  Workspace &ws = pk->ws;
   auto commit = [&](const F *cols, size_t count, bool lagrange, std::vector<AffinePoint> &out) {
     out.resize(count);
-    msm_cols(cols, count, lagrange ? pk->g_lag.data() : pk->g_mon.data(), n, out.data());
+    msm_cols(ws, cols, count, lagrange ? pk->g_lag.data() : pk->g_mon.data(), n, out.data());
   };
 
   // ---- witness, phase 0 (examples/bfv.rs:63-165)
@@ -362,25 +460,33 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   const CircuitInput in = CircuitInput::parse_json(input_json);
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
   std::vector<Cell> make_public;
+  {
+    Context *cs[3] = {&ctx0, &ctx_gate, &ctx_rlc};
+    for (int i = 0; i < 3; ++i) {
+      cs[i]->advice.reserve(ws.cells[i]);
+      cs[i]->selector.reserve(ws.sels[i]);
+    }
+    ctx_gate.lookup.reserve(ws.lookups);
+  }
   const BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
   std::vector<U256> inst;
   for (const Cell &c : make_public) inst.push_back(c.value);
   for (const U256 &v : inst) tr.common_scalar(v);
-  Assigner as(cfg, false);
+  if (ws.advice_table.size() != (size_t)n_adv * n) ws.advice_table.assign((size_t)n_adv * n, fe::zero());
+  Assigner as(cfg, false, ws.advice_table.data());
   as.place(ctx0, true);
-  std::vector<F> adv((size_t)n_adv * n);
+  F *adv = ws.adv.get((size_t)n_adv * n);
   auto load_advice = [&](unsigned c0, unsigned c1) {
-    for (unsigned c = c0; c < c1; ++c) {
-      const U256 *src = as.t.advice[c];
-      F *dst = adv.data() + (size_t)c * n;
+    for (unsigned c = c0; c < c1; ++c) take(adv + (size_t)c * n + u, n - u);
 #pragma omp parallel for schedule(static)
-      for (size_t r = 0; r < u; ++r) dst[r] = to_m(src[r]);
-      take(dst + u, n - u);
+    for (size_t idx = (size_t)c0 * u; idx < (size_t)c1 * u; ++idx) {
+      const size_t c = idx / u, r = idx % u;
+      adv[c * n + r] = to_m(as.t.advice[c][r]);
     }
   };
   load_advice(0, cfg.n_gate0);
   std::vector<AffinePoint> adv_commit(n_adv), cm;
-  commit(adv.data(), cfg.n_gate0, true, cm);
+  commit(adv, cfg.n_gate0, true, cm);
   for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = cm[c]);
   const U256 gamma_rlc = tr.squeeze();
   tm.lap();  // 0: phase 0
@@ -390,9 +496,17 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   as.place(ctx_gate, true);
   as.place(ctx_rlc, true);
   as.place_lookups(ctx_gate);
+  {
+    const Context *cs[3] = {&ctx0, &ctx_gate, &ctx_rlc};
+    for (int i = 0; i < 3; ++i) {
+      ws.cells[i] = cs[i]->advice.size();
+      ws.sels[i] = cs[i]->selector.size();
+    }
+    ws.lookups = ctx_gate.lookup.size();
+  }
   tm.lap();  // 1: phase-1 witness
   load_advice(cfg.n_gate0, n_adv);
-  commit(adv.data() + (size_t)cfg.n_gate0 * n, n_adv - cfg.n_gate0, true, cm);
+  commit(adv + (size_t)cfg.n_gate0 * n, n_adv - cfg.n_gate0, true, cm);
   for (unsigned c = cfg.n_gate0; c < n_adv; ++c) tr.write_point(adv_commit[c] = cm[c - cfg.n_gate0]);
   (void)tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
   tm.lap();  // 2: advice commitments
@@ -400,10 +514,10 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   // ---- lookups: permuted input / table
   std::vector<U256> table(n);
   for (size_t r = 0; r < n; ++r) table[r] = from_m(pk->fixed_l[(size_t)cfg.fix_table() * n + r]);
-  std::vector<F> la((size_t)n_lk * n), ls((size_t)n_lk * n);
+  F *la = ws.la.get((size_t)n_lk * n), *ls = ws.ls.get((size_t)n_lk * n);
   for (unsigned i = 0; i < n_lk; ++i) {
-    take(la.data() + (size_t)i * n + u, n - u);
-    take(ls.data() + (size_t)i * n + u, n - u);
+    take(la + (size_t)i * n + u, n - u);
+    take(ls + (size_t)i * n + u, n - u);
   }
   std::string lookup_err;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -422,8 +536,8 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   }
   if (!lookup_err.empty()) throw std::runtime_error(lookup_err);
   std::vector<AffinePoint> la_commit, ls_commit;
-  commit(la.data(), n_lk, true, la_commit);
-  commit(ls.data(), n_lk, true, ls_commit);
+  commit(la, n_lk, true, la_commit);
+  commit(ls, n_lk, true, ls_commit);
   for (unsigned i = 0; i < n_lk; ++i) {
     tr.write_point(la_commit[i]);
     tr.write_point(ls_commit[i]);
@@ -436,7 +550,7 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   std::vector<F> inst_col(n, fzero());
   for (size_t i = 0; i < inst.size(); ++i) inst_col[i] = to_m(inst[i]);
   auto permcol_l = [&](unsigned c) -> const F * {
-    if (c < n_adv) return adv.data() + (size_t)c * n;
+    if (c < n_adv) return adv + (size_t)c * n;
     return c == cfg.perm_const() ? pk->fixed_l.data() + (size_t)cfg.fix_const() * n : inst_col.data();
   };
   std::vector<F> wpow(n), bdelta(n_perm);
@@ -452,7 +566,7 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
       d = fmul(d, pk->delta);
     }
   }
-  std::vector<F> pz((size_t)n_chunks * n), lz((size_t)n_lk * n);
+  F *pz = ws.pz.get((size_t)n_chunks * n), *lz = ws.lz.get((size_t)n_lk * n);
 #pragma omp parallel for schedule(dynamic, 1)
   for (unsigned j = 0; j < n_chunks; ++j) {
     std::vector<F> num(u, fone()), den(u, fone());
@@ -464,34 +578,34 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
       }
     }
     batch_inv(den.data(), u);
-    F *z = pz.data() + (size_t)j * n;  // local prefix products (start 1); the carry over the chunks is applied below
+    F *z = pz + (size_t)j * n;  // local prefix products (start 1); the carry over the chunks is applied below
     z[0] = fone();
     for (size_t r = 0; r < u; ++r) z[r + 1] = fmul(z[r], fmul(num[r], den[r]));
   }
   {
-    F carry = fone();
-    for (unsigned j = 0; j < n_chunks; ++j) {
-      F *z = pz.data() + (size_t)j * n;
-      if (j) {
-#pragma omp parallel for schedule(static)
-        for (size_t r = 0; r <= u; ++r) z[r] = fmul(z[r], carry);
-      }
-      carry = z[u];
-      take(z + u + 1, n - u - 1);
-    }
+    // z_j(row) = (product of the chunks before j) * local prefix product; the last chunk must close at 1
+    std::vector<F> carry(n_chunks + 1);
+    carry[0] = fone();
+    for (unsigned j = 0; j < n_chunks; ++j) carry[j + 1] = fmul(carry[j], pz[(size_t)j * n + u]);
     const F one = fone();
-    if (!fe_eq(&carry, &one)) throw std::runtime_error("permutation argument does not close: copy constraints violated");
+    if (!fe_eq(&carry[n_chunks], &one)) throw std::runtime_error("permutation argument does not close: copy constraints violated");
+#pragma omp parallel for schedule(static)
+    for (size_t idx = (size_t)(u + 1); idx < (size_t)n_chunks * (u + 1); ++idx) {
+      const size_t j = idx / (u + 1), r = idx % (u + 1);
+      pz[j * n + r] = fmul(pz[j * n + r], carry[j]);
+    }
+    for (unsigned j = 0; j < n_chunks; ++j) take(pz + (size_t)j * n + u + 1, n - u - 1);
   }
   // ---- lookup grand products
   const F *tab_l = pk->fixed_l.data() + (size_t)cfg.fix_table() * n;
   int lookup_open = 0;
 #pragma omp parallel for schedule(dynamic, 1)
   for (unsigned i = 0; i < n_lk; ++i) {
-    const F *a_l = adv.data() + (size_t)(cfg.adv_lookup0() + i) * n, *ap = la.data() + (size_t)i * n, *sp = ls.data() + (size_t)i * n;
+    const F *a_l = adv + (size_t)(cfg.adv_lookup0() + i) * n, *ap = la + (size_t)i * n, *sp = ls + (size_t)i * n;
     std::vector<F> den(u);
     for (size_t r = 0; r < u; ++r) den[r] = fmul(fadd(ap[r], beta), fadd(sp[r], gamma));
     batch_inv(den.data(), u);
-    F *z = lz.data() + (size_t)i * n;
+    F *z = lz + (size_t)i * n;
     z[0] = fone();
     for (size_t r = 0; r < u; ++r) z[r + 1] = fmul(z[r], fmul(fmul(fadd(a_l[r], beta), fadd(tab_l[r], gamma)), den[r]));
     const F one = fone();
@@ -501,11 +615,11 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
     }
   }
   if (lookup_open) throw std::runtime_error("lookup argument does not close");
-  for (unsigned i = 0; i < n_lk; ++i) take(lz.data() + (size_t)i * n + u + 1, n - u - 1);
+  for (unsigned i = 0; i < n_lk; ++i) take(lz + (size_t)i * n + u + 1, n - u - 1);
   std::vector<AffinePoint> pz_commit, lz_commit;
-  commit(pz.data(), n_chunks, true, pz_commit);
+  commit(pz, n_chunks, true, pz_commit);
   for (const AffinePoint &p : pz_commit) tr.write_point(p);
-  commit(lz.data(), n_lk, true, lz_commit);
+  commit(lz, n_lk, true, lz_commit);
   for (const AffinePoint &p : lz_commit) tr.write_point(p);
   // ---- vanishing argument: random polynomial
   std::vector<F> rand_c(n);
@@ -517,23 +631,24 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   tm.lap();  // 4: grand products + commitments
 
   // ---- coefficient forms and the extended coset
-  ntt_cols(pk->dom, adv.data(), n_adv, true);
-  ntt_cols(pk->dom, la.data(), n_lk, true);
-  ntt_cols(pk->dom, ls.data(), n_lk, true);
-  ntt_cols(pk->dom, pz.data(), n_chunks, true);
-  ntt_cols(pk->dom, lz.data(), n_lk, true);
+  ntt_cols(pk->dom, adv, n_adv, true);
+  ntt_cols(pk->dom, la, n_lk, true);
+  ntt_cols(pk->dom, ls, n_lk, true);
+  ntt_cols(pk->dom, pz, n_chunks, true);
+  ntt_cols(pk->dom, lz, n_lk, true);
   pk->dom->fft(inst_col.data(), true);
-  std::vector<F> adv_e((size_t)n_adv * ne), la_e((size_t)n_lk * ne), ls_e((size_t)n_lk * ne), pz_e((size_t)n_chunks * ne), lz_e((size_t)n_lk * ne), inst_e(ne);
-  to_ext(pk, adv.data(), n_adv, adv_e.data());
-  to_ext(pk, la.data(), n_lk, la_e.data());
-  to_ext(pk, ls.data(), n_lk, ls_e.data());
-  to_ext(pk, pz.data(), n_chunks, pz_e.data());
-  to_ext(pk, lz.data(), n_lk, lz_e.data());
-  to_ext(pk, inst_col.data(), 1, inst_e.data());
+  F *adv_e = ws.adv_e.get((size_t)n_adv * ne), *la_e = ws.la_e.get((size_t)n_lk * ne), *ls_e = ws.ls_e.get((size_t)n_lk * ne);
+  F *pz_e = ws.pz_e.get((size_t)n_chunks * ne), *lz_e = ws.lz_e.get((size_t)n_lk * ne), *inst_e = ws.inst_e.get(ne);
+  to_ext(pk, adv, n_adv, adv_e);
+  to_ext(pk, la, n_lk, la_e);
+  to_ext(pk, ls, n_lk, ls_e);
+  to_ext(pk, pz, n_chunks, pz_e);
+  to_ext(pk, lz, n_lk, lz_e);
+  to_ext(pk, inst_col.data(), 1, inst_e);
   tm.lap();  // 5: NTTs
 
   // ---- quotient numerator, expression by expression in halo2's folding order (oracle/halo2_ref.py expressions_at)
-  std::vector<F> h_e(ne);
+  F *h_e = ws.h_e.get(ne);
   {
     const F g_rlc = to_m(gamma_rlc), one = fone();
     const F gn = fpow(f_u64(COSET_G), n), i4 = fpow(pk->dom_e->omega(), n);
@@ -542,8 +657,8 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
     const F *fx = pk->fixed_e.data(), *sg = pk->sigma_e.data(), *l0 = pk->l_e.data(), *ll = l0 + ne, *lact = ll + ne;
     const unsigned m = n_chunks - 1;
     auto permcol_e = [&](unsigned c) -> const F * {
-      if (c < n_adv) return adv_e.data() + (size_t)c * ne;
-      return c == cfg.perm_const() ? fx + (size_t)cfg.fix_const() * ne : inst_e.data();
+      if (c < n_adv) return adv_e + (size_t)c * ne;
+      return c == cfg.perm_const() ? fx + (size_t)cfg.fix_const() * ne : inst_e;
     };
     std::vector<const F *> pcol(n_perm);
     for (unsigned c = 0; c < n_perm; ++c) pcol[c] = permcol_e(c);
@@ -553,11 +668,11 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
       F acc = fzero();
       auto fold = [&](const F &e) { acc = fadd(fmul(acc, y), e); };
       for (unsigned j = 0; j < cfg.n_gate(); ++j) {
-        const F *a = adv_e.data() + (size_t)j * ne;
+        const F *a = adv_e + (size_t)j * ne;
         fold(fmul(fx[(size_t)j * ne + i], fsub(fadd(a[i], fmul(a[i1], a[i2])), a[i3])));
       }
       for (unsigned j = 0; j < cfg.n_rlc; ++j) {
-        const F *a = adv_e.data() + (size_t)(cfg.adv_rlc0() + j) * ne;
+        const F *a = adv_e + (size_t)(cfg.adv_rlc0() + j) * ne;
         fold(fmul(fx[(size_t)(cfg.fix_qrlc0() + j) * ne + i], fsub(fadd(fmul(a[i], g_rlc), a[i1]), a[i2])));
       }
       fold(fmul(l0[i], fsub(one, pz_e[i])));
@@ -588,7 +703,7 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
     }
   }
   // extended_to_coeff: inverse transform, then a[i] *= g^-i
-  pk->dom_e->fft(h_e.data(), true);
+  pk->dom_e->fft(h_e, true);
   {
     const F ginv = finv(f_u64(COSET_G));
     std::vector<F> gp(ne);
@@ -603,7 +718,7 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
   for (size_t i = 3 * n; i < ne; ++i)
     if (!fe_is_zero(&h_e[i])) throw std::runtime_error("quotient degree too high: some constraint is violated");
   std::vector<AffinePoint> h_commit;
-  commit(h_e.data(), 3, false, h_commit);
+  commit(h_e, 3, false, h_commit);
   for (const AffinePoint &p : h_commit) tr.write_point(p);
   const F x = to_m(tr.squeeze());
   tm.lap();  // 6: quotient
@@ -617,16 +732,16 @@ void prove_impl(const cpu_pk *pk, const char *input_json, const uint8_t seed32[3
     for (size_t i = 0; i < n; ++i) Hpoly[i] = fadd(h_e[i], fadd(fmul(h_e[n + i], xn), fmul(h_e[2 * n + i], xn2)));
   }
   std::vector<const F *> poly(L.count);
-  for (unsigned c = 0; c < n_adv; ++c) poly[L.adv0 + c] = adv.data() + (size_t)c * n;
+  for (unsigned c = 0; c < n_adv; ++c) poly[L.adv0 + c] = adv + (size_t)c * n;
   for (unsigned c = 0; c < cfg.n_fixed(); ++c) poly[L.fixed0 + c] = pk->fixed_c.data() + (size_t)c * n;
   poly[L.H] = Hpoly.data();
   poly[L.rand] = rand_c.data();
   for (unsigned c = 0; c < n_perm; ++c) poly[L.sigma0 + c] = pk->sigma_c.data() + (size_t)c * n;
-  for (unsigned j = 0; j < n_chunks; ++j) poly[L.pz0 + j] = pz.data() + (size_t)j * n;
+  for (unsigned j = 0; j < n_chunks; ++j) poly[L.pz0 + j] = pz + (size_t)j * n;
   for (unsigned i = 0; i < n_lk; ++i) {
-    poly[L.lk0 + 3 * i] = lz.data() + (size_t)i * n;
-    poly[L.lk0 + 3 * i + 1] = la.data() + (size_t)i * n;
-    poly[L.lk0 + 3 * i + 2] = ls.data() + (size_t)i * n;
+    poly[L.lk0 + 3 * i] = lz + (size_t)i * n;
+    poly[L.lk0 + 3 * i + 1] = la + (size_t)i * n;
+    poly[L.lk0 + 3 * i + 2] = ls + (size_t)i * n;
   }
   F pt[N_ROT_IDS];
   pt[ROT_0] = x;
@@ -844,5 +959,8 @@ CPU_EXPORT int cpu_prove(const cpu_pk *pk, const char *input_json, const uint8_t
 }
 
 CPU_EXPORT int cpu_prover_threads(void) { return omp_get_max_threads(); }
+CPU_EXPORT void cpu_prover_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+}
 
 }  // extern "C"

@@ -43,6 +43,9 @@ def lib():
         so = os.path.join(_HERE, "libcpuprover.so")
         if not os.path.exists(so):
             build()
+        # idle OpenMP workers sleep instead of spinning through the serial stretches (witness generation, transcript):
+        # on a box whose container has fewer CPUs than it shows, spinning threads starve the working ones
+        os.environ.setdefault("KMP_BLOCKTIME", "0")
         L = ctypes.CDLL(so)
         L.cpu_pk_create.restype = ctypes.c_void_p
         L.cpu_pk_create.argtypes = [ctypes.POINTER(_Cfg), ctypes.c_char_p, ctypes.c_char_p] + [ctypes.c_void_p] * 7 + [ctypes.c_char_p, ctypes.c_size_t]
@@ -56,6 +59,29 @@ def lib():
 
 def threads():
     return int(lib().cpu_prover_threads())
+
+
+def set_threads(n):
+    lib().cpu_prover_set_threads(int(n))
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def seed32(seed):
