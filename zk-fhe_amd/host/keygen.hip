@@ -156,6 +156,17 @@ static int build_resident_tables(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * wext;
     }
+    if (pk->ext_rows == 3) {
+      // the three-coset quotient's interpolation back to coefficients (prove.hip, k_ext3_combine) multiplies row t by
+      // (g w_ext^t)^-i: constant per key, so the powers are resident instead of three launches per proof
+      CK(pk->ext3_pw.alloc(ctx, 3 * n * 32));
+      Fr gk = mont_u64(COSET_G);
+      for (int t = 0; t < 3; ++t) {
+        zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(Fr::one(), fr_inv(gk), pk->ext3_pw.fr() + (size_t)t * n, n);
+        ZK_LAUNCH_CHECK(ctx);
+        gk = gk * wext;
+      }
+    }
   }
   return ZKFHE_OK;
 }
@@ -300,7 +311,7 @@ int zkfhe_bfv_pk_destroy(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk) {
   ZK_ENTER(ctx);
   if (!pk) return ZKFHE_OK;
   zkfhe_sync(ctx);
-  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow,
+  DevBuf *bufs[] = {&pk->fixed_l, &pk->sigma_l, &pk->fixed_ext, &pk->sigma_ext, &pk->l_ext, &pk->xs_ext, &pk->dpow, &pk->ext3_pw,
                     &pk->lookup_src, &pk->inv_slots, &pk->place_start, &pk->place_len};
   for (DevBuf *b : bufs) b->release();
   for (auto &kv : pk->workspaces) free_workspace(kv.second);

@@ -908,7 +908,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     } else {
       // three size-n inverse transforms, then the 3x3 Vandermonde solve per coefficient (prover_kernels.hip.hpp: k_ext3_combine)
       Fr *rows3 = ws->partials.fr();            // the partials are dead after the combine; 3n values
-      Fr *pw = rows3 + 4 * n;                    // 3n values
+      const Fr *pw = pk->ext3_pw.fr();           // (g w_ext^t)^-i, resident in the key
       CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)ws->h_ext.p, (zkfhe_fr *)rows3, 3, (int)k, 1));
       Fr gk[3], c[3];
       gk[0] = g;
@@ -926,10 +926,6 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
           vinv.v[1 * 3 + k1] = (Fr::zero() - (a + b)) * den;  // X^1
           vinv.v[2 * 3 + k1] = den;                      // X^2
         }
-      }
-      for (int t = 0; t < 3; ++t) {
-        zkp::k_powers<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(Fr::one(), fr_inv(gk[t]), pw + (size_t)t * n, n);
-        ZK_LAUNCH_CHECK(ctx);
       }
       zkp::k_ext3_combine<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(rows3, pw, vinv, n, ws->h_c.fr());
       ZK_LAUNCH_CHECK(ctx);

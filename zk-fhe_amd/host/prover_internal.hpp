@@ -230,7 +230,7 @@ struct GpuPolyMul : PolyMulBackend {
 struct zkfhe_bfv_pk {
   CircuitConfig cfg;
   BfvParams prm;
-  DevBuf fixed_l, sigma_l, fixed_ext, sigma_ext, l_ext, xs_ext, dpow;
+  DevBuf fixed_l, sigma_l, fixed_ext, sigma_ext, l_ext, xs_ext, dpow, ext3_pw;
   std::vector<AffinePoint> fixed_commit, sigma_commit;
   U256 vk_digest;
   // structure of the phase-1 gate stream, recorded at keygen for the GPU witness generator
