@@ -443,9 +443,45 @@ def test_k14_proof_bytes_match_oracle(ctx):
     srs.destroy()
 
 
-def _prove_and_verify_large(ctx, N, k, tag):
-    """Large configurations: the CPU oracle prover would take minutes, so the check is: the GPU proof is accepted by the
-    oracle VERIFIER (pairing check) against the commitments of the GPU keygen, and a tampered proof is not."""
+def native_cpu_proof(pk, hcfg, prm, text, seed, tmp_dir):
+    """The same proof by the native CPU prover (oracle/cpu_prover.cpp: the oracle's 64-bit-limb arithmetic, its own Pippenger,
+    NTT, quotient and SHPLONK loops), fed with the fixed / sigma columns of the GPU key (read back from the key file, whose
+    last section holds them) and the oracle's SRS for the same seed.  Parity of the PROVER at sizes the Python oracle prover
+    cannot reach in reasonable time; the keygen itself is compared with the oracle's at k = 13 / 14."""
+    import types
+    import numpy as np
+    from oracle import binding as orc
+    from oracle import cpu_prover as CP
+    n = hcfg.n
+    path = os.path.join(tmp_dir, "key.pk")
+    pk.save(path)
+    tail = (hcfg.n_fixed + hcfg.n_perm) * n * 32
+    with open(path, "rb") as f:
+        f.seek(-tail, os.SEEK_END)
+        cols = np.frombuffer(f.read(tail), dtype=np.uint64).reshape(hcfg.n_fixed + hcfg.n_perm, n, 4)
+    os.remove(path)
+    fixed_l, sigma_l = cols[: hcfg.n_fixed], cols[hcfg.n_fixed:]
+    lag = np.zeros((3, n, 4), dtype=np.uint64)
+    one = H.M(1)
+    lag[0, 0] = one
+    lag[1, hcfg.u] = one
+    lag[2, : hcfg.u] = one
+    info = pk.info()
+    key = types.SimpleNamespace(fixed_lagrange=fixed_l, sigma_lagrange=sigma_l, fixed_coeff=orc.ntt(fixed_l, hcfg.k, True),
+                                sigma_coeff=orc.ntt(sigma_l, hcfg.k, True), l_coeff=orc.ntt(lag, hcfg.k, True),
+                                vk_digest=info["vk_digest"], break_points=info["break_points"])
+    cp = CP.CpuProver(hcfg, key, H.make_srs(hcfg.k), prm)
+    CP.set_threads(CP.usable_cpus())
+    proof = cp.prove(text, seed)
+    print("native CPU prover, k = %d: %s ms" % (hcfg.k, {k2: round(v) for k2, v in cp.phase_ms.items()}))
+    cp.close()
+    return proof
+
+
+def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
+    """Large configurations: the Python oracle prover would take many minutes, so the checks are: the GPU proof is accepted by
+    the oracle VERIFIER (pairing check) against the commitments of the GPU keygen, a tampered proof is not, and (tmp_dir given)
+    the proof equals the native CPU prover's byte for byte."""
     import numpy as np
     import zk_fhe_amd as zk
     Q, T, B = (1 << 60) - 93, 7, 19
@@ -492,6 +528,10 @@ def _prove_and_verify_large(ctx, N, k, tag):
     vkb = pk.export_vk()
     ok, why = zk.bfv_verify(vkb, inst, proof)
     assert ok, why
+    if tmp_dir is not None:
+        import types
+        proof_c = native_cpu_proof(pk, hcfg, types.SimpleNamespace(N=N, Q=Q, T=T, B=B), text, tag.encode(), str(tmp_dir))
+        assert first_diff(proof, proof_c) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_c)
     # negative coverage at this size: a flipped bit in a commitment, an evaluation and both opening points, and a changed
     # public input -- each rejected by the oracle verifier and by the C++ verifier
     for pos in (5, len(proof) // 2, len(proof) - 40, len(proof) - 1):
@@ -507,13 +547,14 @@ def _prove_and_verify_large(ctx, N, k, tag):
     return (n0, n1, nl, nr), probe["cells"]
 
 
-def test_config4_k16_n4096_60bit_modulus(ctx):
-    """BASELINE config 4: N = 4096, 60-bit Q (witness values up to 132 bits), k = 16."""
-    cols, cells = _prove_and_verify_large(ctx, 4096, 16, "config4")
+def test_config4_k16_n4096_60bit_modulus(ctx, tmp_path):
+    """BASELINE config 4: N = 4096, 60-bit Q (witness values up to 132 bits), k = 16: accepted by both verifiers and
+    byte-identical to the native CPU prover's proof."""
+    cols, cells = _prove_and_verify_large(ctx, 4096, 16, "config4", tmp_path)
     assert cols == (2, 124, 34, 3) and cells[1] == 8073420     # the shape SURVEY.md section 8d predicts
 
 
-def test_config5_k19_n16384(ctx):
+def test_config5_k19_n16384(ctx, tmp_path):
     """BASELINE config 5: N = 16384, k = 19 (n = 524288 rows): MSM-dominated, long-row NTTs everywhere."""
-    cols, cells = _prove_and_verify_large(ctx, 16384, 19, "config5")
+    cols, cells = _prove_and_verify_large(ctx, 16384, 19, "config5", tmp_path)
     assert cols[1] <= 64
