@@ -174,6 +174,12 @@ for fn, cmd in (('bench_driver', "`python bench.py --steps 20 --warmup 5` (the d
     lines.append("| %s | %.2f | %.2f | %s | %s | %.1f | %s: %.3f, %.2f |" % (
         cmd, d['value'], d['ms_per_step'], c['concurrent_proofs_per_gpu'], ('%.1f' % c['steady_state_proofs_per_s']) if c['steady_state_proofs_per_s'] else '-',
         c['host_cpu_ms_per_proof'], r['kernel'], r['avg_launch_ms'], r['int_alu']['frac']))
+dd = jl('bench_driver.json')
+if dd and dd.get('cpu_baseline'):
+    cb = dd['cpu_baseline']
+    lines += ["", "`cpu_baseline` of the driver's command: %.3f %s on %s threads (`kind: %s`) -- %s.  Seconds per proof by thread count: %s; "
+              "phases of the last proof (ms): %s." % (cb['value'], cb['unit'], cb['cores'], cb['kind'], cb['sample'], cb.get('seconds_per_proof_by_threads'),
+                                                      cb.get('phase_ms_last_proof'))]
 lines += ["", "The full JSON line of the driver's command:", "", "```", rd('bench_driver.json').strip().splitlines()[-1] if os.path.exists(R + 'bench_driver.json') else '', "```", ""]
 open(P + 'r3_bench_lines.md', 'w').write('\n'.join(lines))
 open(P + 'r3_microbench.md', 'w').write("# r3 -- micro-benchmarks (`python tools/microbench.py`, MI355X box; the NTT sweep runs out of place: `zkfhe_ntt_batch_to`)\n\n```\n" + rd('microbench.json') + "```\n")
