@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="k13", help="k13 = the headline (BASELINE configs[1]); k16 / k19 = configs[3] / [4], single GPU")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra, separately reported steady-state pass (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stagger-ms", type=float, default=None, help="start offset between the concurrent proofs of the timed wave")
     ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
                     help="Fiat-Shamir hash: poseidon = snark-verifier PoseidonTranscript (the reference's, examples/bfv.rs:311); blake2b = halo2's own")
     args = ap.parse_args()
@@ -148,7 +149,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
-    batch.run_concurrent(list(range(si, si + args.steps)), ctxs, one_proof)   # exactly K proofs, n_streams in flight
+    batch.run_concurrent(list(range(si, si + args.steps)), ctxs, one_proof, stagger_s=(args.stagger_ms or 0.0) * 1e-3)   # exactly K proofs, n_streams in flight
     for c in ctxs:
         c.sync()
     barrier()

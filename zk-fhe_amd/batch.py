@@ -6,6 +6,7 @@ communication is collecting the <= 62 KB proofs (all_gather_object) and the max-
 Works with the gloo backend on CPU (tests) and nccl (= RCCL) on GPUs.
 """
 import threading
+import time
 
 
 def shard_indices(n_items, rank, world):
@@ -13,15 +14,19 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def run_concurrent(jobs, workers, fn):
+def run_concurrent(jobs, workers, fn, stagger_s=0.0):
     """Run fn(worker, job) for every job, `len(workers)` at a time (one thread per worker, jobs pulled from a shared
-    counter).  Returns results in job order; the first exception is re-raised."""
+    counter).  Returns results in job order; the first exception is re-raised.  stagger_s > 0 starts worker i that many
+    seconds after worker i - 1: proofs that start together reach every Fiat-Shamir round together and leave the GPU idle
+    while all of them hash; a small offset keeps some of them in a kernel phase while others are on the host."""
     results = [None] * len(jobs)
     lock = threading.Lock()
     nxt = [0]
     errs = []
 
-    def loop(w):
+    def loop(w, delay=0.0):
+        if delay > 0:
+            time.sleep(delay)
         while True:
             with lock:
                 j = nxt[0]
@@ -34,7 +39,7 @@ def run_concurrent(jobs, workers, fn):
                 with lock:
                     errs.append(e)
                 return
-    ths = [threading.Thread(target=loop, args=(w,)) for w in workers]
+    ths = [threading.Thread(target=loop, args=(w, i * stagger_s)) for i, w in enumerate(workers)]
     for t in ths:
         t.start()
     for t in ths:
