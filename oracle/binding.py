@@ -16,7 +16,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "witness_ref.c", "bn254_ref.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "bn254_ref.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
