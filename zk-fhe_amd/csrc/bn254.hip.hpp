@@ -206,30 +206,37 @@ ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
   fp_reduce_once<P>(o.l);
   return o;
 #else
-  u32 t[9];
-  for (int i = 0; i < 9; ++i) t[i] = 0;
-  for (int i = 0; i < 8; ++i) {
-    u64 c = 0;
-    const u32 bi = b.l[i];
-    for (int j = 0; j < 8; ++j) {
-      c = (u64)a.l[j] * bi + ((u64)t[j] + c);
-      t[j] = (u32)c;
-      c >>= 32;
-    }
-    t[8] += (u32)c;
-    const u32 m = t[0] * P::INV;
-    c = ((u64)m * P::MOD[0] + t[0]) >> 32;
-    for (int j = 1; j < 8; ++j) {
-      c = (u64)m * P::MOD[j] + ((u64)t[j] + c);
-      t[j - 1] = (u32)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[7] = (u32)c;
-    t[8] = (u32)(c >> 32);
+  // host: CIOS on four 64-bit limbs (the 32-bit limb array read as little-endian u64 pairs), fully unrolled by the compiler;
+  // p < 2^254, so the running value fits four limbs and the carry word
+  typedef unsigned __int128 u128;
+  u64 A[4], B[4], Pm[4];
+  for (int i = 0; i < 4; ++i) {
+    A[i] = (u64)a.l[2 * i] | ((u64)a.l[2 * i + 1] << 32);
+    B[i] = (u64)b.l[2 * i] | ((u64)b.l[2 * i + 1] << 32);
+    Pm[i] = (u64)P::MOD[2 * i] | ((u64)P::MOD[2 * i + 1] << 32);
+  }
+  // -p^-1 mod 2^64 from the 32-bit constant: one Newton step (x <- x (2 + p x), x = -p^-1 mod 2^32 doubles its valid bits)
+  const u64 inv32 = (u64)P::INV;
+  const u64 inv = inv32 * (2 + Pm[0] * inv32);
+  u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 c;
+    const u64 bi = B[i];
+    c = (u128)A[0] * bi + t0; t0 = (u64)c;
+    c = (u128)A[1] * bi + t1 + (u64)(c >> 64); t1 = (u64)c;
+    c = (u128)A[2] * bi + t2 + (u64)(c >> 64); t2 = (u64)c;
+    c = (u128)A[3] * bi + t3 + (u64)(c >> 64); t3 = (u64)c;
+    const u64 t4 = (u64)(c >> 64);
+    const u64 m = t0 * inv;
+    c = (u128)m * Pm[0] + t0;
+    c = (u128)m * Pm[1] + t1 + (u64)(c >> 64); t0 = (u64)c;
+    c = (u128)m * Pm[2] + t2 + (u64)(c >> 64); t1 = (u64)c;
+    c = (u128)m * Pm[3] + t3 + (u64)(c >> 64); t2 = (u64)c;
+    t3 = t4 + (u64)(c >> 64);
   }
   Fp<P> r;
-  for (int i = 0; i < 8; ++i) r.l[i] = t[i];
+  r.l[0] = (u32)t0, r.l[1] = (u32)(t0 >> 32), r.l[2] = (u32)t1, r.l[3] = (u32)(t1 >> 32);
+  r.l[4] = (u32)t2, r.l[5] = (u32)(t2 >> 32), r.l[6] = (u32)t3, r.l[7] = (u32)(t3 >> 32);
   fp_reduce_once<P>(r.l);
   return r;
 #endif
