@@ -255,14 +255,29 @@ class GpuPhase1 {
   // evals[3 i .. 3 i + 2] = a(gamma), b(gamma), c(gamma) of the i-th constrain_mul: fill the reserved gate cells, then
   // stream -> gate columns (break points) and lookup columns
   int finish(const U256 evals[12]) {
-    Fr *mg_host = (Fr *)(ws->host_pool + mg_slot);
+    // the 16 values and their destinations go up with the staging ring, one small kernel stores them (it used to be one
+    // upload and four device copies)
+    Fr mg[16];
     for (int i = 0; i < 4; ++i) {
-      mg_host[4 * i] = Fr::zero();
-      for (int j = 0; j < 3; ++j) mg_host[4 * i + 1 + j] = mont(evals[3 * i + j]);
+      mg[4 * i] = Fr::zero();
+      for (int j = 0; j < 3; ++j) mg[4 * i + 1 + j] = mont(evals[3 * i + j]);
     }
-    ZK_HIP(ctx, hipMemcpyAsync(ws->pool.fr() + mg_slot, mg_host, 16 * 32, hipMemcpyHostToDevice, ctx->stream));
+    zkw::PatchCell cells[16];
+    unsigned nc = 0;
     for (unsigned i = 0; i < n_mg; ++i)
-      ZK_HIP(ctx, hipMemcpyAsync(stream + mg_off[i], ws->pool.fr() + mg_slot + 4 * i, 4 * 32, hipMemcpyDeviceToDevice, ctx->stream));
+      for (unsigned j = 0; j < 4; ++j) {
+        cells[nc].dst_adv = stream + mg_off[i] + j;
+        cells[nc].dst_patch = nullptr;
+        cells[nc].value = 4 * i + j;
+        ++nc;
+      }
+    if (nc) {
+      STAGE(vals_dev, Fr, ws, mg, sizeof(mg));
+      STAGE(cells_dev, zkw::PatchCell, ws, cells, nc * sizeof(zkw::PatchCell));
+      CK(flush_staged(ctx, ws));
+      zkw::k_patch_cells<<<1, 64, 0, ctx->stream>>>(cells_dev, nc, vals_dev);
+      ZK_LAUNCH_CHECK(ctx);
+    }
     return place();
   }
 
