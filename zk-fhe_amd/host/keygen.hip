@@ -60,6 +60,8 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int e
     take(ws->lz_l, ws->lz_ext, c.n_lookup);
     take(ws->inst_l, ws->inst_ext, 1);
   }
+  ZK_HIP(ctx, hipMemsetAsync(ws->inst_l.p, 0, col, ctx->stream));   // the prover only ever writes the public-input rows
+  ws->inst_count = 0;
   CK(ws->tmp_c.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * col));
   CK(ws->partials.alloc(ctx, 96 * 4 * col));
   CK(ws->h_ext.alloc(ctx, 4 * col));

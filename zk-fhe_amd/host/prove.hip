@@ -519,6 +519,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Assigner as(cfg, false, ws->host_adv);
   as.place(ctx0, true);
   trace.mark("place phase 0");
+  // the instance column's values ride up with the proof's first table flush (they are needed from the grand products on)
+  if (instances.size() > n) return zk_fail_msg(ctx, ZKFHE_EINVAL, "more public inputs than rows");
+  const bool inst_via_ring = instances.size() * 32 <= ((size_t)1 << 20);   // long instance columns (k >= 18) keep their own copy
+  const U256 *inst_staged = nullptr;
+  if (inst_via_ring) {
+    STAGE(staged, U256, ws, instances.data(), instances.size() * 32);
+    inst_staged = staged;
+  }
   auto blind_and_upload = [&](unsigned c_lo, unsigned c_hi) -> int {
     // the table is pinned and column-contiguous: one DMA for the whole phase; the blinding rows u .. n-1 are drawn on the device
     ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c_lo * n, as.t.advice[c_lo], (size_t)(c_hi - c_lo) * n * 32, hipMemcpyHostToDevice, ctx->stream));
@@ -707,9 +715,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const Fr beta = mont(beta_c), gamma = mont(gamma_c);
   // ------------------------------------------------------------ permutation grand products
   {
-    std::vector<U256> inst_col(n, fe::zero());
-    std::copy(instances.begin(), instances.end(), inst_col.begin());
-    CK(upload_canon(ctx, ws->inst_l.fr(), inst_col.data(), n));
+    if (instances.size() < ws->inst_count)
+      ZK_HIP(ctx, hipMemsetAsync(ws->inst_l.fr() + instances.size(), 0, (ws->inst_count - instances.size()) * 32, ctx->stream));
+    if (inst_via_ring) {
+      CK(flush_staged(ctx, ws));   // nothing to send when an earlier round's flush took the values along
+      if (!instances.empty()) CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)inst_staged, (zkfhe_fr *)ws->inst_l.p, instances.size()));
+    } else {
+      CK(upload_canon(ctx, ws->inst_l.fr(), instances.data(), instances.size()));
+    }
+    ws->inst_count = instances.size();
   }
   U256 dcan;
   memcpy(dcan.l, DELTA_CANON, 32);

@@ -85,6 +85,7 @@ struct Workspace {
   // same order on the extended coset (all_ext) -- one iNTT launch and one coset-NTT launch cover all of them
   DevBuf all_l, all_ext;
   View adv_l, la_l, ls_l, pz_l, lz_l, inst_l, adv_ext, la_ext, ls_ext, pz_ext, lz_ext, inst_ext;
+  size_t inst_count = 0;   // rows of inst_l that hold public inputs of the last proof; the rest of the column is zero since allocation
   size_t n_all = 0;
   U256 *host_adv = nullptr;    // pinned [n_advice][n] witness table, reused by every proof on this context
   U256 *host_blind = nullptr;  // pinned staging for blinding rows / permuted lookup columns
