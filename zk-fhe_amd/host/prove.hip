@@ -99,13 +99,32 @@ class GpuPhase1 {
     calls.clear();
     call_level.clear();
     produced.clear();
-    // inputs: one pinned staging block, one DMA
+    // inputs: one pinned staging block.  While they fit (k = 13: 0.66 MB) the block is a piece of the proof's staging ring and
+    // goes up with the gadget arguments in ONE copy; longer inputs keep their own block and their own DMA.
     h_used = 0;
+    {
+      const PolyChip *ins[14] = {&st.e0, &st.e1, &st.u, &st.m, &st.pk0_u, &st.quotient_0, &st.remainder_0, &st.quotient_0_times_cyclo, &st.expected_c0,
+                                 &st.pk1_u, &st.quotient_1, &st.remainder_1, &st.quotient_1_times_cyclo, &st.expected_c1};
+      size_t cells = 1 + 16;   // delta, the reserved gate cells
+      for (const PolyChip *pc : ins) cells += pc->assigned_coefficients.size();
+      in_host = ws->host_pool;
+      in_dev = ws->pool.fr();
+      in_ring = false;
+      void *h = nullptr;
+      if (cells * 32 <= ((size_t)1 << 20)) {
+        void *d = stage_reserve(ws, cells * 32, &h);
+        if (d) {
+          in_host = (U256 *)h;
+          in_dev = (Fr *)d;
+          in_ring = true;
+        }
+      }
+    }
     DevPoly e0 = stage(st.e0), e1 = stage(st.e1), u = stage(st.u), m = stage(st.m);
     DevPoly pk0_u = stage(st.pk0_u), q0 = stage(st.quotient_0), r0 = stage(st.remainder_0), q0c = stage(st.quotient_0_times_cyclo), xc0 = stage(st.expected_c0);
     DevPoly pk1_u = stage(st.pk1_u), q1 = stage(st.quotient_1), r1 = stage(st.remainder_1), q1c = stage(st.quotient_1_times_cyclo), xc1 = stage(st.expected_c1);
-    ws->host_pool[h_used] = st.delta.value;
-    const Fr *delta = ws->pool.fr() + h_used;
+    in_host[h_used] = st.delta.value;
+    const Fr *delta = in_dev + h_used;
     const uint64_t delta_bits = st.delta.value.bits();
     ++h_used;
     pool_used = h_used;
@@ -114,7 +133,7 @@ class GpuPhase1 {
     n_mg = 0;
     h_used += 16;
     pool_used = h_used;
-    ZK_HIP(ctx, hipMemcpyAsync(ws->pool.p, ws->host_pool, mg_slot * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (!in_ring) ZK_HIP(ctx, hipMemcpyAsync(ws->pool.p, ws->host_pool, mg_slot * 32, hipMemcpyHostToDevice, ctx->stream));
 
     CK(in_range(e0, B, Q));
     CK(in_range(e1, B, Q));
@@ -304,13 +323,16 @@ class GpuPhase1 {
   Fr *stream = nullptr;
   size_t off = 0, pool_used = 0, h_used = 0, mg_slot = 0, mg_off[4] = {0, 0, 0, 0};
   unsigned n_mg = 0;
+  U256 *in_host = nullptr;   // where the input polynomials are staged on the host ...
+  Fr *in_dev = nullptr;      // ... and where the gadgets read them
+  bool in_ring = false;
 
   DevPoly stage(const PolyChip &p) {
     DevPoly d;
     d.len = p.assigned_coefficients.size();
     d.bits = p.max_num_bits;
-    d.d = ws->pool.fr() + h_used;
-    for (size_t i = 0; i < d.len; ++i) ws->host_pool[h_used + i] = p.assigned_coefficients[i].value;
+    d.d = in_dev + h_used;
+    for (size_t i = 0; i < d.len; ++i) in_host[h_used + i] = p.assigned_coefficients[i].value;
     h_used += d.len;
     return d;
   }
@@ -1306,6 +1328,7 @@ int zkfhe_bfv_witness_stream(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk_c, const cha
     memcpy(gamma.l, gamma_le, 32);
     if (!(gamma < fe::MOD)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "gamma is not a canonical Fr value");
     CK(alloc_witness_buffers(ctx, pk, ws));
+    ws->ring_off = ws->ring_flushed = 0;   // the stream is idle (synchronised above): the staging ring starts over, as in a proof
     GpuPhase1 g1(ctx, pk, ws);
     CK(g1.launch(st));
     bfv_phase1_rlc(st, ctx_rlc, gamma, evals);

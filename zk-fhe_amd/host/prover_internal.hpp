@@ -187,6 +187,15 @@ static inline void *stage_table(Workspace *ws, const void *src, size_t bytes) {
   ws->ring_off += need;
   return dev;
 }
+// The same for a block the caller fills in place before the next flush_staged(): *host = where to write, returns the device address
+static inline void *stage_reserve(Workspace *ws, size_t bytes, void **host) {
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (!ws->ring || !ws->dev_ring.p || ws->ring_off + need > Workspace::RING_BYTES) return nullptr;
+  *host = ws->ring + ws->ring_off;
+  void *dev = (char *)ws->dev_ring.p + ws->ring_off;
+  ws->ring_off += need;
+  return dev;
+}
 static inline int flush_staged(zkfhe_ctx *ctx, Workspace *ws) {
   if (ws->ring_off > ws->ring_flushed) {
     ZK_HIP(ctx, hipMemcpyAsync((char *)ws->dev_ring.p + ws->ring_flushed, ws->ring + ws->ring_flushed, ws->ring_off - ws->ring_flushed, hipMemcpyHostToDevice, ctx->stream));
