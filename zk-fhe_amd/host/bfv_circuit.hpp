@@ -3,6 +3,7 @@
 // host.  The operation order below fixes the cell stream, which the reference's configs/bfv.json pins.
 #pragma once
 #include <chrono>
+#include <exception>
 #include <cstdio>
 #include <thread>
 #include <array>
@@ -31,19 +32,16 @@ struct CircuitInput {
   std::vector<std::string> pk0, pk1, m, u, e0, e1, c0, c1, cyclo;
 
   static CircuitInput parse_json(const std::string &text) {
-    // minimal parser for {"name": ["123", ...], ...}
-    std::map<std::string, std::vector<std::string>> kv;
+    // minimal parser for {"name": ["123", ...], ...}.  Pass 1 walks the object and records where each array's text lies (the
+    // values are decimal strings: no escapes, no nesting); pass 2 turns every array into its strings -- one thread per array
+    // once the text is long (N = 16384: 2.8 MB, 8 ms on one core).
+    struct Span {
+      std::string key;
+      size_t lo, hi;   // text between '[' and ']'
+    };
+    std::vector<Span> spans;
     size_t i = 0;
     auto skip = [&]() { while (i < text.size() && isspace((unsigned char)text[i])) ++i; };
-    auto str = [&]() {
-      skip();
-      if (i >= text.size() || text[i] != '"') throw std::runtime_error("input JSON: expected string");
-      size_t j = text.find('"', i + 1);
-      if (j == std::string::npos) throw std::runtime_error("input JSON: unterminated string");
-      std::string s = text.substr(i + 1, j - i - 1);
-      i = j + 1;
-      return s;
-    };
     auto expect = [&](char c) {
       skip();
       if (i >= text.size() || text[i] != c) throw std::runtime_error(std::string("input JSON: expected '") + c + "'");
@@ -52,30 +50,77 @@ struct CircuitInput {
     expect('{');
     skip();
     while (i < text.size() && text[i] != '}') {
-      std::string key = str();
+      skip();
+      if (i >= text.size() || text[i] != '"') throw std::runtime_error("input JSON: expected string");
+      const size_t j = text.find('"', i + 1);
+      if (j == std::string::npos) throw std::runtime_error("input JSON: unterminated string");
+      Span sp;
+      sp.key = text.substr(i + 1, j - i - 1);
+      i = j + 1;
       expect(':');
       expect('[');
-      std::vector<std::string> arr;
-      skip();
-      while (i < text.size() && text[i] != ']') {
-        arr.push_back(str());
-        skip();
-        if (i < text.size() && text[i] == ',') ++i;
-        skip();
-      }
-      expect(']');
-      kv[key] = std::move(arr);
+      sp.lo = i;
+      const size_t close = text.find(']', i);
+      if (close == std::string::npos) throw std::runtime_error("input JSON: expected ']'");
+      sp.hi = close;
+      i = close + 1;
+      spans.push_back(std::move(sp));
       skip();
       if (i < text.size() && text[i] == ',') ++i;
       skip();
     }
+    auto parse_array = [&text](size_t lo, size_t hi, std::vector<std::string> &arr) {
+      size_t commas = 0;
+      for (size_t q = lo; q < hi; ++q) commas += text[q] == ',';
+      arr.reserve(commas + 1);
+      size_t q = lo;
+      auto skipw = [&]() { while (q < hi && isspace((unsigned char)text[q])) ++q; };
+      skipw();
+      while (q < hi) {
+        if (text[q] != '"') throw std::runtime_error("input JSON: expected string");
+        const size_t e = text.find('"', q + 1);
+        if (e == std::string::npos || e >= hi) throw std::runtime_error("input JSON: unterminated string");
+        arr.emplace_back(text, q + 1, e - q - 1);
+        q = e + 1;
+        skipw();
+        if (q < hi && text[q] == ',') ++q;
+        skipw();
+      }
+    };
     CircuitInput in;
     const char *names[9] = {"pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo"};
     std::vector<std::string> *dst[9] = {&in.pk0, &in.pk1, &in.m, &in.u, &in.e0, &in.e1, &in.c0, &in.c1, &in.cyclo};
+    const Span *src[9];
     for (int k = 0; k < 9; ++k) {
-      auto it = kv.find(names[k]);
-      if (it == kv.end()) throw std::runtime_error(std::string("input JSON: missing field ") + names[k]);
-      *dst[k] = it->second;
+      src[k] = nullptr;
+      for (const Span &sp : spans)
+        if (sp.key == names[k]) src[k] = &sp;   // a repeated key: the last one counts, as with a map
+      if (!src[k]) throw std::runtime_error(std::string("input JSON: missing field ") + names[k]);
+    }
+    for (const Span &sp : spans) {   // fields the circuit does not read are still checked for form
+      bool used = false;
+      for (int k = 0; k < 9; ++k) used = used || src[k] == &sp;
+      if (!used) {
+        std::vector<std::string> ignored;
+        parse_array(sp.lo, sp.hi, ignored);
+      }
+    }
+    if (text.size() < ((size_t)1 << 18)) {
+      for (int k = 0; k < 9; ++k) parse_array(src[k]->lo, src[k]->hi, *dst[k]);
+    } else {
+      std::exception_ptr err[9];
+      std::thread th[9];
+      for (int k = 0; k < 9; ++k)
+        th[k] = std::thread([&, k] {
+          try {
+            parse_array(src[k]->lo, src[k]->hi, *dst[k]);
+          } catch (...) {
+            err[k] = std::current_exception();
+          }
+        });
+      for (auto &t : th) t.join();
+      for (int k = 0; k < 9; ++k)
+        if (err[k]) std::rethrow_exception(err[k]);
     }
     return in;
   }
@@ -111,15 +156,29 @@ inline BfvState bfv_phase0(Context &ctx, const CircuitInput &input, const BfvPar
     fprintf(stderr, "[phase0] +%.3f ms %s\n", t - tl, w);
     tl = t;
   };
-  Poly pk0_un = Poly::from_string(input.pk0, Q);
-  Poly pk1_un = Poly::from_string(input.pk1, Q);
-  Poly m_un = Poly::from_string(input.m, Q);
-  Poly u_un = Poly::from_string(input.u, Q);
-  Poly e0_un = Poly::from_string(input.e0, Q);
-  Poly e1_un = Poly::from_string(input.e1, Q);
-  Poly c0_un = Poly::from_string(input.c0, Q);
-  Poly c1_un = Poly::from_string(input.c1, Q);
-  Poly cyclo_un = Poly::from_string(input.cyclo, Q);
+  Poly pk0_un, pk1_un, m_un, u_un, e0_un, e1_un, c0_un, c1_un, cyclo_un;
+  {
+    // examples/bfv.rs:71-79: nine independent decimal-to-integer conversions; on their own threads once they are long
+    const std::vector<std::string> *src[9] = {&input.pk0, &input.pk1, &input.m, &input.u, &input.e0, &input.e1, &input.c0, &input.c1, &input.cyclo};
+    Poly *dst[9] = {&pk0_un, &pk1_un, &m_un, &u_un, &e0_un, &e1_un, &c0_un, &c1_un, &cyclo_un};
+    if (N < 4096) {
+      for (int k = 0; k < 9; ++k) *dst[k] = Poly::from_string(*src[k], Q);
+    } else {
+      std::exception_ptr err[9];
+      std::thread th[9];
+      for (int k = 0; k < 9; ++k)
+        th[k] = std::thread([&, k] {
+          try {
+            *dst[k] = Poly::from_string(*src[k], Q);
+          } catch (...) {
+            err[k] = std::current_exception();
+          }
+        });
+      for (auto &t : th) t.join();
+      for (int k = 0; k < 9; ++k)
+        if (err[k]) std::rethrow_exception(err[k]);
+    }
+  }
   mark("from_string x9");
   ZK_ASSERT(pk0_un.deg() == N - 1 && pk1_un.deg() == N - 1 && m_un.deg() == N - 1 && u_un.deg() == N - 1 && e0_un.deg() == N - 1 &&
                 e1_un.deg() == N - 1 && c0_un.deg() == N - 1 && c1_un.deg() == N - 1,
