@@ -42,8 +42,11 @@ namespace {
 
 // one radix-2 DIF stage over vectors of length n (all columns): pairs (j, j+half) inside blocks of 2*half
 //   a' = a + b ; b' = (a - b) * omega_n^(j * n/(2*half)),  j = index inside the half
+// pre != nullptr (first pass of a coset extension): the n_cols transforms are `rows` coset rows of n_cols / rows input vectors;
+// transform c reads input vector c / rows and multiplies element i by pre[(c % rows) * n + i] on the way in (the coset powers).
 __global__ void __launch_bounds__(256) k_dif_stage(const Fr *src, Fr *data, size_t n_cols, int log_n, int log_half,
-                                                   const Fr *__restrict__ tw_n /* omega_n^j, j < n/2, 2^261 form */) {
+                                                   const Fr *__restrict__ tw_n /* omega_n^j, j < n/2, 2^261 form */,
+                                                   const Fr *__restrict__ pre = nullptr, unsigned rows = 1) {
   const size_t half = (size_t)1 << log_half;
   const size_t per_col = (size_t)1 << (log_n - 1);
   const size_t total = n_cols * per_col;
@@ -52,9 +55,19 @@ __global__ void __launch_bounds__(256) k_dif_stage(const Fr *src, Fr *data, size
     const size_t i = g & (per_col - 1);
     const size_t j = i & (half - 1);
     const size_t blk = i >> log_half;
-    const size_t o = (c << log_n) + (blk << (log_half + 1)) + j;
+    const size_t w = (blk << (log_half + 1)) + j;
+    const size_t o = (c << log_n) + w;
     Fr *p = data + o;
-    Fr x = src[o], y = src[o + half];   // src == data: in place
+    Fr x, y;
+    if (pre) {
+      const size_t cs = c / rows, k1 = c - cs * rows;
+      const Fr *ps = src + (cs << log_n) + w, *pp = pre + (k1 << log_n) + w;
+      x = fr29_mul_const(ps[0], pp[0]);
+      y = fr29_mul_const(ps[half], pp[half]);
+    } else {
+      x = src[o];   // src == data: in place
+      y = src[o + half];
+    }
     Fr s = x + y, d = x - y;
     const size_t e = j << (log_n - 1 - log_half);
     p[0] = s;
@@ -66,7 +79,8 @@ __global__ void __launch_bounds__(256) k_dif_stage(const Fr *src, Fr *data, size
 // 2^S elements base + m * 2^(log_half - S + 1) of one block of 2^(log_half + 1) and runs the S butterfly levels in
 // registers.  Long rows (k = 16 .. 19) used to make one full read+write of every column per stage.
 template <int S>
-__global__ void __launch_bounds__(256) k_dif_fused(const Fr *src, Fr *data, size_t n_cols, int log_n, int log_half, const Fr *__restrict__ tw_n) {
+__global__ void __launch_bounds__(256) k_dif_fused(const Fr *src, Fr *data, size_t n_cols, int log_n, int log_half, const Fr *__restrict__ tw_n,
+                                                   const Fr *__restrict__ pre = nullptr, unsigned rows = 1 /* as in k_dif_stage */) {
   constexpr int R = 1 << S;
   const int log_q = log_half - S + 1;            // distance between the elements of a thread
   const size_t q = (size_t)1 << log_q;
@@ -77,12 +91,20 @@ __global__ void __launch_bounds__(256) k_dif_fused(const Fr *src, Fr *data, size
     const size_t i = g & (per_col - 1);
     const size_t j0 = i & (q - 1);
     const size_t blk = i >> log_q;
-    const size_t o = (c << log_n) + (blk << (log_half + 1)) + j0;
+    const size_t w = (blk << (log_half + 1)) + j0;
+    const size_t o = (c << log_n) + w;
     Fr *p = data + o;
-    const Fr *ps = src + o;   // src == data: in place; otherwise the first pass of an out-of-place transform
     Fr x[R];
+    if (pre) {
+      const size_t cs = c / rows, k1 = c - cs * rows;
+      const Fr *ps = src + (cs << log_n) + w, *pp = pre + (k1 << log_n) + w;
 #pragma unroll
-    for (int m = 0; m < R; ++m) x[m] = ps[(size_t)m << log_q];
+      for (int m = 0; m < R; ++m) x[m] = fr29_mul_const(ps[(size_t)m << log_q], pp[(size_t)m << log_q]);
+    } else {
+      const Fr *ps = src + o;   // src == data: in place; otherwise the first pass of an out-of-place transform
+#pragma unroll
+      for (int m = 0; m < R; ++m) x[m] = ps[(size_t)m << log_q];
+    }
 #pragma unroll
     for (int t = 0; t < S; ++t) {
       constexpr int dummy = 0;
@@ -135,17 +157,6 @@ __global__ void __launch_bounds__(256) k_pow_table_scaled(Fr start, Fr base, Fr 
 // coefficient i1*n + i2 = g^-(i1*n+i2) * 2^-lef * sum_k1 A[k1][i2] * w_ext^(-k1 (i1*n + i2))
 //                       = scale[i1*n+i2] * sum_k1 (A[k1][i2] * w_ext^(-k1 i2)) * w_E^(-k1 i1),  E = 2^lef.
 // LEF in {1,2,3}.
-// large-n forward coset extension, step 1: out[c][k1][i] = in[c][i] * pre[k1][i]
-__global__ void __launch_bounds__(256) k_coset_prescale(const Fr *__restrict__ in, const Fr *__restrict__ pre, Fr *__restrict__ out, size_t n_cols,
-                                                        int log_n, int rows) {
-  const size_t n = (size_t)1 << log_n, ne = n * (size_t)rows;
-  const size_t total = n_cols * ne;
-  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-    const size_t c = g / ne, r = g - c * ne, i = r & (n - 1);
-    out[g] = fr29_mul_const(in[c * n + i], pre[r]);   // pre: 2^261 form
-  }
-}
-
 template <int LEF>
 __global__ void __launch_bounds__(256) k_ext_combine(const Fr *__restrict__ rows, Fr *__restrict__ out, size_t n_cols, int log_n,
                                                      const Fr *__restrict__ tw_ext_inv /* w_ext^-j, j < n*E */,
@@ -235,7 +246,7 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
 
 #define MAX_TILE_LOG 13
 
-int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse);
+int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse, const Fr *pre = nullptr, unsigned rows = 1);
 
 extern "C" {
 
@@ -247,9 +258,11 @@ int zkfhe_ntt_batch_to(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev
   return zk_ntt_impl(ctx, in_dev, out_dev, n_cols, log_n, inverse);
 }
 
-// src == nullptr: in place on cols_dev
-extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse) {
+// src == nullptr: in place on cols_dev.  pre (long rows, forward, out of place only): the n_cols transforms are `rows` coset rows
+// of the n_cols / rows vectors at src, each multiplied by its row of pre (2^261 form) while the first pass loads it.
+extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse, const Fr *pre, unsigned rows) {
   ZK_ENTER(ctx);
+  ZK_ARG(ctx, pre == nullptr || (src_dev != nullptr && !inverse && log_n > 13 && rows >= 1 && n_cols % rows == 0));
   ZK_ARG(ctx, log_n >= 1 && log_n <= 26);
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, cols_dev != nullptr);
@@ -336,10 +349,11 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
     unsigned grid = zk_blocks(wk, 256);
     unsigned cap = (unsigned)ctx->num_cu * 16;
     if (grid > cap) grid = cap;
-    if (S == 3) k_dif_fused<3><<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw);
-    else if (S == 2) k_dif_fused<2><<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw);
-    else k_dif_stage<<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw);
+    if (S == 3) k_dif_fused<3><<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw, pre, rows);
+    else if (S == 2) k_dif_fused<2><<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw, pre, rows);
+    else k_dif_stage<<<grid, 256, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw, pre, rows);
     ZK_LAUNCH_CHECK(ctx);
+    pre = nullptr;   // only the first pass reads the unscaled input
     pass_in = work;
     s -= S;
   }
@@ -395,16 +409,9 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
     }
   }
   if (log_n > MAX_TILE_LOG) {
-    unsigned gr = zk_blocks(n_cols * nr, 256);
-    const unsigned capg = (unsigned)ctx->num_cu * 16;
-    if (gr > capg) gr = capg;
-    // pre-scaled rows into a scratch arena, then one out-of-place transform of all of them into the destination
-    void *ps;
-    rc = zk_scratch(ctx, 2, n_cols * nr * sizeof(Fr), &ps);
-    if (rc) return rc;
-    k_coset_prescale<<<gr, 256, 0, ctx->stream>>>(in_dev, pre, (Fr *)ps, n_cols, log_n, rows);
-    ZK_LAUNCH_CHECK(ctx);
-    return zk_ntt_impl(ctx, (const zkfhe_fr *)ps, (zkfhe_fr *)out_dev, n_cols * (size_t)rows, log_n, 0);
+    // one out-of-place transform of all (column, coset) rows into the destination; its first pass multiplies by the coset powers
+    // as it loads (it used to be a separate pre-scaling pass through a scratch arena: one more read and write of every row)
+    return zk_ntt_impl(ctx, (const zkfhe_fr *)in_dev, (zkfhe_fr *)out_dev, n_cols * (size_t)rows, log_n, 0, pre, (unsigned)rows);
   }
   TileArgs a{};
   a.in = in_dev;
@@ -504,15 +511,7 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     }
     if (log_n > MAX_TILE_LOG) {
       // rows longer than one tile: pre-scale into the output rows, then a batched size-n NTT over all (column, k1) rows
-      unsigned gr = zk_blocks(n_cols * ne, 256);
-      const unsigned capg = (unsigned)ctx->num_cu * 16;
-      if (gr > capg) gr = capg;
-      void *ps;
-      rc = zk_scratch(ctx, 2, n_cols * ne * sizeof(Fr), &ps);
-      if (rc) return rc;
-      k_coset_prescale<<<gr, 256, 0, ctx->stream>>>((const Fr *)in_dev, pre, (Fr *)ps, n_cols, log_n, E);
-      ZK_LAUNCH_CHECK(ctx);
-      return zk_ntt_impl(ctx, (const zkfhe_fr *)ps, out_dev, n_cols * E, log_n, 0);
+      return zk_ntt_impl(ctx, in_dev, out_dev, n_cols * E, log_n, 0, pre, (unsigned)E);
     }
     TileArgs a{};
     a.in = (const Fr *)in_dev;
