@@ -74,6 +74,37 @@ def test_bad_inputs_fail_with_status():
         zk.bfv_build_tables(json.dumps(bad), PRM, zcfg, 1, True)
     with pytest.raises(zk.ZkfheError):
         zk.bfv_build_tables("{not json", PRM, zcfg, 1, True)
+    # the form errors of the input file, each named
+    text = json.dumps(inp)
+    for broken, what in ((text.replace('"cyclo"', '"cyclone"'), "missing field cyclo"),
+                         (text[: text.index("]")], "expected ']'"),
+                         (text.replace('"pk1": [', '"pk1": '), r"expected '\['"),
+                         (text.replace('"m": ["', '"m": [', 1), "expected string"),
+                         (json.dumps(dict(inp, e0=[])), "at least one coefficient")):
+        with pytest.raises(zk.ZkfheError, match=what):
+            zk.bfv_build_tables(broken, PRM, zcfg, 1, True)
+    # fields the circuit does not read are ignored; a repeated field counts once (the last occurrence)
+    extra = json.dumps(dict(inp, note=["1", "2"]))
+    assert zk.bfv_build_tables(extra, PRM, zcfg, 1, False)["cells"] == zk.bfv_build_tables(text, PRM, zcfg, 1, False)["cells"]
+
+
+def test_long_inputs_parse_on_threads_like_short_ones():
+    """N = 4096 inputs (above the 256 KB mark) take the threaded parse and the threaded decimal conversions: same tables as the
+    same numbers re-serialised with different white space, and the form errors still surface from the worker threads."""
+    from zk_fhe_amd import inputs as gen
+    N, Q = 4096, (1 << 60) - 93
+    inp = gen.generate(N, Q, 7, 19, seed=5)
+    compact = json.dumps(inp, separators=(",", ":"))
+    spaced = json.dumps(inp, indent=1)
+    assert len(compact) > (1 << 18)
+    cfg = zk.BfvConfig(16, 8, 400, 120, 16, 109)
+    a = zk.bfv_build_tables(compact, (N, Q, 7, 19), cfg, 3, keygen_mode=False)
+    b = zk.bfv_build_tables(spaced, (N, Q, 7, 19), cfg, 3, keygen_mode=False)
+    assert a["cells"] == b["cells"] and (a["instance"] == b["instance"]).all() and (a["advice"] == b["advice"]).all()
+    with pytest.raises(zk.ZkfheError, match="expected string"):
+        zk.bfv_build_tables(compact.replace('"c1":["', '"c1":[', 1), (N, Q, 7, 19), cfg, 3, keygen_mode=False)
+    with pytest.raises(zk.ZkfheError, match="coeff <= modulus"):
+        zk.bfv_build_tables(json.dumps(dict(inp, m=[str(Q + 1)] + inp["m"][1:]), separators=(",", ":")), (N, Q, 7, 19), cfg, 3, keygen_mode=False)
 
 
 def test_auto_config_reproduces_the_pinned_column_counts():
