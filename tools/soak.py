@@ -21,20 +21,28 @@ def main():
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--transcript", default="blake2b")
     ap.add_argument("--inputs", type=int, default=12)
+    ap.add_argument("--config", default="k13", choices=["k13", "k16"], help="k16: N = 4096, Q = 2^60 - 93 (auto-configured columns)")
     args = ap.parse_args()
     import zk_fhe_amd as zk
     import zk_fhe_amd.batch as batch
     from zk_fhe_amd import inputs as gen
-    N, Q, T, B = 1024, 536870909, 7, 19
-    cfgj = json.load(open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv_config.json")))
-    zcfg = zk.BfvConfig.from_pinning(cfgj, transcript=args.transcript)
+    T, B = 7, 19
     ctx = zk.Context(0)
-    srs = zk.Srs(ctx, 13)
+    if args.config == "k13":
+        N, Q, k = 1024, 536870909, 13
+        cfgj = json.load(open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv_config.json")))
+        zcfg = zk.BfvConfig.from_pinning(cfgj, transcript=args.transcript)
+        ins = [open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv.in"), "rb").read()]
+    else:
+        N, Q, k = 4096, (1 << 60) - 93, 16
+        ins = []
+    ins += [json.dumps(gen.generate(N, Q, T, B, seed=777 + i)).encode() for i in range(args.inputs - len(ins))]
+    if args.config != "k13":
+        zcfg = zk.bfv_auto_config(ins[0], (N, Q, T, B), k, transcript=args.transcript)
+    srs = zk.Srs(ctx, k)
     empty = json.dumps(gen.empty(N))
-    pk = zk.BfvProvingKey(ctx, srs, empty, (N, Q, T, B), zcfg, replay=True)
+    pk = zk.BfvProvingKey(ctx, srs, empty, (N, Q, T, B), zcfg, replay=args.config == "k13")
     vk = pk.export_vk()
-    ins = [open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv.in"), "rb").read()]
-    ins += [json.dumps(gen.generate(N, Q, T, B, seed=777 + i)).encode() for i in range(args.inputs - 1)]
     ctxs = [ctx] + [zk.Context(0) for _ in range(args.streams - 1)]
     first = {}
     lock = threading.Lock()
