@@ -139,12 +139,26 @@ def test_ntt_golden(ctx, vec):
         assert orc.mont_to_ints(ctx.ntt(a[None], t["log_n"], False)[0]) == hx(t["out"])
 
 
-@pytest.mark.parametrize("log_n", [14, 15, 16, 17])
+@pytest.mark.parametrize("log_n", [14, 15, 16, 17, 18, 19, 20])
 def test_ntt_large(ctx, log_n):
+    """Rows longer than the 2^13 tile: one, two or three fused stages per pass over memory (2^19: two passes of three, 2^20: three passes)."""
     rng = np.random.default_rng(log_n)
     a = rand_fr(rng, 2 << log_n).reshape(2, 1 << log_n, 4)
     assert np.array_equal(ctx.ntt(a, log_n, False), orc.ntt(a, log_n, False))
     assert np.array_equal(ctx.ntt(a, log_n, True), orc.ntt(a, log_n, True))
+
+
+def test_coset_extension_of_long_rows(ctx):
+    """2^19 rows on the coset of the extended domain (2 extension bits): the coset powers are multiplied in by the first pass as it
+    loads."""
+    rng = np.random.default_rng(1919)
+    log_n, lef = 19, 2
+    n, E = 1 << log_n, 1 << lef
+    a = rand_fr(rng, n).reshape(1, n, 4)
+    g = orc.ints_to_mont([pyref.FR_GEN])[0]
+    got = ctx.coset_ntt(a, log_n, lef, g)
+    nat = orc.coset_ntt(a[0], log_n + lef, g)
+    assert np.array_equal(got[0], nat.reshape(n, E, 4).transpose(1, 0, 2).reshape(n * E, 4))
 
 
 def test_ntt_k13_batch_properties(ctx):
