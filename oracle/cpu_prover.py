@@ -32,6 +32,7 @@ def build(force=False):
     so = os.path.join(_HERE, "libcpuprover.so")
     host = os.path.join(_HERE, "..", "zk-fhe_amd", "host")
     srcs = [os.path.join(_HERE, f) for f in ("cpu_prover.cpp", "bn254_ref.h")] + [os.path.join(host, f) for f in os.listdir(host) if f.endswith((".hpp", "_ifma.cpp"))]
+    srcs.append(os.path.join(host, "..", "csrc", "bn254.hip.hpp"))   # fe.hpp includes it
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libcpuprover.so"], stdout=subprocess.DEVNULL)
     return so
