@@ -94,7 +94,10 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
     import zk_fhe_amd as zk
+    import zk_fhe_amd.batch as batch
 
+    # transcript hashing mode from the host CPUs each rank can count on (the ranks of this launch share one node)
+    host = batch.configure_host(zk, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     ctx = zk.Context(local_rank)
     conf = CONFIGS[args.config]
     big = args.config != "k13"
@@ -127,11 +130,11 @@ def main():
             dist.barrier()
 
     import threading
-    import zk_fhe_amd.batch as batch
     n_streams = max(1, min(args.streams, args.steps))
     ctxs = [ctx] + [zk.Context(local_rank) for _ in range(n_streams - 1)]
     acc = np.zeros(5)
     proof_len = [0]
+    last = {}
     lock = threading.Lock()
 
     def one_proof(c, j):
@@ -139,6 +142,8 @@ def main():
         with lock:
             acc[:] += np.array(tm)
             proof_len[0] = len(proof)
+            last[j] = (proof, inst)
+            last.pop(j - 64, None)
         return proof
 
     # warm-up: every stream proves once (allocates its workspace), then W more proofs
@@ -155,8 +160,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     host_cpu_ms = (time.process_time() - cpu0) * 1e3 / max(1, args.steps)   # all threads of this rank
+    # outside the clock: the LAST proof made inside the timed region goes through the host verifier (transcript replay, quotient
+    # identity, SHPLONK, one pairing-product check -- zkfhe_bfv_verify); its public inputs are the ones the prover returned
+    v_proof, v_inst = last[si + args.steps - 1]
+    verified, why = zk.bfv_verify(pk.export_vk(), v_inst, v_proof)
+    if not verified:
+        raise SystemExit("bench: a proof of the timed region does not verify: %s" % why)
     si += args.steps
-    dt = batch.max_over_ranks(dt, device="cuda" if (world > 1 and backend == "nccl") else None)
+    dev = "cuda" if (world > 1 and backend == "nccl") else None
+    dt = batch.max_over_ranks(dt, device=dev)
+    host_cpu_by_rank = batch.gather_floats(host_cpu_ms, device=dev)
     stage = acc / max(1, args.steps)    # a copy: the passes below keep adding to acc
     # steady state, reported separately (never the headline): the driver's --steps may be a single wave of concurrent proofs,
     # whose rate is (proofs) / (latency of the slowest); this pass keeps every stream busy for >= steady_seconds
@@ -248,6 +261,7 @@ def main():
                                    "one proof per step, k=%d, N=%d, Q=2^60-93 (BASELINE configs[%d]); columns by halo2-base auto-configuration"
                                    % (conf["k"], conf["N"], 3 if args.config == "k16" else 4),
                        "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
+                       "host_cpu_ms_per_proof_by_rank": host_cpu_by_rank, "host": host, "verified": bool(verified),
                        "steady_state_proofs_per_s": steady,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 -- DIFFERENT HARDWARE and a LARGER constraint system "

@@ -211,6 +211,18 @@ int zkfhe_transcript_bytes(const zkfhe_transcript *t, uint8_t *out, size_t cap, 
  * constants (65 x 3 round constants, 3 x 3 MDS, canonical 32-byte LE each) for cross-checks. */
 int zkfhe_poseidon_permute(uint8_t state_le[96]);
 int zkfhe_poseidon_constants(uint8_t round_constants_le[65 * 3 * 32], uint8_t mds_le[9 * 32]);
+/* n_jobs independent sponge hashes (fresh sponge, absorb counts[j] canonical scalars taken in order from values_le, squeeze) --
+ * the parity and timing hook of the eight-lane sponge engine the prover's transcripts share when several proofs are in flight
+ * (host/poseidon_x8.cpp: one sponge per AVX-512 IFMA lane, ragged lengths, lanes refilled as they run dry).
+ * mode 0: the scalar / single-sponge path (what a lone transcript runs); 1: eight lanes on the calling thread; 2: through the
+ * hash service's worker threads, as the prover does.  Modes 1 and 2 return ZKFHE_ENODEV on a CPU without AVX-512 IFMA.
+ * No GPU involved; the same digests in every mode. */
+/* How the Poseidon transcripts of the proofs in flight in this process hash: 0 = every transcript on its own (lowest latency:
+ * the default), 1 = long runs of all of them through the shared eight-lane service (about half the host CPU per proof, about
+ * twice the hashing latency: for hosts with few CPUs per GPU), -1 = query.  Returns the mode in force (ZKFHE_EINVAL for any
+ * other argument).  Process-wide; takes effect for transcripts' next runs.  Initial value from ZKFHE_HASH_MODE=latency|shared. */
+int zkfhe_host_hash_mode(int mode);
+int zkfhe_poseidon_hash_many(const uint8_t *values_le, const size_t *counts, size_t n_jobs, int mode, uint8_t *digests_le);
 
 /* ---- BFV circuit: witness tables, keygen, prove (reference examples/bfv.rs + halo2-scaffold run_eth) ---- */
 /* Runtime form of the compile-time constants at examples/bfv.rs:27-30. */

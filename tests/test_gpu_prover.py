@@ -409,6 +409,16 @@ def test_twelve_concurrent_k13_proofs_match_sequential(ctx):
     got = batch.run_concurrent(jobs, ctxs, lambda c, j: pk.prove(texts[j % 6], b"c%d" % j, ctx=c))
     for j in jobs[:12]:
         assert got[j][0] == alone[j], "proof %d differs when proved concurrently" % j
+    # the same again with the transcripts' long runs (public inputs, commitments, evaluations) going through the shared eight-lane
+    # Poseidon service (host/poseidon_x8.cpp; zkfhe_host_hash_mode): the same bytes
+    if zk.poseidon_hash_many([[1, 2]], mode=1) is not None:
+        assert zk.host_hash_mode("shared") == "shared"
+        try:
+            shared = batch.run_concurrent(jobs[:24], ctxs, lambda c, j: pk.prove(texts[j % 6], b"c%d" % j, ctx=c))
+        finally:
+            zk.host_hash_mode("latency")
+        for j in jobs[:24]:
+            assert shared[j][0] == got[j][0], "proof %d differs with the shared hash service" % j
     # jobs 12.. repeat the inputs with other seeds: different bytes, same instances, all valid
     vk = pk.export_vk()
     for j in (12, 23, 35):

@@ -144,3 +144,31 @@ def test_vector_and_scalar_permutation_agree():
     flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
     if "avx512ifma" not in flags:
         print("no AVX-512 IFMA on this CPU: both runs took the scalar path")
+
+
+def test_eight_lane_sponges_match_oracle_and_single_path():
+    """host/poseidon_x8.cpp: one sponge per AVX-512 IFMA lane, the path the prover's transcripts share when several proofs are in
+    flight.  Ragged batches (0 ... 71 values, more jobs than lanes, so lanes are refilled while others are mid-way) on the calling
+    thread and through the hash service threads must give the oracle sponge's digests; the single-sponge path likewise.  Edge
+    values 0 and r - 1 included.  On a CPU without IFMA the lane modes report "unavailable" and the test says so."""
+    rng = random.Random(11)
+    seqs = [[rng.randrange(P.R) for _ in range(n)] for n in [0, 1, 2, 3, 16, 17, 33, 64, 71, 5, 40, 2, 9, 30, 31, 8, 1, 70, 12]]
+    seqs.append([0] * 21)
+    seqs.append([P.R - 1] * 22)
+    want = []
+    for s in seqs:
+        sp = P.Sponge()
+        sp.update(s)
+        want.append(sp.squeeze())
+    assert zk.poseidon_hash_many(seqs, mode=0) == want
+    for mode in (1, 2):
+        got = zk.poseidon_hash_many(seqs, mode=mode)
+        if got is None:
+            print("no AVX-512 IFMA on this CPU: the eight-lane engine is not available")
+            return
+        assert got == want, "mode %d" % mode
+    # the 5121-value run of a k = 13 proof's public inputs, four sponges side by side
+    long_seqs = [[rng.randrange(P.R) for _ in range(5121)] for _ in range(2)]
+    sp = P.Sponge()
+    sp.update(long_seqs[0])
+    assert zk.poseidon_hash_many(long_seqs, mode=2)[0] == sp.squeeze()

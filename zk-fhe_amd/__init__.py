@@ -35,7 +35,7 @@ EXPORTS = [
     "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
     "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
-    "zkfhe_poseidon_permute", "zkfhe_poseidon_constants",
+    "zkfhe_poseidon_permute", "zkfhe_poseidon_constants", "zkfhe_poseidon_hash_many", "zkfhe_host_hash_mode",
     "zkfhe_version",
 ]
 
@@ -435,6 +435,33 @@ def poseidon_permute(state):
     if rc != 0:
         raise ZkfheError("zkfhe_poseidon_permute refused its argument (%d)" % rc)
     return [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(3)]
+
+
+def host_hash_mode(mode=None):
+    """'latency' | 'shared' | None (query): how concurrent provers' Poseidon transcripts hash (zkfhe_host_hash_mode)"""
+    lib = load_library()
+    lib.zkfhe_host_hash_mode.argtypes = [ctypes.c_int]
+    code = {None: -1, "latency": 0, "shared": 1}[mode]
+    rc = lib.zkfhe_host_hash_mode(code)
+    if rc < 0:
+        raise ZkfheError("zkfhe_host_hash_mode(%r) failed" % (mode,))
+    return ["latency", "shared"][rc]
+
+
+def poseidon_hash_many(sequences, mode=1):
+    """sponge digests of independent scalar sequences (python ints); mode 0 = single-sponge path, 1 = eight AVX-512 lanes on this
+    thread, 2 = through the hash service threads (what concurrent provers use).  None when the CPU lacks AVX-512 IFMA (modes 1, 2)."""
+    lib = load_library()
+    flat = b"".join(int(v).to_bytes(32, "little") for s in sequences for v in s)
+    counts = (ctypes.c_size_t * max(1, len(sequences)))(*[len(s) for s in sequences])
+    out = ctypes.create_string_buffer(32 * max(1, len(sequences)))
+    lib.zkfhe_poseidon_hash_many.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]
+    rc = lib.zkfhe_poseidon_hash_many(flat, counts, len(sequences), mode, out)
+    if rc == -4:
+        return None
+    if rc != 0:
+        raise ZkfheError("zkfhe_poseidon_hash_many failed (%d)" % rc)
+    return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(len(sequences))]
 
 
 def poseidon_constants():

@@ -5,8 +5,44 @@ concurrently on several contexts (HIP streams) against one proving key.  There i
 communication is collecting the <= 62 KB proofs (all_gather_object) and the max-over-ranks of the wall time.
 Works with the gloo backend on CPU (tests) and nccl (= RCCL) on GPUs.
 """
+import os
 import threading
 import time
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+# A k = 13 proof costs 28 ms of host CPU with every Poseidon transcript hashing on its own and ~16 ms through the shared
+# eight-lane service, which in turn doubles the hashing latency of a proof (DESIGN.md section 5).  One GPU proves ~220 proofs/s,
+# i.e. keeps ~6 cores busy in the first mode: with fewer CPUs per rank than that the host is the bottleneck and the service pays.
+CPUS_PER_GPU_FOR_LATENCY_MODE = 6
+
+
+def configure_host(zk, ranks_on_this_host=1):
+    """Picks the transcript hashing mode for a batch run from the CPUs each rank can count on (unless ZKFHE_HASH_MODE is set);
+    returns {"usable_cpus", "cpus_per_rank", "hash_mode"}."""
+    cpus = usable_cpus()
+    per = cpus / max(1, ranks_on_this_host)
+    if "ZKFHE_HASH_MODE" not in os.environ:
+        zk.host_hash_mode("shared" if per < CPUS_PER_GPU_FOR_LATENCY_MODE else "latency")
+    return {"usable_cpus": cpus, "cpus_per_rank": per, "hash_mode": zk.host_hash_mode()}
 
 
 def shard_indices(n_items, rank, world):
@@ -79,6 +115,18 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value, device=None):
+    """one float per rank -> list over ranks (on every rank); what bench.py reports per rank (host CPU per proof)"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -351,6 +351,46 @@ int zkfhe_poseidon_permute(uint8_t state_le[96]) {
   }
   return ZKFHE_OK;
 }
+int zkfhe_host_hash_mode(int mode) {
+  if (mode == 0 || mode == 1) pos::hash_mode().store(mode);
+  else if (mode != -1) return ZKFHE_EINVAL;
+  return pos::hash_mode().load();
+}
+int zkfhe_poseidon_hash_many(const uint8_t *values_le, const size_t *counts, size_t n_jobs, int mode, uint8_t *digests_le) try {
+  if (!counts || !digests_le || mode < 0 || mode > 2) return ZKFHE_EINVAL;
+  if (mode && !pos::x8_available()) return ZKFHE_ENODEV;
+  size_t total = 0;
+  for (size_t j = 0; j < n_jobs; ++j) total += counts[j];
+  if (total && !values_le) return ZKFHE_EINVAL;
+  std::vector<U256> vals(total);
+  for (size_t i = 0; i < total; ++i)
+    if (!load_fr(values_le + 32 * i, vals[i])) return ZKFHE_EINVAL;
+  std::vector<pos::Sponge> sp(n_jobs);
+  std::vector<pos::AbsorbJob> jobs(n_jobs);
+  std::vector<pos::AbsorbJob *> ptr(n_jobs);
+  size_t off = 0;
+  for (size_t j = 0; j < n_jobs; off += counts[j], ++j) {
+    ptr[j] = &jobs[j];
+    if (mode == 0) {
+      for (size_t i = 0; i < counts[j]; ++i) sp[j].update(vals[off + i]);
+    } else if (mode == 1) {
+      sp[j].begin_bulk_prepare(vals.data() + off, counts[j], jobs[j]);
+    } else {
+      sp[j].begin_bulk(vals.data() + off, counts[j], jobs[j]);
+    }
+  }
+  if (mode == 1 && !pos::x8_absorb_now(ptr.data(), n_jobs)) return ZKFHE_ENODEV;
+  for (size_t j = 0; j < n_jobs; ++j) {
+    if (mode) sp[j].end_bulk(jobs[j]);
+    const U256 d = sp[j].squeeze();
+    memcpy(digests_le + 32 * j, d.l, 32);
+  }
+  return ZKFHE_OK;
+} catch (const std::bad_alloc &) {
+  return ZKFHE_ENOMEM;
+} catch (const std::exception &) {
+  return ZKFHE_EINVAL;
+}
 int zkfhe_poseidon_constants(uint8_t *rc_le, uint8_t *mds_le) try {
   const pos::Constants &c = pos::constants();
   for (int r = 0; r < pos::ROUNDS && rc_le; ++r)

@@ -456,6 +456,55 @@ struct OpenItem {
   U256 ev[4];            // canonical evaluations
 };
 
+// Admission gate of the GPU-heavy middle of a proof (grand products, their commitment, coset extension, quotient).  Proofs
+// that start together move through the Fiat-Shamir rounds together: they all hash on the host at the same moments and all
+// reach the light, serial end of the proof (evaluations, 758 Poseidon permutations, two one-column commitments) together, with
+// the chip nearly idle.  Letting only a few proofs into the heavy part at a time -- first come, first served -- costs no
+// throughput (that part is bound by the chip, a handful of proofs fill it) and spreads the proofs out: the serial end of one
+// overlaps the heavy part of the next.  ZKFHE_GATE = proofs admitted at once (0 = no gate).
+class HeavyGate {
+ public:
+  static HeavyGate &get() {
+    static HeavyGate g;
+    return g;
+  }
+  void enter() {
+    if (!slots) return;
+    std::unique_lock<std::mutex> l(mu);
+    const uint64_t my = next_ticket++;
+    cv.wait(l, [&] { return my < serving + (uint64_t)slots; });
+  }
+  void leave() {
+    if (!slots) return;
+    {
+      std::lock_guard<std::mutex> l(mu);
+      ++serving;
+    }
+    cv.notify_all();
+  }
+  int slots = 0;
+
+ private:
+  HeavyGate() {
+    if (const char *e = getenv("ZKFHE_GATE")) slots = atoi(e);
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t next_ticket = 0, serving = 0;   // tickets below `serving` have left; FIFO admission of serving .. serving + slots - 1
+};
+struct GateHold {
+  bool held = false;
+  void enter() {
+    HeavyGate::get().enter();
+    held = true;
+  }
+  void leave() {
+    if (held) HeavyGate::get().leave();
+    held = false;
+  }
+  ~GateHold() { leave(); }
+};
+
 // ZKFHE_TRACE=1: host-side phase times of one proof on stderr
 struct Trace {
   bool on;
@@ -705,7 +754,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     CK(commit_cols_out(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, cfg.n_advice() - cfg.n_gate0, ws, pts));
   }
   trace.mark("commit phase 1 (GPU)");
-  for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) tr.write_point(adv_commit[c] = pts[c - cfg.n_gate0]);
+  for (unsigned c = cfg.n_gate0; c < cfg.n_advice(); ++c) adv_commit[c] = pts[c - cfg.n_gate0];
+  tr.write_points(pts);
   tr.squeeze();  // theta: squeezed in protocol order, unused by single-expression lookups
   // ------------------------------------------------------------ lookups: permuted input / table
   if (cfg.n_lookup) {
@@ -727,14 +777,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       ls_commit.assign(la_commit.begin() + cfg.n_lookup, la_commit.end());
       la_commit.resize(cfg.n_lookup);
     }
-    for (unsigned i = 0; i < cfg.n_lookup; ++i) {
-      tr.write_point(la_commit[i]);
-      tr.write_point(ls_commit[i]);
-    }
+    std::vector<AffinePoint> both(2 * (size_t)cfg.n_lookup);
+    for (unsigned i = 0; i < cfg.n_lookup; ++i) both[2 * i] = la_commit[i], both[2 * i + 1] = ls_commit[i];
+    tr.write_points(both);
   }
   trace.mark("lookup permute + commit");
   const U256 beta_c = tr.squeeze(), gamma_c = tr.squeeze();
   const Fr beta = mont(beta_c), gamma = mont(gamma_c);
+  GateHold gate;
+  if (!srs->sharded()) gate.enter();   // a sharded proof's collectives must not wait for another rank's admission order
   // ------------------------------------------------------------ permutation grand products
   {
     if (instances.size() < ws->inst_count)
@@ -806,10 +857,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   CK(commit_cols_out(ctx, srs, srs->g_lagrange, ws->pz_l.fr(), nch + cfg.n_lookup, ws, pz_commit));  // pz | lz contiguous
   if (!closes[0]) return zk_fail_msg(ctx, ZKFHE_EINVAL, "permutation argument does not close: a copy constraint is violated");
   if (!closes[1]) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup argument does not close");
+  tr.write_points(pz_commit);   // permutation products, then lookup products
   lz_commit.assign(pz_commit.begin() + nch, pz_commit.end());
   pz_commit.resize(nch);
-  for (const auto &p : pz_commit) tr.write_point(p);
-  for (const auto &p : lz_commit) tr.write_point(p);
   // ------------------------------------------------------------ vanishing: random polynomial (coefficient form)
   Fr *rand_c = ws->misc.fr() + 8 * n, *rand_l = ws->misc.fr() + 9 * n, *H_c = ws->misc.fr() + 10 * n, *H_l = ws->misc.fr() + 11 * n;
   // committed at the start of the proof on the auxiliary stream ("random polynomial, early"): the last n draws of the stream
@@ -991,6 +1041,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     for (const auto &v : top)
       if (!v.is_zero()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "quotient degree too high: a constraint is violated");
   }
+  gate.leave();
   for (const auto &p : h_commit) tr.write_point(p);
   const U256 x_c = tr.squeeze();
   const Fr x = mont(x_c);
@@ -1106,9 +1157,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   }
   const OpenLayout layout(cfg);
   if (items.size() != layout.count || idx_H != layout.H) return zk_fail_msg(ctx, ZKFHE_EINVAL, "opening layout mismatch");
-  for (size_t i = 0; i < items.size(); ++i) {
-    if (i == idx_H) continue;  // implied by the identity, not written
-    for (int r = 0; r < items[i].n_rot; ++r) tr.write_scalar(items[i].ev[r]);
+  {
+    std::vector<U256> evs;
+    evs.reserve(items.size() * 2);
+    for (size_t i = 0; i < items.size(); ++i) {
+      if (i == idx_H) continue;  // implied by the identity, not written
+      for (int r = 0; r < items[i].n_rot; ++r) evs.push_back(items[i].ev[r]);
+    }
+    tr.write_scalars(evs);
   }
   // ------------------------------------------------------------ SHPLONK (halo2 ProverSHPLONK; Lagrange form, commitments are basis independent)
   const Fr yq = mont(tr.squeeze());
@@ -1266,6 +1322,7 @@ int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk
   ZK_ENTER(ctx);
   ZK_ARG(ctx, srs && pk && input_json && seed && proof_out && proof_len);
   try {
+    pos::BulkClientScope in_flight;   // transcript.hpp bulk_ok(): the hash service is shared by the provers in flight
     std::vector<uint8_t> proof;
     std::vector<U256> inst;
     int rc = prove_impl(ctx, srs, const_cast<zkfhe_bfv_pk *>(pk), input_json, seed, proof, inst, timings_ms);

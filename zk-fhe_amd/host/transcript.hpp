@@ -5,6 +5,7 @@
 // (zkfhe_bfv_config.transcript).  Mirrors oracle/halo2_ref.py `TRANSCRIPTS` / `Rng`.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -194,13 +195,53 @@ class Transcript {
     join();
     absorb_scalar(s);
   }
-  // Absorbs a long run of scalars (the public inputs) on a helper thread; every later call waits for it first.
+  // Absorbs a long run of scalars (the public inputs) beside the caller; every later call waits for it first.  With several
+  // provers in flight the run goes to the eight-lane hash service (poseidon_x8.cpp), where it shares a core with the other
+  // proofs' runs; a lone prover hashes it on a helper thread of its own.
   void common_scalars_async(std::vector<U256> v) {
     join();
     pending = std::move(v);
+    if (bulk_ok(pending.size())) {
+      sp.begin_bulk(pending.data(), pending.size(), job);
+      in_bulk = true;
+      return;
+    }
     worker = std::thread([this] {
       for (const U256 &s : pending) absorb_scalar(s);
     });
+  }
+  // a run of scalars / points written at once (the evaluations, a round's commitments): same bytes and the same sponge state as
+  // one write_* call each
+  void write_scalars(const std::vector<U256> &v) {
+    join();
+    for (const U256 &s : v) {
+      const uint8_t *b = (const uint8_t *)s.l;
+      out.insert(out.end(), b, b + 32);
+    }
+    if (!bulk_ok(v.size())) {
+      for (const U256 &s : v) absorb_scalar(s);
+      return;
+    }
+    sp.begin_bulk(v.data(), v.size(), job);
+    sp.end_bulk(job);
+  }
+  void write_points(const std::vector<AffinePoint> &v) {
+    join();
+    if (kind != TR_POSEIDON || !bulk_ok(2 * v.size())) {
+      for (const AffinePoint &p : v) write_point(p);
+      return;
+    }
+    std::vector<U256> xy(2 * v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (v[i].is_identity()) throw std::runtime_error("Cannot write points at infinity to the transcript");
+      xy[2 * i] = fq_to_fr(v[i].x);
+      xy[2 * i + 1] = fq_to_fr(v[i].y);
+      uint8_t b[32];
+      compress(v[i], b);
+      out.insert(out.end(), b, b + 32);
+    }
+    sp.begin_bulk(xy.data(), xy.size(), job);
+    sp.end_bulk(job);
   }
   void write_point(const AffinePoint &p) {
     common_point(p);
@@ -239,8 +280,24 @@ class Transcript {
   pos::Sponge sp;
   std::thread worker;
   std::vector<U256> pending;
+  pos::AbsorbJob job;
+  bool in_bulk = false;
   void join() {
     if (worker.joinable()) worker.join();
+    if (in_bulk) {
+      in_bulk = false;
+      sp.end_bulk(job);
+    }
+  }
+  // the hash service: only in the "shared" mode (poseidon.hpp hash_mode), only when somebody can share the lanes
+  // (ZKFHE_X8_MIN provers in flight, default 2), only for runs of 16 values or more
+  bool bulk_ok(size_t n_values) const {
+    static const int min_clients = [] {
+      const char *e = getenv("ZKFHE_X8_MIN");
+      return e ? atoi(e) : 2;
+    }();
+    return kind == TR_POSEIDON && n_values >= 16 && pos::hash_mode().load(std::memory_order_relaxed) == 1 && pos::x8_available() &&
+           pos::bulk_clients().load(std::memory_order_relaxed) >= min_clients;
   }
   void absorb_scalar(const U256 &s) {
     if (kind == TR_POSEIDON) {
