@@ -269,7 +269,27 @@ int zkfhe_bfv_tables_poke_advice(zkfhe_bfv_tables *t, uint32_t column, uint32_t 
 /* Unsafe seeded test SRS (the reference's gen_srs is an unsafe seeded setup as well, README.md:34): s derived
  * from the seed, g[i] = s^i G, g_lagrange[i] = L_i(s) G, both computed on the GPU and kept as MSM bases. */
 typedef struct zkfhe_srs zkfhe_srs;
+/* Passing exactly this string as the seed derives s the way the REFERENCE's setup does: halo2-scaffold gen_srs ->
+ * ParamsKZG::<Bn256>::setup(k, ChaCha20Rng::from_seed([0u8; 32])), s = Fr::from_u512 of the first 64 bytes of the ChaCha20
+ * keystream of the all-zero key (the published RFC 7539 zero-key vector).  Any other seed: Blake2b-512("zkfhe-srs", seed) mod r. */
+#define ZKFHE_SRS_HALO2_UNSAFE "halo2:ParamsKZG::setup(k, ChaCha20Rng::from_seed([0u8; 32]))"
 int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out);
+/* params/kzg_bn254_<k>.srs (README.md:34; .gitignore:17), the file halo2 `ParamsKZG::write` / `::read` exchange
+ * (SerdeFormat::RawBytes): u32 k little-endian | g[2^k] | g_lagrange[2^k] | g2 | s_g2 -- G1 points as x | y, G2 points as
+ * x.c0 | x.c1 | y.c0 | y.c1, every coordinate four little-endian u64 Montgomery limbs, i.e. the library's in-memory layout.
+ * save: an unsharded SRS made by zkfhe_srs_create, zkfhe_srs_load, or zkfhe_srs_from_points + zkfhe_srs_set_g2.
+ * load: checks the frame, that every coordinate is reduced and every point on its curve (as halo2's RawBytes read does). */
+int zkfhe_srs_save(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path);
+int zkfhe_srs_load(zkfhe_ctx *ctx, const char *path, zkfhe_srs **out);
+/* The verifier's half, as zkfhe_bfv_verify_g2 takes it: canonical little-endian x.c0 | x.c1 | y.c0 | y.c1 of G2 and s G2.
+ * zkfhe_srs_g2: of an SRS in memory (ZKFHE_EINVAL when it has none: from_points without set_g2); zkfhe_srs_file_g2: read from
+ * the tail of a params file on the host alone (no GPU: `verify` needs nothing else of the SRS); *k_out = the file's k. */
+int zkfhe_srs_g2(const zkfhe_srs *srs, uint8_t g2_le[128], uint8_t s_g2_le[128]);
+int zkfhe_srs_set_g2(zkfhe_srs *srs, const uint8_t g2_le[128], const uint8_t s_g2_le[128]);
+int zkfhe_srs_file_g2(const char *path, uint32_t *k_out, uint8_t g2_le[128], uint8_t s_g2_le[128]);
+/* One ChaCha20 block (RFC 7539 section 2.3; words 12..15 of the state as given): host-only hook that pins the keystream the
+ * reference derivation above reads to the published vectors. */
+int zkfhe_chacha20_block(const uint8_t key[32], const uint32_t counter_nonce[4], uint8_t out[64]);
 /* An SRS from outside (a ceremony file such as the reference's params/kzg_bn254_<k>.srs, README.md:34-38, read by the
  * caller): 2^k points g[i] = s^i G and g_lagrange[i] = L_i(s) G, host memory, affine, Montgomery limbs (halo2curves'
  * in-memory G1Affine).  The library only builds its MSM tables from them; nothing is checked about the ceremony. */
@@ -316,6 +336,18 @@ int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols
  * generated with. */
 int zkfhe_bfv_pk_save(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, const char *path);
 int zkfhe_bfv_pk_load(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path, zkfhe_bfv_pk **out);
+
+/* data/<name>.snark (README.md:42-52).  snark-verifier-sdk's `Snark { protocol, instances: Vec<Vec<Fr>>, proof: Vec<u8> }` is
+ * written with bincode (fixed-width little-endian integers, u64 lengths); its `protocol` field is the compiled PlonkProtocol of
+ * the reference's constraint system, which this library does not have.  This container keeps the two
+ * fields that ARE common, byte for byte as bincode writes them, behind a 16-byte header:
+ *   "ZKFHESN2" | u64 protocol_len = 0 (absent) | u64 1 | u64 n | n x Fr | u64 proof_len | proof bytes
+ * with Fr as halo2curves' serde derives it: four little-endian u64 limbs of the MONTGOMERY form (x * 2^256 mod r) -- so a Rust
+ * reader skips 16 bytes and `bincode::deserialize::<(Vec<Vec<Fr>>, Vec<u8>)>`s the rest.  Host only.
+ * encode: instances as canonical 32-byte LE scalars; out = NULL / cap too small: *len = bytes needed (ZKFHE_EINVAL if cap > 0).
+ * decode: also accepts the round-1..3 container ("ZKFHESN1" | u64 n | n canonical scalars | proof); NULL outputs = sizes only. */
+int zkfhe_snark_encode(const uint8_t *instances_le, size_t n_instances, const uint8_t *proof, size_t proof_len, uint8_t *out, size_t cap, size_t *len);
+int zkfhe_snark_decode(const uint8_t *snark, size_t snark_len, uint8_t *instances_le, size_t *n_instances, uint8_t *proof, size_t *proof_len);
 
 /* verify (README.md:48-52), host CPU only (no GPU, like the reference's verifier): replays the transcript, checks the
  * quotient identity at x, and ends in one BN254 pairing-product check.  instances: n_instances canonical 32-byte LE

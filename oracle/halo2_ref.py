@@ -171,10 +171,21 @@ class Config:
 
 
 # ----------------------------------------------------------------------------------------- SRS
+SRS_HALO2_UNSAFE = b"halo2:ParamsKZG::setup(k, ChaCha20Rng::from_seed([0u8; 32]))"
+
+
+def srs_secret(seed):
+    """the reference's own derivation (oracle/chacha20_ref.py) for the marker seed, Blake2b of the seed otherwise"""
+    if bytes(seed) == SRS_HALO2_UNSAFE:
+        from oracle import chacha20_ref
+        return chacha20_ref.reference_srs_secret()
+    return from_bytes_wide(hashlib.blake2b(bytes(seed), digest_size=64, person=b"zkfhe-srs").digest())
+
+
 def make_srs(k, seed=b"zkfhe-unsafe-srs"):
     """Unsafe test SRS (the reference's `gen_srs` is an unsafe seeded setup too, README.md:34)."""
     n = 1 << k
-    s = from_bytes_wide(hashlib.blake2b(bytes(seed), digest_size=64, person=b"zkfhe-srs").digest())
+    s = srs_secret(seed)
     G = orc.points_to_arr([pyref.G1_GEN])[0]
     pw = orc.fr_powers(M(1), M(s), n)
     g = orc.g1_mul(np.repeat(G[None], n, axis=0), pw)
@@ -190,7 +201,7 @@ def make_srs(k, seed=b"zkfhe-unsafe-srs"):
 
 def srs_verifier_half(k, seed=b"zkfhe-unsafe-srs"):
     """Only what verify() needs from the SRS (s*G2): skips the 2 * 2^k G1 scalar multiplications."""
-    s = from_bytes_wide(hashlib.blake2b(bytes(seed), digest_size=64, person=b"zkfhe-srs").digest())
+    s = srs_secret(seed)
     return {"k": k, "s": s, "s_g2": PR.ec_mul(PR.G2_GEN, s)}
 
 

@@ -8,11 +8,18 @@ crate behind the `Snark.proof` bytes of reference examples/bfv.rs:311):
     from_bytes: is_inf = byte31 >> 7, ysign = (byte31 >> 6) & 1, byte31 &= 0b0011_1111
 Parity unpinned: no reference-made proof exists in /root/reference and the crate is not on this machine."""
 
+import os
+
 Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
-SIGN_BIT = 0x40       # bit 6 of byte 31: y is odd
-IDENTITY_BIT = 0x80   # bit 7 of byte 31: the point at infinity (every other bit zero)
-X_MASK = 0x3F
+# ONE switch shared with the product (zk-fhe_amd/host/point_encoding.hpp): ZKFHE_POINT_ENCODING = "halo2curves-0.3.2" (default)
+# or "halo2curves-0.3.1" (sign in bit 7, identity = 32 zero bytes)
+if os.environ.get("ZKFHE_POINT_ENCODING") == "halo2curves-0.3.1":
+    SIGN_BIT, IDENTITY_BIT, X_MASK = 0x80, 0x00, 0x7F
+else:
+    SIGN_BIT = 0x40       # bit 6 of byte 31: y is odd
+    IDENTITY_BIT = 0x80   # bit 7 of byte 31: the point at infinity (every other bit zero)
+    X_MASK = 0x3F
 
 
 def point_compress(P):
@@ -29,7 +36,7 @@ def point_compress(P):
 
 def point_decompress(b):
     b = bytearray(b)
-    if b[31] & IDENTITY_BIT:
+    if (b[31] & IDENTITY_BIT) if IDENTITY_BIT else not any(b):
         assert not any(b[:31]) and b[31] == IDENTITY_BIT, "non-canonical identity encoding"
         return None
     sign = 1 if b[31] & SIGN_BIT else 0

@@ -60,9 +60,20 @@ def test_keygen_prove_verify_walkthrough(tmp_path):
     want = json.load(open(os.path.join(G, "bfv_config.json")))
     assert got["params"] == want["params"] and got["break_points"] == want["break_points"]
     assert os.path.getsize(tmp_path / "data" / "bfv.pk") > 50 << 20 and os.path.exists(tmp_path / "data" / "bfv.vk")
+    # README.md:34 / .gitignore:17: the unsafe test setup lands in params/kzg_bn254_13.srs (halo2 RawBytes frame) and is the
+    # reference's own: g[1] = s G with s from ChaCha20Rng::from_seed([0; 32]) (tests/test_srs_file.py pins the keystream)
+    srs_path = tmp_path / "params" / "kzg_bn254_13.srs"
+    assert "kzg_bn254_13.srs" in r.stdout and os.path.getsize(srs_path) == 4 + 2 * 64 * 8192 + 256
+    srs_blob = open(srs_path, "rb").read()
+    from oracle import chacha20_ref, pyref
+    to_int = lambda b: int.from_bytes(b, "little") * pow(1 << 256, -1, pyref.Q) % pyref.Q   # noqa: E731  raw Montgomery limbs
+    assert (to_int(srs_blob[68:100]), to_int(srs_blob[100:132])) == pyref.g1_mul(pyref.G1_GEN, chacha20_ref.reference_srs_secret())
+    stamp = os.stat(srs_path).st_mtime_ns
     r = _run(tmp_path, "--input", "bfv/bfv.in", "prove")
     assert r.returncode == 0 and "Proving time" in r.stdout, r.stderr
+    assert "wrote" not in r.stdout and os.stat(srs_path).st_mtime_ns == stamp and open(srs_path, "rb").read() == srs_blob   # read, not rebuilt
     snark = open(tmp_path / "data" / "bfv.snark", "rb").read()
+    assert snark[:8] == b"ZKFHESN2"
     r = _run(tmp_path, "--input", "bfv/bfv.in", "verify")
     assert r.returncode == 0 and "Snark verified successfully" in r.stdout, r.stderr
     # two proofs of the same statement differ (fresh blinding seed from the OS) and both verify
@@ -70,7 +81,7 @@ def test_keygen_prove_verify_walkthrough(tmp_path):
     assert r.returncode == 0
     assert open(tmp_path / "data" / "bfv.snark", "rb").read() != snark
     assert _run(tmp_path, "--input", "bfv/bfv.in", "verify").returncode == 0
-    for pos in (len(snark) - 10, 16 + 32 * 100 + 3, len(snark) // 2):      # an opening point, a public input, an evaluation
+    for pos in (len(snark) - 10, 32 + 32 * 100 + 3, len(snark) // 2):      # an opening point, a public input, an evaluation
         bad = bytearray(snark)
         bad[pos] ^= 1
         open(tmp_path / "data" / "bfv.snark", "wb").write(bytes(bad))
@@ -81,6 +92,21 @@ def test_keygen_prove_verify_walkthrough(tmp_path):
     vk[200] ^= 1
     open(tmp_path / "data" / "bfv.vk", "wb").write(bytes(vk))
     assert _run(tmp_path, "--input", "bfv/bfv.in", "verify").returncode != 0
+    # verify needs only the G2 tail of the params file; without the file it derives the same setup; with another setup's file it rejects
+    open(tmp_path / "data" / "bfv.vk", "wb").write(bytes(vk[:200]) + bytes([vk[200] ^ 1]) + bytes(vk[201:]))
+    assert _run(tmp_path, "--input", "bfv/bfv.in", "verify").returncode == 0
+    os.rename(srs_path, str(srs_path) + ".away")
+    assert _run(tmp_path, "--input", "bfv/bfv.in", "verify").returncode == 0
+    tail = bytearray(srs_blob)
+    tail[-128:] = tail[-256:-128]                     # s G2 := G2, i.e. s = 1
+    open(srs_path, "wb").write(bytes(tail))
+    assert _run(tmp_path, "--input", "bfv/bfv.in", "verify").returncode != 0
+    # a damaged params file stops prove instead of being silently replaced
+    open(srs_path, "wb").write(srs_blob[:-9])
+    r = _run(tmp_path, "--input", "bfv/bfv.in", "prove")
+    assert r.returncode != 0 and "params" in r.stderr
+    os.remove(srs_path)
+    os.rename(str(srs_path) + ".away", srs_path)
     # a wrong witness is refused by prove with a non-zero exit code
     inp = json.load(open(tmp_path / "data" / "bfv" / "bfv.in"))
     inp["e0"][0] = "25"

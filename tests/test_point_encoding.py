@@ -22,7 +22,8 @@ def test_layout_constants():
     assert PE.SIGN_BIT == 1 << V["layout"]["sign_bit"] and PE.IDENTITY_BIT == 1 << V["layout"]["identity_bit"]
     assert PE.X_MASK == V["layout"]["x_mask_byte31"]
     src = open(os.path.join(HERE, "..", "zk-fhe_amd", "host", "point_encoding.hpp")).read()
-    assert "SIGN_BIT = 0x%02x" % PE.SIGN_BIT in src and "IDENTITY_BIT = 0x%02x" % PE.IDENTITY_BIT in src and "X_MASK = 0x%02x" % PE.X_MASK in src
+    assert "return Layout{0x%02x, 0x%02x, 0x%02x};" % (PE.SIGN_BIT, PE.IDENTITY_BIT, PE.X_MASK) in src     # the product's default
+    assert "ZKFHE_POINT_ENCODING" in src and "ZKFHE_POINT_ENCODING" in open(PE.__file__).read()           # one switch for both sides
     # nobody keeps a private copy of the layout
     for f in ("transcript.hpp", "verifier.cpp"):
         body = open(os.path.join(HERE, "..", "zk-fhe_amd", "host", f)).read()
@@ -72,3 +73,29 @@ def test_product_verifier_reads_the_layout():
     bad[31] |= PE.IDENTITY_BIT
     ok, why = zk.bfv_verify(vkb, inst, bytes(bad))
     assert not ok and "identity" in why, why
+
+
+def test_one_switch_flips_product_and_oracle_together():
+    """ZKFHE_POINT_ENCODING=halo2curves-0.3.1 (sign in bit 7, identity = 32 zero bytes) in a fresh interpreter: the oracle codec
+    and the product's transcript both follow, and an oracle-made proof still verifies -- the layout lives in one place per side
+    and both sides read the same variable."""
+    import subprocess
+    import sys
+    prog = (
+        "import sys; sys.path.insert(0, ROOT)\n"
+        "import zk_fhe_amd as zk\n"
+        "from oracle import point_encoding as PE\n"
+        "assert (PE.SIGN_BIT, PE.IDENTITY_BIT, PE.X_MASK) == (0x80, 0, 0x7f)\n"
+        "P = (1, 2); N = (1, PE.Q - 2)\n"
+        "tr = zk.HostTranscript('blake2b'); tr.write_point(P); tr.write_point(N); s = tr.stream(); tr.close()\n"
+        "assert s == PE.point_compress(P) + PE.point_compress(N), s.hex()\n"
+        "assert s[31] == 0 and s[63] == 0x80\n"
+        "assert PE.point_decompress(bytes(32)) is None and PE.point_decompress(s[32:]) == N\n"
+        "from tests.test_host_verifier import make\n"
+        "vkb, inst, proof = make('poseidon')\n"
+        "assert zk.bfv_verify(vkb, inst, proof)[0]\n"
+        "print('flipped ok')\n"
+    ).replace("ROOT", repr(os.path.dirname(HERE)))
+    env = dict(os.environ, ZKFHE_POINT_ENCODING="halo2curves-0.3.1")
+    r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "flipped ok" in r.stdout, r.stderr[-2000:]

@@ -31,7 +31,8 @@ EXPORTS = [
     "zkfhe_bfv_build_tables", "zkfhe_bfv_auto_config", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points", "zkfhe_bfv_mock_check", "zkfhe_bfv_tables_poke_advice",
-    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info",
+    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_srs_save", "zkfhe_srs_load", "zkfhe_srs_g2", "zkfhe_srs_set_g2", "zkfhe_srs_file_g2",
+    "zkfhe_chacha20_block", "zkfhe_snark_encode", "zkfhe_snark_decode", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info",
     "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
     "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
@@ -640,6 +641,8 @@ class Comm:
         self.ctx, self.rank, self.world = ctx, rank, world
         self.h = ctypes.c_void_p()
         lib.zkfhe_comm_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if world > 1 and unique_id is None and all_gather is None:
+            raise ValueError("Comm(world > 1) needs a transport: unique_id= (RCCL) or all_gather= (a host all-gather callable)")
         if unique_id is None:     # host transport (or, with world == 1 and no callback, no transport at all)
             def cb(_user, send, nbytes, recv):
                 try:
@@ -686,6 +689,62 @@ class Comm:
             self.h = ctypes.c_void_p()
 
 
+# zkfhe.h ZKFHE_SRS_HALO2_UNSAFE: as a seed it selects the reference's own derivation (ChaCha20Rng::from_seed([0; 32]))
+SRS_HALO2_UNSAFE = b"halo2:ParamsKZG::setup(k, ChaCha20Rng::from_seed([0u8; 32]))"
+
+
+def chacha20_block(key, counter_nonce):
+    """one ChaCha20 block (RFC 7539 2.3): key 32 bytes, counter_nonce = the four state words 12..15"""
+    lib = load_library()
+    out = ctypes.create_string_buffer(64)
+    lib.zkfhe_chacha20_block.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_char_p]
+    if lib.zkfhe_chacha20_block(bytes(key), (ctypes.c_uint32 * 4)(*counter_nonce), out) != 0:
+        raise ZkfheError("zkfhe_chacha20_block refused its arguments")
+    return out.raw
+
+
+def _g2_tuple(b):
+    v = [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(4)]
+    return ((v[0], v[1]), (v[2], v[3]))
+
+
+def srs_file_g2(path):
+    """(k, G2, s G2) from the tail of a params/kzg_bn254_<k>.srs file; points as ((x.c0, x.c1), (y.c0, y.c1)).  Host only."""
+    lib = load_library()
+    a, b, k = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128), ctypes.c_uint32()
+    lib.zkfhe_srs_file_g2.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_char_p, ctypes.c_char_p]
+    if lib.zkfhe_srs_file_g2(os.fsencode(path), ctypes.byref(k), a, b) != 0:
+        raise ZkfheError("%s is not a params file" % path)
+    return k.value, _g2_tuple(a.raw), _g2_tuple(b.raw)
+
+
+def snark_encode(instances, proof):
+    """data/<name>.snark container (zkfhe.h zkfhe_snark_encode): instances = ints or an Instances object"""
+    lib = load_library()
+    inst = instances.raw if isinstance(instances, Instances) else b"".join(int(v).to_bytes(32, "little") for v in instances)
+    n = len(inst) // 32
+    lib.zkfhe_snark_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    ln = ctypes.c_size_t()
+    lib.zkfhe_snark_encode(inst, n, bytes(proof), len(proof), None, 0, ctypes.byref(ln))
+    out = ctypes.create_string_buffer(ln.value)
+    if lib.zkfhe_snark_encode(inst, n, bytes(proof), len(proof), out, ln.value, ctypes.byref(ln)) != 0:
+        raise ZkfheError("zkfhe_snark_encode: an instance is not a reduced scalar")
+    return out.raw
+
+
+def snark_decode(snark):
+    """-> (list of instance ints, proof bytes); raises on a malformed container"""
+    lib = load_library()
+    lib.zkfhe_snark_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    n, pl = ctypes.c_size_t(), ctypes.c_size_t()
+    if lib.zkfhe_snark_decode(bytes(snark), len(snark), None, ctypes.byref(n), None, ctypes.byref(pl)) != 0:
+        raise ZkfheError("not a snark container")
+    inst, proof = ctypes.create_string_buffer(32 * n.value + 1), ctypes.create_string_buffer(pl.value + 1)
+    if lib.zkfhe_snark_decode(bytes(snark), len(snark), inst, ctypes.byref(n), proof, ctypes.byref(pl)) != 0:
+        raise ZkfheError("snark container: an instance is not a reduced scalar")
+    return [int.from_bytes(inst.raw[32 * i:32 * i + 32], "little") for i in range(n.value)], proof.raw[:pl.value]
+
+
 class Srs:
     def __init__(self, ctx, k, seed=b"zkfhe-unsafe-srs", comm=None):
         """comm: a Comm -> only this rank's point range of both halves is built and every commitment of keygen / prove is
@@ -718,6 +777,40 @@ class Srs:
         ctx._check(lib.zkfhe_srs_from_points(ctx.h, k, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
         self.h = h
         return self
+
+    @classmethod
+    def load(cls, ctx, path):
+        """zkfhe_srs_load: a params/kzg_bn254_<k>.srs file (halo2 ParamsKZG RawBytes layout)"""
+        lib = ctx.lib
+        lib.zkfhe_srs_load.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.zkfhe_srs_destroy.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        ctx._check(lib.zkfhe_srs_load(ctx.h, os.fsencode(path), ctypes.byref(h)))
+        self.ctx, self.h, self.comm = ctx, h, None
+        self.k = int.from_bytes(open(path, "rb").read(4), "little")
+        return self
+
+    def save(self, path):
+        lib = self.ctx.lib
+        lib.zkfhe_srs_save.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+        self.ctx._check(lib.zkfhe_srs_save(self.ctx.h, self.h, os.fsencode(path)))
+
+    def g2(self):
+        """(G2, s G2) as ((x.c0, x.c1), (y.c0, y.c1)) ints: what bfv_verify(g2=, s_g2=) takes"""
+        lib = self.ctx.lib
+        a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+        lib.zkfhe_srs_g2.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        if lib.zkfhe_srs_g2(self.h, a, b) != 0:
+            raise ZkfheError("this SRS has no G2 half")
+        return _g2_tuple(a.raw), _g2_tuple(b.raw)
+
+    def set_g2(self, g2, s_g2):
+        lib = self.ctx.lib
+        enc = lambda p: b"".join(int(v).to_bytes(32, "little") for v in (p[0][0], p[0][1], p[1][0], p[1][1]))  # noqa: E731
+        lib.zkfhe_srs_set_g2.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+        if lib.zkfhe_srs_set_g2(self.h, enc(g2), enc(s_g2)) != 0:
+            raise ZkfheError("zkfhe_srs_set_g2: a point is not on the twist")
 
     def table_bits(self):
         """(digit width of the Lagrange half's digit-multiple table or 0, whether calls of many columns take the table path)."""

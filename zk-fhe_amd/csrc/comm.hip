@@ -17,7 +17,25 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>   // the installed header: compile-time check of every signature used below and of ncclUint8
+#else
+// A build host without the RCCL development files: the slice of the API that is used, as RCCL 2.x declares it (the library is
+// only ever resolved with dlopen at run time).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include "ctx.hpp"
 

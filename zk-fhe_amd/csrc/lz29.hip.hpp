@@ -29,6 +29,7 @@ struct Lz {
   int l[9];
 };
 using LzT = Lz<0, 1, 2>;   // what a product returns: tight limbs, value in (-r, 2 r)
+struct LzW : LzT {};       // what lz_weak returns: the same limbs, value in [0, 2 r) -- the only thing lz_store_weak accepts
 struct Lw {   // canonical constant operand (twiddle), limbs in [0, 2^29)
   u32 l[9];
 };
@@ -78,16 +79,18 @@ ZK_HD Lz<0, 1, V> lz_norm(const Lz<LO, HI, V> &a) {
 }
 
 // value (either sign, |v| < 16 r) -> the same residue in [0, 2 r) (in fact below 1.04 r), limbs normalised.
-// q = floor(t m / 2^16) with t = floor((l[8] - LO) / 2^13) and m = 169 for t >= 0, 170 for t < 0: the lower limbs sum to more than
-// -LO 2^232, so t 2^245 <= v, and 169 < 2^261 / r = 169.29.. < 170, so q never exceeds v / r (the multiplier is rounded towards
-// the side that makes the estimate smaller) and falls short of it by less than 1.1.
+// q = floor(t m / 2^16) with t = floor((l[8] - LO) / 2^13) and m = 169 for t >= 0, 170 for t < 0.  The lower limbs sum to more than
+// -LO 2^232 (1 + 2^-29), so t 2^245 <= v + LO 2^203: not quite t 2^245 <= v, but the sliver (below 2^205 = 2^-48 r) is covered
+// by the rounding of the multiplier -- 169 < 2^261 / r = 169.29.. < 170, i.e. the estimate is 0.17 % (t > 0) resp. 0.42 %
+// (t < 0) of |t| 2^245 >= 2^245 on the safe side, and t = 0 gives q = 0 -- so q never exceeds v / r and falls short of it by
+// less than 1.1.
 template <int LO, int HI, int V>
-ZK_HD LzT lz_weak(const Lz<LO, HI, V> &a) {
+ZK_HD LzW lz_weak(const Lz<LO, HI, V> &a) {
   static_assert(V <= 16, "weak reduction: |value| below 16 r");
   constexpr u32 P[9] = ZK_R29_P;
   const int t = (a.l[8] - LO) >> 13;
   const int q = (t * (169 - (t >> 31))) >> 16;
-  LzT r;
+  LzW r;
   long long c = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -172,8 +175,9 @@ ZK_HD LzT lz_mul2(const Lz<0, 1, V> &a, const Lw &w, const Lz<0, 1, V2> &b, cons
   return r;
 }
 
-// canonical packed column value from a weakly reduced one (value in [0, 2 r), normalised limbs)
-ZK_HD Fr lz_store_weak(const LzT &a) {
+// canonical packed column value from a weakly reduced one (value in [0, 2 r), normalised limbs): takes lz_weak's own type, so a
+// product's result (which may be negative) cannot be passed by mistake
+ZK_HD Fr lz_store_weak(const LzW &a) {
   constexpr u32 P[9] = ZK_R29_P;
   int t[9], c = 0;
 #pragma unroll

@@ -214,6 +214,13 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
   auto it = ctx->domains.find(log_n);
   if (it == ctx->domains.end()) {
     NttDomain d;
+    struct Guard {   // the tables of a half-built domain are released on every early return
+      NttDomain *d;
+      ~Guard() {
+        if (!d) return;
+        (void)hipFree(d->fwd), (void)hipFree(d->inv), (void)hipFree(d->fwd29), (void)hipFree(d->inv29), (void)hipFree(d->n_inv29_dev);
+      }
+    } guard{&d};
     d.log_n = log_n;
     const size_t n = (size_t)1 << log_n;
     d.omega = zk_fr_root_of_unity(log_n);
@@ -239,6 +246,7 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
     ZK_HIP(ctx, hipMemcpyAsync(d.n_inv29_dev, &d.n_inv29, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the source is a local of this function
     it = ctx->domains.emplace(log_n, d).first;
+    guard.d = nullptr;
   }
   *out = &it->second;
   return ZKFHE_OK;
@@ -254,7 +262,14 @@ int zkfhe_ntt_batch(zkfhe_ctx *ctx, zkfhe_fr *cols_dev, size_t n_cols, int log_n
 
 int zkfhe_ntt_batch_to(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev, size_t n_cols, int log_n, int inverse) {
   ZK_ENTER(ctx);
-  ZK_ARG(ctx, in_dev != nullptr && (const void *)in_dev != (const void *)out_dev);
+  ZK_ARG(ctx, in_dev != nullptr && out_dev != nullptr && log_n >= 0 && log_n < 40);
+  {
+    // "not overlapping" is enforced, not only documented: at n = 2^13 two workgroups per column read all of it while the other
+    // writes, and a partial overlap would corrupt the result silently
+    const Fr *i0 = (const Fr *)in_dev, *o0 = (const Fr *)out_dev;
+    const size_t span = n_cols << log_n;
+    if (!(i0 + span <= o0 || o0 + span <= i0)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_ntt_batch_to: input and output must not overlap (zkfhe_ntt_batch transforms in place)");
+  }
   return zk_ntt_impl(ctx, in_dev, out_dev, n_cols, log_n, inverse);
 }
 

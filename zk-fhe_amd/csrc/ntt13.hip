@@ -340,16 +340,30 @@ int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const 
     if (rc) return rc;
     rc = zk_domain(ctx, 13 + lef, &edom);
     if (rc) return rc;
-    LwMem *p = nullptr;
-    ZK_HIP(ctx, hipMalloc((void **)&p, (size_t)rows * 2 * 8192 * sizeof(LwMem)));
+    // The generator comes from the caller of zkfhe_coset_ntt_batch: a bounded cache (the prover uses one or two keys; a caller
+    // that sweeps g would otherwise grow device memory by rows * 786 KB per value for the life of the context).  On overflow
+    // everything goes: the stream is drained first, queued transforms may still be reading the tables.
+    if (ctx->pre13.size() >= 8) {
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (auto &kv : ctx->pre13) (void)hipFree(kv.second);
+      ctx->pre13.clear();
+    }
+    struct Owned {   // released unless handed to the cache
+      LwMem *p = nullptr;
+      ~Owned() {
+        if (p) (void)hipFree(p);
+      }
+    } own;
+    ZK_HIP(ctx, hipMalloc((void **)&own.p, (size_t)rows * 2 * 8192 * sizeof(LwMem)));
     Fr shift = g;
     const Fr start = scaled ? dom->n_inv29 : zk_fr_to_29(Fr::one());
     for (int k1 = 0; k1 < rows; ++k1) {
-      k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, p + (size_t)k1 * 2 * 8192);
+      k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * 2 * 8192);
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * edom->omega;
     }
-    it = ctx->pre13.emplace(key, (void *)p).first;
+    it = ctx->pre13.emplace(key, (void *)own.p).first;
+    own.p = nullptr;
   }
   *out = it->second;
   return ZKFHE_OK;
@@ -357,14 +371,23 @@ int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const 
 
 int zk_launch_tile_13(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsigned cols) {
   if (a.pre && !a.pre13) return zk_fail_msg(ctx, ZKFHE_EINVAL, "2^13 tile: coset tables missing (zk_pre13)");
-  // the two workgroups of a column both read all of it and write interleaved halves: never in place
-  if ((const void *)a.in == (const void *)a.out) return zk_fail_msg(ctx, ZKFHE_EINVAL, "2^13 tile: input and output must be different buffers");
+  // the two workgroups of a column both read all of it and write interleaved halves: never in place, and no partial overlap
+  // either (a column's output would land in a column another workgroup has yet to read)
+  {
+    const size_t in_span = (size_t)(cols ? cols - 1 : 0) * a.col_stride_in + (size_t)(tiles ? tiles - 1 : 0) * a.in_tile_stride + 8192;
+    const size_t out_span = (size_t)(cols ? cols - 1 : 0) * a.col_stride_out + (size_t)tiles * 8192;
+    const Fr *i0 = a.in, *o0 = a.out;
+    if (!(i0 + in_span <= o0 || o0 + out_span <= i0)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "2^13 tile: input and output buffers must not overlap");
+  }
   auto it = ctx->tw13.find((const void *)a.tw);
   if (it == ctx->tw13.end()) {
     LwMem *p = nullptr;
     ZK_HIP(ctx, hipMalloc((void **)&p, (size_t)PACK_LEN * sizeof(LwMem)));
     k_tw13_pack<<<zk_blocks(PACK_LEN, 256), 256, 0, ctx->stream>>>(a.tw, p);
-    ZK_LAUNCH_CHECK(ctx);
+    if (hipGetLastError() != hipSuccess) {
+      (void)hipFree(p);
+      return zk_fail_msg(ctx, ZKFHE_EHIP, "2^13 tile: twiddle pack launch failed");
+    }
     it = ctx->tw13.emplace((const void *)a.tw, (void *)p).first;
   }
   static bool attr_set = false;

@@ -2,6 +2,9 @@
 // examples/bfv.rs:306-312):   bfv --name bfv -k 13 --input bfv/bfv.in {mock|keygen|prove|verify}
 // Files: reads data/<input>, configs/<name>.json (prove); writes configs/<name>.json (keygen), data/<name>.snark (prove).
 // keygen also writes data/<name>.vk and data/<name>.pk; `prove` loads the pk, `verify` reads vk + snark on the host CPU.
+// SRS: params/kzg_bn254_<k>.srs (README.md:34, .gitignore:17; directory from $PARAMS_DIR as in halo2-base's gen_srs), halo2's
+// ParamsKZG RawBytes layout.  keygen / prove read it when it exists and otherwise derive the reference's unsafe test setup
+// (ChaCha20Rng::from_seed([0; 32]), zkfhe.h ZKFHE_SRS_HALO2_UNSAFE) and write it; verify reads only its G2 tail.
 // --transcript poseidon|blake2b (keygen; default poseidon = the reference's PoseidonTranscript) is recorded in pk and vk.
 #include <chrono>
 #include <cstdio>
@@ -13,6 +16,7 @@
 #include <vector>
 
 #include <sys/random.h>
+#include <sys/stat.h>
 
 #include "../../include/zkfhe.h"
 
@@ -190,27 +194,33 @@ int main(int argc, char **argv) {
     printf("Mock prover: %zu advice columns x %zu rows, %zu copy constraints: every gate, lookup and copy constraint holds\n", n_adv, n_rows, n_copies);
     return 0;
   }
-  const char *seed = "zkfhe-unsafe-srs";
+  const char *seed = ZKFHE_SRS_HALO2_UNSAFE;
+  const char *pdir = getenv("PARAMS_DIR");
+  const std::string params_dir = pdir && pdir[0] ? pdir : "params";
+  const std::string srs_path = params_dir + "/kzg_bn254_" + std::to_string(k) + ".srs";
   if (cmd == "verify") {
     // README.md:48-52: reads data/<name>.vk and data/<name>.snark (host CPU only, no GPU needed)
     const std::string vk = slurp(data_path + "/" + name + ".vk"), sn = slurp(data_path + "/" + name + ".snark");
-    if (sn.size() < 16 || memcmp(sn.data(), "ZKFHESN1", 8)) {
-      fprintf(stderr, "%s/%s.snark is not a zkfhe snark file\n", data_path.c_str(), name.c_str());
+    std::vector<uint8_t> instv, proofv;
+    if (zkfhe_snark_decode((const uint8_t *)sn.data(), sn.size(), nullptr, nullptr, nullptr, nullptr) != ZKFHE_OK) {
+      fprintf(stderr, "%s/%s.snark is not a zkfhe snark file (or is truncated)\n", data_path.c_str(), name.c_str());
       return 1;
     }
-    uint64_t ninst = 0;
-    memcpy(&ninst, sn.data() + 8, 8);
-    if (sn.size() < 16 + 32 * ninst) {
-      fprintf(stderr, "snark file truncated\n");
-      return 1;
-    }
-    const uint8_t *inst = (const uint8_t *)sn.data() + 16, *proof = inst + 32 * ninst;
-    const size_t proof_len = sn.size() - 16 - 32 * ninst;
+    size_t ninst = 0, proof_len = 0;
+    zkfhe_snark_decode((const uint8_t *)sn.data(), sn.size(), nullptr, &ninst, nullptr, &proof_len);
+    instv.resize(32 * ninst + 1), proofv.resize(proof_len + 1);
+    zkfhe_snark_decode((const uint8_t *)sn.data(), sn.size(), instv.data(), &ninst, proofv.data(), &proof_len);
+    const uint8_t *inst = instv.data(), *proof = proofv.data();
     int ok = 0;
     char err[256] = {0};
     auto t0 = std::chrono::steady_clock::now();
-    zkfhe_bfv_verify((const uint8_t *)vk.data(), vk.size(), inst, (size_t)ninst, proof, proof_len, (const uint8_t *)seed, strlen(seed), &ok, err,
-                     sizeof(err));
+    uint8_t g2[128], sg2[128];
+    uint32_t fk = 0;
+    if (zkfhe_srs_file_g2(srs_path.c_str(), &fk, g2, sg2) == ZKFHE_OK && fk == k) {
+      zkfhe_bfv_verify_g2((const uint8_t *)vk.data(), vk.size(), inst, ninst, proof, proof_len, g2, sg2, &ok, err, sizeof(err));
+    } else {   // no params file: the reference's unsafe setup, derived (gen_srs would do the same)
+      zkfhe_bfv_verify((const uint8_t *)vk.data(), vk.size(), inst, ninst, proof, proof_len, (const uint8_t *)seed, strlen(seed), &ok, err, sizeof(err));
+    }
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!ok) {
       fprintf(stderr, "Snark verification FAILED%s%s\n", err[0] ? ": " : "", err);
@@ -220,13 +230,26 @@ int main(int argc, char **argv) {
     return 0;
   }
   setenv("ZKFHE_SPIN_WAIT", "1", 0);  // one proof at a time: spinning waits are ~1.4 ms faster per proof than sleeping ones
+  // one command = one keygen or one proof: the 86 GB of digit-multiple tables a proving service builds once (1.1 s) would cost a
+  // hundred proofs' time here; a 2 GB budget builds in ~30 ms and serves the narrow commitments
+  setenv("ZKFHE_TABLE_GB", "2", 0);
   zkfhe_ctx *ctx = nullptr;
   if (zkfhe_ctx_create(0, nullptr, &ctx)) {
     fprintf(stderr, "no gfx950 device: %s\n", zkfhe_last_error(nullptr));
     return 1;
   }
   zkfhe_srs *srs = nullptr;
-  CHECK(zkfhe_srs_create(ctx, k, (const uint8_t *)seed, strlen(seed), &srs));
+  {
+    struct stat sb;
+    if (stat(srs_path.c_str(), &sb) == 0) {
+      CHECK(zkfhe_srs_load(ctx, srs_path.c_str(), &srs));
+    } else {
+      CHECK(zkfhe_srs_create(ctx, k, (const uint8_t *)seed, strlen(seed), &srs));
+      mkdir(params_dir.c_str(), 0755);
+      CHECK(zkfhe_srs_save(ctx, srs, srs_path.c_str()));
+      printf("wrote %s (unsafe test setup: ChaCha20Rng::from_seed([0; 32]))\n", srs_path.c_str());
+    }
+  }
   zkfhe_bfv_pk *pk = nullptr;
   if (cmd == "keygen") {
     zkfhe_bfv_config c{};
@@ -298,13 +321,13 @@ int main(int argc, char **argv) {
     CHECK(zkfhe_bfv_prove(ctx, srs, pk, text.c_str(), seed32, proof.data(), proof.size(), &len, instb.data(), &ninst, tm));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     {
-      // data/<name>.snark = "ZKFHESN1" | u64 n_instances | instances (32 B LE each) | proof bytes
+      // data/<name>.snark: zkfhe.h zkfhe_snark_encode ("ZKFHESN2": the instances and proof fields of snark-verifier-sdk's Snark as bincode writes them)
+      size_t slen = 0;
+      zkfhe_snark_encode(instb.data(), ninst, proof.data(), len, nullptr, 0, &slen);
+      std::vector<uint8_t> sb(slen);
+      CHECK(zkfhe_snark_encode(instb.data(), ninst, proof.data(), len, sb.data(), sb.size(), &slen));
       std::ofstream f(data_path + "/" + name + ".snark", std::ios::binary);
-      const uint64_t n64 = ninst;
-      f.write("ZKFHESN1", 8);
-      f.write((const char *)&n64, 8);
-      f.write((const char *)instb.data(), (std::streamsize)(32 * ninst));
-      f.write((const char *)proof.data(), (std::streamsize)len);
+      f.write((const char *)sb.data(), (std::streamsize)slen);
     }
     printf("Proving time: %.3fms  (witness %.1f, commit %.1f, quotient %.1f, open %.1f)\n", ms, tm[0], tm[1], tm[2], tm[3]);
     printf("proof: %zu bytes, %zu public inputs -> %s/%s.snark\n", len, ninst, data_path.c_str(), name.c_str());

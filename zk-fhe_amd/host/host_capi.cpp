@@ -7,6 +7,7 @@
 
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
+#include "srs_secret.hpp"
 #include "transcript.hpp"
 
 using namespace zkhost;
@@ -349,6 +350,89 @@ int zkfhe_poseidon_permute(uint8_t state_le[96]) {
     const U256 v = pos::to_canon(s[i]);
     memcpy(state_le + 32 * i, v.l, 32);
   }
+  return ZKFHE_OK;
+}
+int zkfhe_snark_encode(const uint8_t *instances_le, size_t n_instances, const uint8_t *proof, size_t proof_len, uint8_t *out, size_t cap, size_t *len) try {
+  if (!len || (!instances_le && n_instances) || (!proof && proof_len)) return ZKFHE_EINVAL;
+  const size_t need = 16 + 8 + 8 + 32 * n_instances + 8 + proof_len;
+  *len = need;
+  if (!out || cap < need) return (out && cap) ? ZKFHE_EINVAL : ZKFHE_OK;
+  uint8_t *p = out;
+  auto put64 = [&](uint64_t v) {
+    memcpy(p, &v, 8);
+    p += 8;
+  };
+  memcpy(p, "ZKFHESN2", 8);
+  p += 8;
+  put64(0);             // protocol: absent
+  put64(1);             // instances: one column ...
+  put64(n_instances);   // ... of n values, each the raw Montgomery limbs
+  for (size_t i = 0; i < n_instances; ++i) {
+    U256 v;
+    if (!load_fr(instances_le + 32 * i, v)) return ZKFHE_EINVAL;
+    const pos::F m = pos::from_canon(v);
+    memcpy(p, m.l, 32);
+    p += 32;
+  }
+  put64(proof_len);
+  if (proof_len) memcpy(p, proof, proof_len);
+  return ZKFHE_OK;
+} catch (const std::exception &) {
+  return ZKFHE_EINVAL;
+}
+int zkfhe_snark_decode(const uint8_t *snark, size_t snark_len, uint8_t *instances_le, size_t *n_instances, uint8_t *proof, size_t *proof_len) try {
+  if (!snark || snark_len < 16) return ZKFHE_EINVAL;
+  auto get64 = [&](size_t off) {
+    uint64_t v;
+    memcpy(&v, snark + off, 8);
+    return v;
+  };
+  size_t n = 0, ioff = 0, poff = 0, plen = 0;
+  bool mont_form = false;
+  if (!memcmp(snark, "ZKFHESN1", 8)) {
+    n = get64(8);
+    if (n > (snark_len - 16) / 32) return ZKFHE_EINVAL;
+    ioff = 16, poff = 16 + 32 * n, plen = snark_len - poff;
+  } else if (!memcmp(snark, "ZKFHESN2", 8)) {
+    const uint64_t prot = get64(8);
+    if (prot > snark_len - 16 || snark_len - 16 - prot < 24) return ZKFHE_EINVAL;
+    size_t o = 16 + prot;
+    if (get64(o) != 1) return ZKFHE_EINVAL;   // one instance column
+    n = get64(o + 8);
+    o += 16;
+    if (n > (snark_len - o) / 32 || snark_len - o - 32 * n < 8) return ZKFHE_EINVAL;
+    ioff = o, o += 32 * n;
+    plen = get64(o);
+    poff = o + 8;
+    if (plen != snark_len - poff) return ZKFHE_EINVAL;
+    mont_form = true;
+  } else {
+    return ZKFHE_EINVAL;
+  }
+  if (n_instances) *n_instances = n;
+  if (proof_len) *proof_len = plen;
+  if (instances_le)
+    for (size_t i = 0; i < n; ++i) {
+      if (mont_form) {
+        pos::F m;
+        memcpy(m.l, snark + ioff + 32 * i, 32);
+        U256 lim;
+        memcpy(lim.l, m.l, 32);
+        if (!(lim < fe::MOD)) return ZKFHE_EINVAL;
+        const U256 c = pos::to_canon(m);
+        memcpy(instances_le + 32 * i, c.l, 32);
+      } else {
+        memcpy(instances_le + 32 * i, snark + ioff + 32 * i, 32);
+      }
+    }
+  if (proof && plen) memcpy(proof, snark + poff, plen);
+  return ZKFHE_OK;
+} catch (const std::exception &) {
+  return ZKFHE_EINVAL;
+}
+int zkfhe_chacha20_block(const uint8_t key[32], const uint32_t counter_nonce[4], uint8_t out[64]) {
+  if (!key || !counter_nonce || !out) return ZKFHE_EINVAL;
+  chacha20_block(key, counter_nonce, out);
   return ZKFHE_OK;
 }
 int zkfhe_host_hash_mode(int mode) {

@@ -46,6 +46,11 @@ struct zkfhe_srs {
   // zkfhe_msm_batch_sharded over `comm`
   zkfhe_comm *comm = nullptr;
   size_t lo = 0, hi = 0;
+  // what zkfhe_srs_save writes besides k: the points as they came (unsharded SRS only) and the verifier's half, raw
+  // Montgomery coordinates x.c0 | x.c1 | y.c0 | y.c1
+  std::vector<G1Affine> g_host, gl_host;
+  uint8_t g2_raw[128], sg2_raw[128];
+  bool have_g2 = false;
   bool sharded() const { return comm != nullptr && zkfhe_comm_world(comm) > 1; }
 };
 
@@ -133,6 +138,10 @@ void free_workspace(Workspace *ws);
 int extend_cols(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk, Workspace *ws, const Fr *lagr, size_t count, Fr *ext);
 // prove.hip
 int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws);
+// verifier.cpp (host pairing arithmetic): G2 and s G2 as raw Montgomery coordinates; raw <-> canonical; on-curve check of raw coordinates
+void zk_srs_g2_from_secret(const U256 &s, uint8_t g2_raw[128], uint8_t sg2_raw[128]);
+bool zk_g2_raw_to_canon(const uint8_t raw[128], uint8_t canon[128]);   // false: a coordinate is not reduced or the point is off the twist
+bool zk_g2_canon_to_raw(const uint8_t canon[128], uint8_t raw[128]);
 
 static inline double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -1,6 +1,7 @@
 // The structured reference string on one MI355X (include/zkfhe.h "SRS"): replaces halo2-scaffold `gen_srs` /
 // ParamsKZG::setup (third-party, reached from reference examples/bfv.rs:311; README.md:34 "unsafe" seeded setup).
 #include "prover_internal.hpp"
+#include "srs_secret.hpp"
 
 extern "C" {
 
@@ -12,11 +13,8 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
   if (comm) zkfhe_comm_point_range(comm, n, &lo, &hi);   // this rank's bases
   const size_t nl = hi - lo;
   ZK_ARG(ctx, nl > 0);
-  Blake2b h(64, "zkfhe-srs");
-  h.update(seed, seed_len);
-  uint8_t d[64];
-  h.digest(d);
-  const Fr s = mont(from_bytes_wide(d));
+  const U256 s_canon = srs_secret(seed, seed_len);   // srs_secret.hpp: the reference's ChaCha20 derivation or the seeded one
+  const Fr s = mont(s_canon);
   const NttDomain *dom;
   CK(zk_domain(ctx, (int)k, &dom));
   // everything this function owns until it succeeds: released on every early return (an error code of a later step used
@@ -60,6 +58,7 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
     CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, nl));
     CK(zkfhe_download(ctx, host.data(), pts.p, nl * 64));
     CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, 0, which == 0 ? &srs->g : &srs->g_lagrange));
+    if (!comm) (which == 0 ? srs->g_host : srs->gl_host) = host;   // zkfhe_srs_save writes them
     if (which == 1) {
       static int small_c = -1;
       if (small_c < 0) {
@@ -69,6 +68,8 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
       if (small_c > 0 && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, small_c, &srs->g_lagrange_small));
     }
   }
+  zk_srs_g2_from_secret(s_canon, srs->g2_raw, srs->sg2_raw);
+  srs->have_g2 = true;
   guard.srs = nullptr;   // success: the caller owns it (the buffers go with the guard)
   *out = srs;
   return ZKFHE_OK;
@@ -90,6 +91,8 @@ int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_h
   zkfhe_srs *srs = new zkfhe_srs();
   srs->k = k;
   srs->hi = n;
+  srs->g_host.assign((const G1Affine *)g_host, (const G1Affine *)g_host + n);
+  srs->gl_host.assign((const G1Affine *)g_lagrange_host, (const G1Affine *)g_lagrange_host + n);
   int rc = zkfhe_basis_create(ctx, g_host, n, 0, &srs->g);
   if (!rc) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 0, &srs->g_lagrange);
   if (!rc && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
@@ -97,6 +100,79 @@ int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_h
     zkfhe_srs_destroy(ctx, srs);
     return rc;
   }
+  *out = srs;
+  return ZKFHE_OK;
+}
+
+int zkfhe_srs_g2(const zkfhe_srs *srs, uint8_t g2_le[128], uint8_t s_g2_le[128]) {
+  if (!srs || !g2_le || !s_g2_le || !srs->have_g2) return ZKFHE_EINVAL;
+  return zk_g2_raw_to_canon(srs->g2_raw, g2_le) && zk_g2_raw_to_canon(srs->sg2_raw, s_g2_le) ? ZKFHE_OK : ZKFHE_EINVAL;
+}
+
+int zkfhe_srs_set_g2(zkfhe_srs *srs, const uint8_t g2_le[128], const uint8_t s_g2_le[128]) {
+  if (!srs || !g2_le || !s_g2_le) return ZKFHE_EINVAL;
+  uint8_t a[128], b[128];
+  if (!zk_g2_canon_to_raw(g2_le, a) || !zk_g2_canon_to_raw(s_g2_le, b)) return ZKFHE_EINVAL;
+  memcpy(srs->g2_raw, a, 128);
+  memcpy(srs->sg2_raw, b, 128);
+  srs->have_g2 = true;
+  return ZKFHE_OK;
+}
+
+// halo2 ParamsKZG::write (SerdeFormat::RawBytes): u32 k | g | g_lagrange | g2 | s_g2, raw Montgomery coordinates
+int zkfhe_srs_save(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, srs && path);
+  const size_t n = (size_t)1 << srs->k;
+  if (srs->sharded() || srs->g_host.size() != n || srs->gl_host.size() != n) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: a sharded SRS holds only a slice of the points");
+  if (!srs->have_g2) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: the SRS has no G2 half (zkfhe_srs_set_g2)");
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("cannot write ") + tmp);
+  const uint32_t k = srs->k;
+  bool ok = fwrite(&k, 4, 1, f) == 1 && fwrite(srs->g_host.data(), 64, n, f) == n && fwrite(srs->gl_host.data(), 64, n, f) == n &&
+            fwrite(srs->g2_raw, 128, 1, f) == 1 && fwrite(srs->sg2_raw, 128, 1, f) == 1;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), path) != 0) {   // written aside and renamed: a reader never sees half a file
+    remove(tmp.c_str());
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("writing ") + path + " failed");
+  }
+  return ZKFHE_OK;
+}
+
+int zkfhe_srs_load(zkfhe_ctx *ctx, const char *path, zkfhe_srs **out) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, path && out);
+  *out = nullptr;
+  FILE *f = fopen(path, "rb");
+  if (!f) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("cannot open ") + path);
+  uint32_t k = 0;
+  std::vector<G1Affine> g, gl;
+  uint8_t raw[256], canon[128];
+  bool ok = fread(&k, 4, 1, f) == 1 && k >= 3 && k <= 20;
+  if (ok) {
+    const size_t n = (size_t)1 << k;
+    g.resize(n), gl.resize(n);
+    ok = fread(g.data(), 64, n, f) == n && fread(gl.data(), 64, n, f) == n && fread(raw, 256, 1, f) == 1 && fgetc(f) == EOF;
+  }
+  fclose(f);
+  if (!ok) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + ": not a params file (u32 k | 2^k g | 2^k g_lagrange | g2 | s_g2, RawBytes), or k outside 3..20");
+  // what halo2's RawBytes read checks: reduced coordinates, y^2 = x^3 + 3 (the identity (0, 0) cannot occur in an SRS)
+  const zk::Fq three = zk::fp_to_mont<zk::FqP>([] { zk::Fq t = zk::Fq::zero(); t.l[0] = 3; return t; }());
+  static const U256 QM = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+  for (const auto *v : {&g, &gl})
+    for (const G1Affine &p : *v) {
+      U256 x, y;
+      memcpy(x.l, p.x.l, 32);
+      memcpy(y.l, p.y.l, 32);
+      if (!(x < QM) || !(y < QM) || !(p.y * p.y == p.x * p.x * p.x + three)) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + ": a G1 point is not on the curve");
+    }
+  if (!zk_g2_raw_to_canon(raw, canon) || !zk_g2_raw_to_canon(raw + 128, canon)) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string(path) + ": a G2 point is not on the curve");
+  zkfhe_srs *srs = nullptr;
+  CK(zkfhe_srs_from_points(ctx, k, (const zkfhe_g1_affine *)g.data(), (const zkfhe_g1_affine *)gl.data(), &srs));
+  memcpy(srs->g2_raw, raw, 128);
+  memcpy(srs->sg2_raw, raw + 128, 128);
+  srs->have_g2 = true;
   *out = srs;
   return ZKFHE_OK;
 }

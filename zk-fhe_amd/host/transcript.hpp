@@ -264,12 +264,13 @@ class Transcript {
     return from_bytes_wide(d);
   }
   static void compress(const AffinePoint &p, uint8_t b[32]) {
+    const ptenc::Layout &L = ptenc::layout();
     if (p.is_identity()) {
       memset(b, 0, 32);
-      b[31] |= ptenc::IDENTITY_BIT;
+      b[31] |= L.identity_bit;
     } else {
       memcpy(b, p.x.l, 32);
-      if (p.y.l[0] & 1) b[31] |= ptenc::SIGN_BIT;
+      if (p.y.l[0] & 1) b[31] |= L.sign_bit;
     }
   }
   size_t poseidon_permutations() const { return sp.n_perm; }

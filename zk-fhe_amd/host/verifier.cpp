@@ -13,6 +13,7 @@
 #include "bfv_circuit.hpp"
 #include "pairing.hpp"
 #include "shplonk.hpp"
+#include "srs_secret.hpp"
 #include "transcript.hpp"
 #include "vk.hpp"
 
@@ -20,6 +21,10 @@ using namespace zkhost;
 using zk::Fr;
 
 zk::Fr zk_fr_root_of_unity(int log_n);  // csrc/core.hip
+// the SRS side (srs.hip) borrows the host G2 arithmetic of this file; declared in prover_internal.hpp as well
+void zk_srs_g2_from_secret(const U256 &s, uint8_t g2_raw[128], uint8_t sg2_raw[128]);
+bool zk_g2_raw_to_canon(const uint8_t raw[128], uint8_t canon[128]);
+bool zk_g2_canon_to_raw(const uint8_t canon[128], uint8_t raw[128]);
 
 namespace {
 
@@ -50,16 +55,17 @@ struct Reader {
     memcpy(b, p + pos, 32);
     pos += 32;
     AffinePoint a;
-    if (b[31] & ptenc::IDENTITY_BIT) {
+    const ptenc::Layout &L = ptenc::layout();
+    if (ptenc::is_identity_encoding(b)) {
       // the identity has exactly one encoding (halo2curves rejects anything else)
       for (int i = 0; i < 31; ++i)
         if (b[i]) throw std::runtime_error("non-canonical encoding of the identity");
-      if (b[31] != ptenc::IDENTITY_BIT) throw std::runtime_error("non-canonical encoding of the identity");
+      if (b[31] != L.identity_bit) throw std::runtime_error("non-canonical encoding of the identity");
       a.x = fe::zero();
       a.y = fe::zero();
     } else {
-      const unsigned sign = (b[31] & ptenc::SIGN_BIT) ? 1u : 0u;
-      b[31] &= ptenc::X_MASK;
+      const unsigned sign = (b[31] & L.sign_bit) ? 1u : 0u;
+      b[31] &= L.x_mask;
       memcpy(a.x.l, b, 32);
       static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
       if (!(a.x < QMOD)) throw std::runtime_error("point x not reduced");
@@ -190,11 +196,7 @@ struct SrsG2 {
   pairing::Pt<pairing::Fq2> g2, sg2;
 };
 SrsG2 srs_g2_from_seed(const uint8_t *srs_seed, size_t seed_len) {
-  Blake2b hs(64, "zkfhe-srs");
-  hs.update(srs_seed, seed_len);
-  uint8_t d[64];
-  hs.digest(d);
-  const U256 s = from_bytes_wide(d);
+  const U256 s = srs_secret(srs_seed, seed_len);
   SrsG2 r;
   r.g2 = pairing::g2_generator();
   r.sg2 = pairing::ec_mul(r.g2, s);
@@ -440,9 +442,67 @@ bool verify_impl(const Vk &vk, const std::vector<U256> &inst, const uint8_t *pro
   return pairing::pairing_product_is_one({{Fp, g2}, {nW, sg2}});
 }
 
+const U256 QMOD_C = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+
+void g2_to_raw(const pairing::Pt<pairing::Fq2> &p, uint8_t raw[128]) {
+  const zk::Fq *c[4] = {&p.x.c[0], &p.x.c[1], &p.y.c[0], &p.y.c[1]};
+  for (int i = 0; i < 4; ++i) memcpy(raw + 32 * i, c[i]->l, 32);
+}
+bool g2_from_canon(const uint8_t canon[128], pairing::Pt<pairing::Fq2> &p) {
+  U256 c[4];
+  memcpy(c, canon, 128);
+  for (const auto &x : c)
+    if (!(x < QMOD_C)) return false;
+  p.x.c = {pairing::fq_from_canon(c[0]), pairing::fq_from_canon(c[1])};
+  p.y.c = {pairing::fq_from_canon(c[2]), pairing::fq_from_canon(c[3])};
+  p.inf = false;
+  return pairing::g2_on_curve(p);
+}
+
 }  // namespace
 
+void zk_srs_g2_from_secret(const U256 &s, uint8_t g2_raw[128], uint8_t sg2_raw[128]) {
+  const pairing::Pt<pairing::Fq2> g = pairing::g2_generator();
+  g2_to_raw(g, g2_raw);
+  g2_to_raw(pairing::ec_mul(g, s), sg2_raw);
+}
+bool zk_g2_raw_to_canon(const uint8_t raw[128], uint8_t canon[128]) {
+  for (int i = 0; i < 4; ++i) {
+    zk::Fq m;
+    memcpy(m.l, raw + 32 * i, 32);
+    U256 lim;
+    memcpy(lim.l, m.l, 32);
+    if (!(lim < QMOD_C)) return false;   // a Montgomery residue is reduced too
+    const zk::Fq c = zk::fp_from_mont<zk::FqP>(m);
+    memcpy(canon + 32 * i, c.l, 32);
+  }
+  pairing::Pt<pairing::Fq2> p;
+  return g2_from_canon(canon, p);
+}
+bool zk_g2_canon_to_raw(const uint8_t canon[128], uint8_t raw[128]) {
+  pairing::Pt<pairing::Fq2> p;
+  if (!g2_from_canon(canon, p)) return false;
+  g2_to_raw(p, raw);
+  return true;
+}
+
 extern "C" {
+
+int zkfhe_srs_file_g2(const char *path, uint32_t *k_out, uint8_t g2_le[128], uint8_t s_g2_le[128]) {
+  if (!path || !g2_le || !s_g2_le) return ZKFHE_EINVAL;
+  FILE *f = fopen(path, "rb");
+  if (!f) return ZKFHE_EINVAL;
+  uint32_t k = 0;
+  uint8_t raw[256];
+  bool ok = fread(&k, 4, 1, f) == 1 && k >= 1 && k <= 28;
+  const long want = 4 + (long)2 * 64 * ((long)1 << (ok ? k : 1)) + 256;
+  ok = ok && fseek(f, 0, SEEK_END) == 0 && ftell(f) == want && fseek(f, want - 256, SEEK_SET) == 0 && fread(raw, 256, 1, f) == 1;
+  fclose(f);
+  if (!ok) return ZKFHE_EINVAL;
+  if (!zk_g2_raw_to_canon(raw, g2_le) || !zk_g2_raw_to_canon(raw + 128, s_g2_le)) return ZKFHE_EINVAL;
+  if (k_out) *k_out = k;
+  return ZKFHE_OK;
+}
 
 int zkfhe_bfv_verify(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *instances, size_t n_instances, const uint8_t *proof, size_t proof_len,
                      const uint8_t *srs_seed, size_t seed_len, int *accepted, char *err, size_t err_len) {
@@ -473,16 +533,9 @@ int zkfhe_bfv_verify_g2(const uint8_t *vk_bytes, size_t vk_len, const uint8_t *i
     for (const auto &v : inst)
       if (!(v < fe::MOD)) throw std::runtime_error("instance not reduced");
     auto load = [](const uint8_t *b) {
-      static const U256 QMOD = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
-      U256 c[4];
-      memcpy(c, b, 128);
-      for (const auto &x : c)
-        if (!(x < QMOD)) throw std::runtime_error("G2 coordinate not reduced");
       pairing::Pt<pairing::Fq2> p;
-      p.x.c = {pairing::fq_from_canon(c[0]), pairing::fq_from_canon(c[1])};
-      p.y.c = {pairing::fq_from_canon(c[2]), pairing::fq_from_canon(c[3])};
-      // on the twist y^2 = x^3 + 3/(9+i)?  (subgroup membership is the caller's responsibility, as in halo2's ParamsKZG::read)
-      if (!pairing::g2_on_curve(p)) throw std::runtime_error("G2 point not on the curve");
+      // reduced coordinates, on the twist y^2 = x^3 + 3/(9+i)  (subgroup membership is the caller's responsibility, as in halo2's ParamsKZG::read)
+      if (!g2_from_canon(b, p)) throw std::runtime_error("G2 point: a coordinate is not reduced or the point is not on the curve");
       return p;
     };
     SrsG2 srs;
