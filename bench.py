@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="concurrent proofs per GPU (one HIP stream + workspace each); 0 = 16 at k13, 2 at k16, 1 at k19")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="k13", help="k13 = the headline (BASELINE configs[1]); k16 / k19 = configs[3] / [4], single GPU")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra, separately reported steady-state pass (0 = skip)")
+    ap.add_argument("--mode", choices=["batch", "one-proof-sharded"], default="batch",
+                    help="batch = independent proofs, one replica per rank (weak scaling: the headline); one-proof-sharded = every proof is made by ALL ranks "
+                         "(BASELINE configs[4]: commitments by point range with an RCCL all-gather of the partials, coset extension and quotient by column, "
+                         "evaluations by index -- strong scaling, one proof in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stagger-ms", type=float, default=None, help="start offset between the concurrent proofs of the timed wave")
     ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
@@ -99,6 +103,19 @@ def main():
     # transcript hashing mode from the host CPUs each rank can count on (the ranks of this launch share one node)
     host = batch.configure_host(zk, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     ctx = zk.Context(local_rank)
+    sharded = args.mode == "one-proof-sharded" and world > 1
+    comm = None
+    if sharded:
+        # one communicator for the job: RCCL (the unique id of rank 0 goes round as a byte tensor) or, in the gloo control-flow
+        # test, a host all-gather callback
+        if backend == "nccl":
+            uid = torch.frombuffer(bytearray(zk.Comm.unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).cuda()
+            dist.broadcast(uid, 0)
+            comm = zk.Comm(ctx, rank, world, unique_id=bytes(uid.cpu().numpy().tobytes()))
+        else:
+            comm = zk.Comm(ctx, rank, world, all_gather=lambda b: batch.all_gather_bytes(b, world))
+        args.streams = 1
+    seed_rank = 0 if sharded else rank   # a sharded proof: the same input and the same blinding seed on every rank
     conf = CONFIGS[args.config]
     big = args.config != "k13"
     if not args.streams:
@@ -112,16 +129,16 @@ def main():
         empty = json.dumps({k: ["0"] * (N + 1 if k == "cyclo" else N) for k in ("pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo")})
         # the reference's own data/bfv/bfv.in verbatim (tests/golden/bfv is a byte-identical copy), then seeded synthetic encryptions
         inputs = [open(os.path.join(ROOT, "tests", "golden", "bfv", "bfv.in"), "rb").read()]
-        inputs += [synth_bfv_input(20240613 + 1000 * rank + i).encode() for i in range(3)]   # the JSON text the C ABI takes
+        inputs += [synth_bfv_input(20240613 + 1000 * seed_rank + i).encode() for i in range(3)]   # the JSON text the C ABI takes
     else:
         from zk_fhe_amd import inputs as gen
         n_ring, q_mod = conf["N"], conf["Q"]
-        inputs = [json.dumps(gen.generate(n_ring, q_mod, T, B, seed=20240613 + 1000 * rank + i)).encode() for i in range(2)]
+        inputs = [json.dumps(gen.generate(n_ring, q_mod, T, B, seed=20240613 + 1000 * seed_rank + i)).encode() for i in range(2)]
         empty = json.dumps(gen.empty(n_ring))
         zcfg = zk.bfv_auto_config(inputs[0], (n_ring, q_mod, T, B), conf["k"], transcript=args.transcript)   # halo2-base auto-configuration
-    srs = zk.Srs(ctx, conf["k"])
+    srs = zk.Srs(ctx, conf["k"], comm=comm)
     pk = zk.BfvProvingKey(ctx, srs, empty, (n_ring, q_mod, T, B), zcfg, replay=not big)
-    seeds = [b"bench-%d-%d" % (rank, i) for i in range(args.steps + args.warmup + 4)]
+    seeds = [b"bench-%d-%d" % (seed_rank, i) for i in range(args.steps + args.warmup + 4)]
 
     def barrier():
         ctx.sync()
@@ -169,13 +186,14 @@ def main():
     si += args.steps
     dev = "cuda" if (world > 1 and backend == "nccl") else None
     dt = batch.max_over_ranks(dt, device=dev)
+    jobs = 1 if sharded else world   # proofs per step over the whole job: every rank its own, or all ranks the same one
     host_cpu_by_rank = batch.gather_floats(host_cpu_ms, device=dev)
     stage = acc / max(1, args.steps)    # a copy: the passes below keep adding to acc
     # steady state, reported separately (never the headline): the driver's --steps may be a single wave of concurrent proofs,
     # whose rate is (proofs) / (latency of the slowest); this pass keeps every stream busy for >= steady_seconds
     steady = None
     if args.steady_seconds > 0:
-        n_more = max(4 * n_streams, int(args.steady_seconds * world * args.steps / dt))
+        n_more = max(4 * n_streams, int(args.steady_seconds * args.steps / dt))
         ts = time.perf_counter()
         batch.run_concurrent(list(range(si, si + n_more)), ctxs, one_proof)
         for c in ctxs:
@@ -252,15 +270,15 @@ def main():
             except Exception as e:  # noqa: BLE001  -- the CPU leg is a label: never lose the GPU measurement over it
                 cpu = {"value": None, "unit": "proofs/s", "cores": None, "kind": "port", "sample": "native CPU prover failed: %r" % (e,)}
         out = {
-            "metric": "BFV proofs/sec (k=%d)" % conf["k"], "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
+            "metric": "BFV proofs/sec (k=%d)" % conf["k"], "value": jobs * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if (world == 1 and not big) else None,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if (world == 1 and not big) else None,
             "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
             "config": {"workload": ("one proof per step, k=13, N=1024, Q=536870909 (BASELINE configs[1]); 197 advice columns, pinned bfv.json layout; "
                                     "inputs: the reference's data/bfv/bfv.in + 3 seeded synthetic encryptions") if not big else
                                    "one proof per step, k=%d, N=%d, Q=2^60-93 (BASELINE configs[%d]); columns by halo2-base auto-configuration"
                                    % (conf["k"], conf["N"], 3 if args.config == "k16" else 4),
-                       "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
+                       "mode": args.mode if world > 1 else "batch", "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
                        "host_cpu_ms_per_proof_by_rank": host_cpu_by_rank, "host": host, "verified": bool(verified),
                        "steady_state_proofs_per_s": steady,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
@@ -282,6 +300,8 @@ def main():
         print(json.dumps(out))
     pk.destroy()
     srs.destroy()
+    if comm is not None:
+        comm.destroy()
     if world > 1:
         dist.destroy_process_group()
 

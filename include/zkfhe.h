@@ -159,12 +159,24 @@ int zkfhe_comm_create_with_transport(zkfhe_ctx *ctx, int rank, int world, zkfhe_
 int zkfhe_comm_destroy(zkfhe_ctx *ctx, zkfhe_comm *comm);
 int zkfhe_comm_rank(const zkfhe_comm *comm);
 int zkfhe_comm_world(const zkfhe_comm *comm);
+/* non-zero when commitments made with this communicator go through a collective: world > 1, or a one-rank RCCL communicator */
+int zkfhe_comm_active(const zkfhe_comm *comm);
 void zkfhe_comm_point_range(const zkfhe_comm *comm, size_t n, size_t *lo, size_t *hi);
 int zkfhe_comm_all_gather(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes);
 /* basis_slice: a basis made of this rank's point range; column c's scalars for that range at scalars_dev + c * col_stride
  * (col_stride = the full column length when scalars_dev points at row lo of column 0).  out_dev[c]: the full MSM, on every rank. */
 int zkfhe_msm_batch_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev,
                             size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev);
+/* The same with the collective off the context's stream: the partial MSM runs on the context's stream, the all-gather and the sum
+ * on the communicator's own, so kernels queued on the context's stream after the call (the next batch's partial MSM, witness
+ * kernels) overlap the exchange over xGMI.  out_dev is complete after zkfhe_comm_join: block_host = 0 makes the context's stream
+ * wait for every collective queued so far, 1 the calling thread.  zkfhe_comm_record_event records a HIP event (hipEvent_t)
+ * behind them instead.  With a callback transport (host all-gather) the call completes on the context's stream like
+ * zkfhe_msm_batch_sharded and the join is a plain wait.  Every rank must issue these calls in the same order. */
+int zkfhe_msm_batch_sharded_async(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev, size_t col_stride,
+                                  size_t n_cols, zkfhe_g1_affine *out_dev);
+int zkfhe_comm_join(zkfhe_ctx *ctx, zkfhe_comm *comm, int block_host);
+int zkfhe_comm_record_event(zkfhe_ctx *ctx, zkfhe_comm *comm, void *hip_event);
 
 /* ---- G1 helpers (device, used by tests and by the SRS builder) ------------------------------ */
 /* out[i] = a[i] + b[i] (affine in, affine out; handles doubling / inverse / identity) */

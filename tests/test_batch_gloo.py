@@ -142,7 +142,7 @@ def _circuit(which):
 def _sharded_worker(rank, world, port, which, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("ZKFHE_TABLE_GB", "4")
+    os.environ.setdefault("ZKFHE_TABLE_GB", "4" if world <= 4 else "1")   # per SRS half and per rank: eight ranks share this one GPU
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import torch  # noqa: F401
     import zk_fhe_amd as zk
@@ -190,12 +190,13 @@ def _run_ranks(target, world, *args, timeout=900):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,world", [("toy", 2), ("toy", 3), ("bfv13", 2), ("bfv13", 4), ("k14", 2)])
+@pytest.mark.parametrize("which,world", [("toy", 2), ("toy", 3), ("toy", 8), ("bfv13", 2), ("bfv13", 4), ("bfv13", 8), ("k14", 2)])
 def test_sharded_prover_ranks_share_one_gpu_same_bytes(which, world):
     """zkfhe_srs_create_sharded + zkfhe_bfv_keygen / zkfhe_bfv_prove over a W-rank communicator: every commitment is the sum of
     W point-range partials gathered across processes, and the coset extension + quotient are sharded by column (each rank
     extends and evaluates only the columns of its permutation chunks; the W partial quotients are gathered and summed);
-    verifying key and proof must equal the single-GPU ones.  Three ranks: ragged chunk ranges.  "bfv13" is the
+    verifying key and proof must equal the single-GPU ones.  Three ranks: ragged chunk ranges; eight ranks (SURVEY.md section 4:
+    byte identity at 1 / 2 / 4 / 8): on the toy circuit more ranks than permutation chunks, so some ranks own no column.  "bfv13" is the
     reference's bfv.in at k = 13: each rank's SRS slice takes the digit-multiple table path (k_msm_table) with its own,
     wider digits (a slice of 2^13 / W points fits more bits into the same budget than the whole basis)."""
     got = _run_ranks(_sharded_worker, world, which)
@@ -287,5 +288,38 @@ def test_rccl_transport_one_rank_smoke():
     assert np.array_equal(ctx.msm_sharded(comm, basis, S, 0), orc.msm(S, bases))
     basis.destroy()
     send.free(), recv.free()
+    comm.destroy()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_proof_through_one_rank_rccl_communicator_matches_plain():
+    """The whole collective path of the sharded prover on ONE GPU: an SRS created with a one-rank RCCL communicator
+    (zkfhe_comm_create, world = 1, a real unique id) makes every commitment of keygen and prove go through
+    zkfhe_msm_batch_sharded_async -- the partial MSM on the context's stream, ncclAllGather(ncclUint8) and the sum on the
+    communicator's own stream, two gather buffers alternating, the phase-0 points returned through an event recorded behind the
+    collective while the gadget kernels already run -- and the key and the proof bytes must be the plain single-GPU ones.
+    Both transcripts: with Poseidon the early phase-1 commitment puts two commitment batches in flight at once."""
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    ctx = zk.Context(0)
+    try:
+        uid = zk.Comm.unique_id()
+    except zk.ZkfheError as e:
+        pytest.skip("librccl.so is not loadable here: %s" % e)
+    comm = zk.Comm(ctx, 0, 1, unique_id=uid)
+    for which in ("toy", "bfv13"):
+        text_kg, text, params, cfg, k = _circuit(which)
+        for transcript in ("poseidon", "blake2b"):
+            cfg_t = zk.BfvConfig(cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, cfg.lookup_bits, cfg.break_points, transcript)
+            out = []
+            for c in (comm, None):
+                srs = zk.Srs(ctx, k, comm=c)
+                pk = zk.BfvProvingKey(ctx, srs, text_kg, params, cfg_t)
+                proofs = [pk.prove(text, b"rccl-%d" % i)[0] for i in range(3)]     # three in a row: the gather buffers alternate
+                out.append((pk.info()["vk_digest"], proofs))
+                pk.destroy()
+                srs.destroy()
+            assert out[0] == out[1], (which, transcript)
     comm.destroy()
     ctx.close()

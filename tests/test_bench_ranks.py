@@ -38,3 +38,27 @@ def test_bench_two_ranks_one_gpu_gloo():
     assert d["value"] > 0 and abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-6   # whole job: both ranks' proofs over the slowest rank's time
     assert d["vs_baseline"] is None and d["cpu_baseline"] is None
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+    assert d["config"]["mode"] == "batch" and d["config"]["verified"] is True
+    assert len(d["config"]["host_cpu_ms_per_proof_by_rank"]) == 2 and d["config"]["host"]["hash_mode"] in ("latency", "shared")
+
+
+@pytest.mark.gpu
+def test_bench_one_proof_sharded_two_ranks_one_gpu_gloo():
+    """bench.py --mode one-proof-sharded (BASELINE configs[4]'s shape, here at k = 13 for time): both ranks make EVERY proof
+    together -- sharded SRS, commitments gathered across the ranks (gloo callback here, RCCL on a node), quotient by column --
+    and the line says so: strong scaling, value = proofs of the job, not per rank; the timed proofs verify."""
+    env = dict(os.environ)
+    env["ZKFHE_BENCH_BACKEND"] = "gloo"
+    env["ZKFHE_TABLE_GB"] = "4"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--steady-seconds", "0", "--mode", "one-proof-sharded", "--transcript", "blake2b"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "one-proof-sharded" and d["config"]["verified"] is True
+    assert abs(d["value"] - 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6      # three proofs of the JOB over the wall time
+    assert len(d["config"]["host_cpu_ms_per_proof_by_rank"]) == 2 and d["config"]["host"]["usable_cpus"] >= 1

@@ -205,3 +205,72 @@ def test_host_poly_mul_u32_is_the_integer_product():
     assert run([1 << 32, 1], [1, 1])[0] != 0          # a coefficient of 33 bits
     assert run([1, 2, 3], [1, 2, 3])[0] != 0          # not a power of two
     assert run([1] * 4096, [1] * 4096)[0] != 0        # too long
+
+
+def test_machine_word_phase0_equals_the_restatement(monkeypatch):
+    """host/bfv_phase0_fast.hpp (what a proof runs: u64 / u128 arithmetic, closed-form division by x^N + 1) against bfv_phase0
+    (src/poly.rs + src/poly_chip.rs restated on BigInt): the same advice table, instances and cell counts -- on the reference's
+    files, on seeded encryptions, and on edge inputs: coefficients equal to Q (src/poly.rs:28 allows `<=`), leading zeros, an
+    all-zero u (the zero-dividend branch of divide_by_cyclo), a `+` sign (outside the fast grammar: falls back, same result).
+    ZKFHE_PHASE0=generic forces the restatement."""
+    from zk_fhe_amd import inputs as gen
+    cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
+    zcfg = zk.BfvConfig.from_pinning(cfgj)
+    N, Q, T, B = PRM
+    cases = [open(os.path.join(G, "bfv.in")).read(), open(os.path.join(G, "bfv_empty.in")).read()]
+    for seed in (1, 2):
+        cases.append(json.dumps(gen.generate(N, Q, T, B, seed=seed)))
+    inp = gen.generate(N, Q, T, B, seed=3)
+    edge = dict(inp)
+    edge["pk0"] = [str(Q)] + ["000" + v for v in inp["pk0"][1:]]          # == Q passes the reference's assert; leading zeros
+    edge["pk1"] = [str(Q - 1)] * N
+    cases.append(json.dumps(edge))
+    cases.append(json.dumps(dict(inp, e1=["+" + inp["e1"][0]] + inp["e1"][1:])))   # not in the fast grammar
+    zero_u = dict(inp, u=["0"] * N)
+    cases.append(json.dumps(zero_u))
+
+    def both(text):
+        out = []
+        for mode in ("fast", "generic"):
+            if mode == "generic":
+                monkeypatch.setenv("ZKFHE_PHASE0", "generic")
+            else:
+                monkeypatch.delenv("ZKFHE_PHASE0", raising=False)
+            try:
+                t = zk.bfv_build_tables(text, PRM, zcfg, GAMMA, keygen_mode=False, replay=True)
+                out.append((t["cells"], t["instance"].tobytes(), t["advice"].tobytes()))
+            except zk.ZkfheError as e:
+                out.append(str(e))
+        return out
+    n_ok = 0
+    for text in cases:
+        a, b = both(text)
+        assert a == b
+        n_ok += not isinstance(a, str)
+    assert n_ok >= 5
+    # errors are worded by the restatement whichever path is asked for
+    for bad in (dict(inp, m=[str(Q + 1)] + inp["m"][1:]), dict(inp, c0=inp["c0"][:-1])):
+        a, b = both(json.dumps(bad))
+        assert isinstance(a, str) and a == b
+    # a cyclo of another shape is outside the closed forms: the long division of the restatement runs, whatever it gives
+    a, b = both(json.dumps(dict(inp, cyclo=["2"] + inp["cyclo"][1:])))
+    assert a == b
+
+
+def test_machine_word_phase0_wide_products(tmp_path):
+    """N = 4096 with the 60-bit modulus (BASELINE configs[3]): the products pk_i * u have 132-bit coefficients (three words) and come
+    from the PolyMulBackend -- the GPU convolution in a proof, a schoolbook product in tests/native/phase0_check.cpp.  Cell stream,
+    public inputs, every PolyChip's cells, offsets and max_bits must equal the BigInt restatement's."""
+    import shutil
+    import subprocess
+    from zk_fhe_amd import inputs as gen
+    cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else shutil.which("clang++")
+    if not cxx:
+        pytest.skip("no clang++ (the host headers use clang's carry builtins)")
+    N, Q = 4096, (1 << 60) - 93
+    path = tmp_path / "in.json"
+    path.write_text(json.dumps(gen.generate(N, Q, 7, 19, seed=5)))
+    exe = str(tmp_path / "phase0_check")
+    subprocess.run([cxx, "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "zk-fhe_amd", "host"), os.path.join(HERE, "native", "phase0_check.cpp"), "-o", exe, "-lpthread"], check=True)
+    out = subprocess.run([exe, str(path), str(N), str(Q)], capture_output=True, text=True)
+    assert out.returncode == 0 and "fast path taken 1" in out.stdout and "identical 1" in out.stdout, out.stdout + out.stderr

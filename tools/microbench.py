@@ -68,8 +68,10 @@ def main():
     res["fr_add_elementwise_GBs"] = 64.0 * n / (float(np.median(ts)) * 1e-3) / 1e9
     # NTT sweep, 256 columns
     res["ntt"] = {}
-    for log_n in (10, 12, 13, 15, 16):
-        cols = 256 if log_n <= 13 else 32
+    # 256 columns at 2^13 / 2^15 / 2^16 / 2^19 (4 GiB in + 4 GiB out), 2^21 as 64 columns (the same 4 GiB)
+    big = "--big" in sys.argv
+    for log_n in (10, 12, 13, 15, 16) + ((19, 21) if big else ()):
+        cols = 256 if log_n <= 19 else 64
         buf = ctx.alloc(cols * (32 << log_n))
         out = ctx.alloc(cols * (32 << log_n))   # out of place (zkfhe_ntt_batch_to): how the prover runs every column transform
         ctx._check(ctx.lib.zkfhe_memset_dev(ctx.h, buf.at(0), 1, buf.nbytes))
@@ -115,6 +117,44 @@ def main():
             res["msm"]["c=%d cols=%d" % (c, cols)] = {"ms": ms, "us_per_msm": ms * 1e3 / cols}
             ds.free(), do.free()
         B.destroy()
+    if big:
+        # MSM at n = 2^16 and 2^19 (the bucket pipeline; 2^13 is above), two scalar mixes per size:
+        #   uniform = 254-bit scalars (worst case);  witness = the mix of a gate column of the BFV circuit -- half the cells 8-bit
+        #   limbs of the range checks, a quarter 30-bit coefficients, 15 % 70-bit intermediate sums, 10 % full-width (inverses)
+        res["msm_big"] = {}
+        for log_n, cols in ((16, 32), (19, 8)):
+            nb = 1 << log_n
+            gen_b = np.array([limbs((1 << 256) % Q_MOD) + limbs((2 << 256) % Q_MOD)] * nb, dtype=np.uint64)
+            kk = rng.integers(1, 1 << 62, nb)
+            ks_b = np.array([limbs(((int(x) % R_MOD) << 256) % R_MOD) for x in kk], dtype=np.uint64)
+            bases_b = ctx.g1_mul(gen_b, ks_b)
+            Bb = zk.Basis(ctx, bases_b)
+            for mix in ("uniform", "witness"):
+                raw = np.frombuffer(rng.bytes(32 * nb * cols), dtype=np.uint64).reshape(-1, 4).copy()
+                raw[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+                if mix == "witness":
+                    # canonical small values, then to Montgomery form on the device (the prover's columns are Montgomery values)
+                    u = rng.random(nb * cols)
+                    raw[u < 0.9, 1:] = 0
+                    raw[u < 0.9, 1] = raw[u < 0.9, 0] & np.uint64(0x3F)          # 70 bits
+                    raw[u < 0.75, 1] = 0
+                    raw[u < 0.75, 0] &= np.uint64((1 << 30) - 1)
+                    raw[u < 0.5, 0] &= np.uint64(0xFF)
+                ds = ctx.to_device(raw)
+                if mix == "witness":
+                    ctx._check(ctx.lib.zkfhe_fr_to_mont(ctx.h, ds.at(0), ds.at(0), nb * cols))
+                do = ctx.alloc(cols * 64)
+                for _ in range(2):
+                    ctx.msm_dev(Bb, ds, cols, do)
+                ts = []
+                for _ in range(5):
+                    ctx.timer_start()
+                    ctx.msm_dev(Bb, ds, cols, do)
+                    ts.append(ctx.timer_stop_ms())
+                ms = float(np.median(ts))
+                res["msm_big"]["2^%d x %d %s" % (log_n, cols, mix)] = {"ms": ms, "ms_per_msm": ms / cols, "GBs_algorithmic": 96.0 * nb * cols / (ms * 1e-3) / 1e9}
+                ds.free(), do.free()
+            Bb.destroy()
     print(json.dumps(res, indent=1))
 
 

@@ -99,6 +99,17 @@ struct zkfhe_comm {
   void *transport_user = nullptr;
   uint8_t *host_send = nullptr, *host_recv = nullptr;   // pinned staging of the callback transport
   size_t host_cap = 0;
+  // zkfhe_msm_batch_sharded_async (RCCL / one-rank communicators): the all-gather of the partial commitments and their sum run
+  // on the communicator's own stream, so that whatever the caller queues on the context's stream next -- the partial MSM of the
+  // following batch, the witness kernels -- overlaps the collective.  Two gather buffers alternate: batch i + 1 may fill its
+  // partials while batch i is still on the wire.
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_msm = nullptr, ev_done[2] = {nullptr, nullptr};
+  void *buf[2] = {nullptr, nullptr};
+  size_t buf_sz[2] = {0, 0};
+  bool pending[2] = {false, false};
+  int next = 0, last = -1;
+  bool has_aux() const { return nccl != nullptr || world == 1; }   // the callback transport blocks the host: it stays on the context's stream
 };
 
 extern "C" {
@@ -158,7 +169,14 @@ int zkfhe_comm_destroy(zkfhe_ctx *ctx, zkfhe_comm *comm) {
   ZK_ENTER(ctx);
   if (!comm) return ZKFHE_OK;
   if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  if (comm->aux) (void)hipStreamSynchronize(comm->aux);
   if (comm->nccl) rccl().CommDestroy(comm->nccl);
+  for (int b = 0; b < 2; ++b) {
+    if (comm->buf[b]) (void)hipFree(comm->buf[b]);
+    if (comm->ev_done[b]) (void)hipEventDestroy(comm->ev_done[b]);
+  }
+  if (comm->ev_msm) (void)hipEventDestroy(comm->ev_msm);
+  if (comm->aux) (void)hipStreamDestroy(comm->aux);
   if (comm->host_send) (void)hipHostFree(comm->host_send);
   if (comm->host_recv) (void)hipHostFree(comm->host_recv);
   delete comm;
@@ -167,6 +185,7 @@ int zkfhe_comm_destroy(zkfhe_ctx *ctx, zkfhe_comm *comm) {
 
 int zkfhe_comm_rank(const zkfhe_comm *comm) { return comm ? comm->rank : 0; }
 int zkfhe_comm_world(const zkfhe_comm *comm) { return comm ? comm->world : 1; }
+int zkfhe_comm_active(const zkfhe_comm *comm) { return comm && (comm->world > 1 || comm->nccl != nullptr) ? 1 : 0; }
 
 void zkfhe_comm_point_range(const zkfhe_comm *comm, size_t n, size_t *lo, size_t *hi) {
   const size_t w = comm ? (size_t)comm->world : 1, r = comm ? (size_t)comm->rank : 0;
@@ -211,12 +230,91 @@ int zkfhe_comm_all_gather(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev
   return ZKFHE_OK;
 }
 
+// all-gather on an explicit stream (the RCCL / one-rank halves of zkfhe_comm_all_gather)
+static int gather_on(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes, hipStream_t stream) {
+  if (comm->nccl) {
+    const ncclResult_t rc = rccl().AllGather(send_dev, recv_dev, bytes, ncclUint8, comm->nccl, stream);
+    if (rc != ncclSuccess) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("ncclAllGather failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
+    return ZKFHE_OK;
+  }
+  ZK_HIP(ctx, hipMemcpyAsync(recv_dev, send_dev, bytes, hipMemcpyDeviceToDevice, stream));
+  return ZKFHE_OK;
+}
+
+int zkfhe_msm_batch_sharded_async(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev, size_t col_stride,
+                                  size_t n_cols, zkfhe_g1_affine *out_dev) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, comm != nullptr && basis_slice != nullptr);
+  if (!n_cols) return ZKFHE_OK;
+  if (!comm->has_aux()) return zkfhe_msm_batch_sharded(ctx, comm, basis_slice, scalars_dev, col_stride, n_cols, out_dev);   // complete on the context's stream
+  if (!comm->aux) {
+    ZK_HIP(ctx, hipStreamCreateWithFlags(&comm->aux, hipStreamNonBlocking));
+    ZK_HIP(ctx, hipEventCreateWithFlags(&comm->ev_msm, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) ZK_HIP(ctx, hipEventCreateWithFlags(&comm->ev_done[b], hipEventDisableTiming | hipEventBlockingSync));
+  }
+  const int b = comm->next;
+  comm->next ^= 1;
+  const size_t need = (size_t)(comm->world + 1) * n_cols * sizeof(G1Affine) + 64;
+  if (comm->buf_sz[b] < need) {
+    ZK_HIP(ctx, hipStreamSynchronize(comm->aux));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (comm->buf[b]) ZK_HIP(ctx, hipFree(comm->buf[b]));
+    comm->buf[b] = nullptr, comm->buf_sz[b] = 0;
+    ZK_HIP(ctx, hipMalloc(&comm->buf[b], need + need / 4));
+    comm->buf_sz[b] = need + need / 4;
+    comm->pending[b] = false;
+  }
+  // this buffer carried the batch before the previous one: that collective must be over before the partials below overwrite it
+  if (comm->pending[b]) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, comm->ev_done[b], 0));
+  G1Affine *mine = (G1Affine *)((char *)comm->buf[b] + 64), *all = mine + n_cols;
+  int rc = zk_msm_batch_strided(ctx, basis_slice, scalars_dev, col_stride, n_cols, (zkfhe_g1_affine *)mine);
+  if (rc) return rc;
+  ZK_HIP(ctx, hipEventRecord(comm->ev_msm, ctx->stream));
+  ZK_HIP(ctx, hipStreamWaitEvent(comm->aux, comm->ev_msm, 0));
+  rc = gather_on(ctx, comm, mine, all, n_cols * sizeof(G1Affine), comm->aux);
+  if (rc) return rc;
+  k_sum_partials<<<zk_blocks(n_cols, 64), 64, 0, comm->aux>>>(all, (unsigned)comm->world, n_cols, (G1Affine *)out_dev);
+  ZK_LAUNCH_CHECK(ctx);
+  ZK_HIP(ctx, hipEventRecord(comm->ev_done[b], comm->aux));
+  comm->pending[b] = true;
+  comm->last = b;
+  return ZKFHE_OK;
+}
+
+// block_host = 0: the context's stream waits for every collective queued by the _async calls so far; 1: the calling thread does
+// (and with it for everything that was on the context's stream when the last of them was queued)
+int zkfhe_comm_join(zkfhe_ctx *ctx, zkfhe_comm *comm, int block_host) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, comm != nullptr);
+  if (!comm->aux || comm->last < 0) {
+    if (block_host) ZK_HIP(ctx, zk_wait(ctx));
+    return ZKFHE_OK;
+  }
+  if (block_host) ZK_HIP(ctx, hipEventSynchronize(comm->ev_done[comm->last]));
+  else ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, comm->ev_done[comm->last], 0));
+  return ZKFHE_OK;
+}
+
+// records a HIP event behind the collectives queued so far (on the communicator's stream, or on the context's when the
+// communicator has none): what a caller waits on instead of the context's stream to leave later kernels running
+int zkfhe_comm_record_event(zkfhe_ctx *ctx, zkfhe_comm *comm, void *hip_event) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, comm != nullptr && hip_event != nullptr);
+  ZK_HIP(ctx, hipEventRecord((hipEvent_t)hip_event, comm->aux && comm->last >= 0 ? comm->aux : ctx->stream));
+  return ZKFHE_OK;
+}
+
 int zkfhe_msm_batch_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev, size_t col_stride,
                             size_t n_cols, zkfhe_g1_affine *out_dev) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, comm != nullptr && basis_slice != nullptr);
   if (!n_cols) return ZKFHE_OK;
   if (comm->world == 1 && !comm->nccl) return zk_msm_batch_strided(ctx, basis_slice, scalars_dev, col_stride, n_cols, out_dev);
+  if (comm->has_aux()) {   // the asynchronous form, joined: the result is ordered on the context's stream as before
+    int rc_a = zkfhe_msm_batch_sharded_async(ctx, comm, basis_slice, scalars_dev, col_stride, n_cols, out_dev);
+    if (rc_a) return rc_a;
+    return zkfhe_comm_join(ctx, comm, 0);
+  }
   // scratch slot 3: [my partials | everyone's partials]  (slots 0..2 belong to the MSM itself)
   void *p;
   int rc = zk_scratch(ctx, 3, (size_t)(comm->world + 1) * n_cols * sizeof(G1Affine) + 64, &p);

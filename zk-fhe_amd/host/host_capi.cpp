@@ -7,6 +7,7 @@
 
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
+#include "bfv_phase0_fast.hpp"
 #include "srs_secret.hpp"
 #include "transcript.hpp"
 
@@ -62,11 +63,13 @@ int zkfhe_bfv_build_tables(const char *input_json, const zkfhe_bfv_params *param
     auto *res = new zkfhe_bfv_tables();
     res->cfg = config_from_c(config);
     const BfvParams prm = params_from_c(params);
-    const CircuitInput in = CircuitInput::parse_json(input_json);
     const bool kg = keygen_mode != 0;
     Context ctx0(CTX_PHASE0, false, kg), ctx_gate(CTX_GATE1, false, kg), ctx_rlc(CTX_RLC1, true, kg);
     std::vector<Cell> make_public;
-    BfvState st = bfv_phase0(ctx0, in, prm, make_public);
+    // prover-mode tables take the prover's phase 0 (machine words where the input allows, ZKFHE_PHASE0=generic forces the
+    // restatement): tests/test_host_witness.py compares the two table for table
+    BfvState st;
+    if (kg || !bfv_phase0_fast(ctx0, input_json, strlen(input_json), prm, make_public, st)) st = bfv_phase0(ctx0, CircuitInput::parse_json(input_json), prm, make_public);
     U256 g;
     memcpy(g.l, gamma, 32);
     bfv_phase1(st, prm, ctx_gate, ctx_rlc, g);

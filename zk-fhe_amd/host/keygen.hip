@@ -3,13 +3,19 @@
 #include "prover_internal.hpp"
 
 std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) {
+  const U256 *host = mul_u64_raw(a, b);
+  std::vector<BigInt> out(2 * a.size() - 1);
+  for (size_t i = 0; i < out.size(); ++i) out[i] = fe::to_bigint(host[i]);
+  return out;
+}
+
+const U256 *GpuPolyMul::mul_u64_raw(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) {
   const size_t n = a.size();
   if (ws->polyio.bytes < 2 * n * 8 + 2 * n * 32) throw std::runtime_error("polynomial too long for the prover workspace");
   uint64_t *da = (uint64_t *)ws->polyio.p, *db = da + n;
   Fr *dout = (Fr *)(db + n);
   // operands through the pinned ring, the product back into pinned memory: pageable copies take a process-wide staging
   // path in the runtime, and twenty proofs starting together queued on it (5 ms per product instead of 0.25)
-  std::vector<U256> pageable;
   const U256 *host = ws->host_poly;
   int rc = up(ctx, ws, da, a.data(), n * 8);
   if (!rc) rc = up(ctx, ws, db, b.data(), n * 8);
@@ -24,9 +30,7 @@ std::vector<BigInt> GpuPolyMul::mul_u64(const std::vector<uint64_t> &a, const st
     rc = zkfhe_download(ctx, pageable.data(), dout, (2 * n - 1) * 32);
   }
   if (rc) throw std::runtime_error(std::string("GPU poly mul failed: ") + zkfhe_last_error(ctx));
-  std::vector<BigInt> out(2 * n - 1);
-  for (size_t i = 0; i < out.size(); ++i) out[i] = fe::to_bigint(host[i]);
-  return out;
+  return host;
 }
 
 int up(zkfhe_ctx *ctx, Workspace *ws, void *dst, const void *src, size_t bytes) {

@@ -30,6 +30,8 @@ inline uint64_t bits_u64(uint64_t v) { return v ? 64 - __builtin_clzll(v) : 0; }
 struct PolyMulBackend {
   virtual ~PolyMulBackend() {}
   virtual std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) = 0;
+  // the same product as 2n - 1 canonical 256-bit words owned by the backend (valid until its next call); nullptr = not offered
+  virtual const U256 *mul_u64_raw(const std::vector<uint64_t> &, const std::vector<uint64_t> &) { return nullptr; }
 };
 inline PolyMulBackend *&poly_mul_backend() {
   static thread_local PolyMulBackend *p = nullptr;

@@ -574,18 +574,25 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       return zk_fail_msg(ctx, rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(aux));
     ZK_HIP(ctx, hipEventRecord(ws->ev_rand, aux->stream));
   }
-  const CircuitInput in = CircuitInput::parse_json(input_json);
-  trace.mark("parse_json");
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
   std::vector<Cell> make_public;
   instances.clear();
   tr.common_scalar(pk->vk_digest);
   // the 5121 public inputs are hashed on a helper thread, started as soon as they are known: it runs beside the phase-0
   // precomputation, upload and commitment (a Poseidon sponge is one sequential chain of 2561 permutations here)
-  BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public, [&](const std::vector<Cell> &pub) {
+  const auto on_public = [&](const std::vector<Cell> &pub) {
+    instances.reserve(pub.size());
     for (const Cell &c : pub) instances.push_back(c.value);
     tr.common_scalars_async(instances);
-  });
+  };
+  // machine-word phase 0 (bfv_phase0_fast.hpp) for every input in its domain; anything else goes through the line-by-line
+  // restatement of the reference, which also words the errors
+  BfvState st;
+  if (!bfv_phase0_fast(ctx0, input_json, strlen(input_json), pk->prm, make_public, st, on_public)) {
+    const CircuitInput in = CircuitInput::parse_json(input_json);
+    trace.mark("parse_json");
+    st = bfv_phase0(ctx0, in, pk->prm, make_public, on_public);
+  }
   trace.mark("bfv_phase0");
   Assigner as(cfg, false, ws->host_adv);
   as.place(ctx0, true);
@@ -625,7 +632,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
     CK(alloc_witness_buffers(ctx, pk, ws));
     CK(srs_msm(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, ws->host_pts));   // stored into pinned memory by the MSM itself
-    ZK_HIP(ctx, hipEventRecord(ws->ev_pts, ctx->stream));
+    CK(srs_record(ctx, srs, ws->ev_pts));   // sharded: behind the all-gather on the communicator's stream, which the gadget launches below overlap
     CK(g1.launch(st));
     if (early_p1) {
       // Early phase-1 commitment.  Of the phase-1 columns only the RLC columns and the 16 constrain_mul gate cells depend on
@@ -644,7 +651,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl0, ws->la_l.fr() + u, nbl0, n, cfg.n_lookup));
       CK(rng_fill(ctx->stream, ctr_lk + nbl0, 2 * nbl0, ws->ls_l.fr() + u, nbl0, n, cfg.n_lookup));
       CK(srs_msm(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, ws->host_early));
-      ZK_HIP(ctx, hipEventRecord(ws->ev_early, ctx->stream));
+      CK(srs_record(ctx, srs, ws->ev_early));
     }
     ZK_HIP(ctx, hipEventSynchronize(ws->ev_pts));
     pts.resize(cfg.n_gate0);
@@ -695,6 +702,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         CK(srs_msm(ctx, srs, srs->g_lagrange, patch_cols, np, fix_dev));
       }
       if (cfg.n_rlc) CK(srs_msm(ctx, srs, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, cfg.n_rlc, fix_dev + np));
+      CK(srs_join(ctx, srs, false));
       ZK_HIP(ctx, zk_wait(ctx));   // everything queued so far, the early commitment (ev_early) included
       const G1Affine *fix = fix_dev;
       if (*ws->host_early_err) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
@@ -1377,10 +1385,10 @@ int zkfhe_bfv_witness_stream(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk_c, const cha
       explicit BackendGuard(PolyMulBackend *b) { poly_mul_backend() = b; }
       ~BackendGuard() { poly_mul_backend() = nullptr; }
     } guard(&gpu_mul);
-    const CircuitInput in = CircuitInput::parse_json(input_json);
     Context ctx0(CTX_PHASE0, false, false), ctx_rlc(CTX_RLC1, true, false);
     std::vector<Cell> make_public;
-    BfvState st = bfv_phase0(ctx0, in, pk->prm, make_public);
+    BfvState st;
+    if (!bfv_phase0_fast(ctx0, input_json, strlen(input_json), pk->prm, make_public, st)) st = bfv_phase0(ctx0, CircuitInput::parse_json(input_json), pk->prm, make_public);
     U256 gamma, evals[12];
     memcpy(gamma.l, gamma_le, 32);
     if (!(gamma < fe::MOD)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "gamma is not a canonical Fr value");

@@ -12,6 +12,7 @@
 
 #include "../../include/zkfhe.h"
 #include "bfv_circuit.hpp"
+#include "bfv_phase0_fast.hpp"
 #include "gpu_witness.hip.hpp"
 #include "prover_kernels.hip.hpp"
 #include "shplonk.hpp"
@@ -51,13 +52,15 @@ struct zkfhe_srs {
   std::vector<G1Affine> g_host, gl_host;
   uint8_t g2_raw[128], sg2_raw[128];
   bool have_g2 = false;
-  bool sharded() const { return comm != nullptr && zkfhe_comm_world(comm) > 1; }
+  // more than one rank, or a one-rank communicator with a real transport (the single-GPU test of the whole collective path)
+  bool sharded() const { return comm != nullptr && zkfhe_comm_active(comm) != 0; }
 };
 
 // commitment MSM of `n_cols` full columns (stride n): the whole basis, or this rank's rows + all-gather + sum
 static inline int srs_msm(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out) {
   if (!srs->sharded()) return zkfhe_msm_batch(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_affine *)dev_out);
-  return zkfhe_msm_batch_sharded(ctx, srs->comm, basis, (const zkfhe_fr *)(cols + srs->lo), (size_t)1 << srs->k, n_cols, (zkfhe_g1_affine *)dev_out);
+  // the collective runs on the communicator's stream: srs_join / srs_record before anything reads dev_out
+  return zkfhe_msm_batch_sharded_async(ctx, srs->comm, basis, (const zkfhe_fr *)(cols + srs->lo), (size_t)1 << srs->k, n_cols, (zkfhe_g1_affine *)dev_out);
 }
 
 struct DevBuf {
@@ -219,9 +222,24 @@ static inline int flush_staged(zkfhe_ctx *ctx, Workspace *ws) {
 // commit `n_cols` columns straight into the pinned result block (the last MSM kernel stores its affine points there) and wait
 static inline int commit_cols_out(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, Workspace *ws, std::vector<AffinePoint> &out);
 
+// after srs_msm: host = false -> the context's stream waits for the commitments queued so far (a device-side reader follows);
+// host = true -> the calling thread waits (for them and for everything queued on the context's stream before them)
+static inline int srs_join(zkfhe_ctx *ctx, const zkfhe_srs *srs, bool host) {
+  if (srs->sharded()) return zkfhe_comm_join(ctx, srs->comm, host ? 1 : 0);
+  if (host) ZK_HIP(ctx, zk_wait(ctx));
+  return ZKFHE_OK;
+}
+// an event behind the commitments queued so far (not behind the kernels the caller queues next)
+static inline int srs_record(zkfhe_ctx *ctx, const zkfhe_srs *srs, hipEvent_t ev) {
+  if (srs->sharded()) return zkfhe_comm_record_event(ctx, srs->comm, (void *)ev);
+  ZK_HIP(ctx, hipEventRecord(ev, ctx->stream));
+  return ZKFHE_OK;
+}
+
 // commit `n_cols` columns (device, Montgomery) and return canonical affine points
 static inline int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, G1Affine *dev_out, std::vector<AffinePoint> &out) {
   CK(srs_msm(ctx, srs, basis, cols, n_cols, dev_out));
+  CK(srs_join(ctx, srs, false));
   std::vector<G1Affine> h(n_cols);
   CK(zkfhe_download(ctx, h.data(), dev_out, n_cols * sizeof(G1Affine)));
   out.resize(n_cols);
@@ -232,7 +250,7 @@ static inline int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_
 static inline int commit_cols_out(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, Workspace *ws, std::vector<AffinePoint> &out) {
   if (!ws->host_out || n_cols > ws->out_pts_cap) return commit_cols(ctx, srs, basis, cols, n_cols, (G1Affine *)ws->points.p, out);
   CK(srs_msm(ctx, srs, basis, cols, n_cols, ws->out_pts()));
-  ZK_HIP(ctx, zk_wait(ctx));
+  CK(srs_join(ctx, srs, true));
   out.resize(n_cols);
   for (size_t i = 0; i < n_cols; ++i) out[i] = point_canon(ws->out_pts()[i]);
   return ZKFHE_OK;
@@ -243,6 +261,10 @@ struct GpuPolyMul : PolyMulBackend {
   Workspace *ws;
   GpuPolyMul(zkfhe_ctx *c, Workspace *w) : ctx(c), ws(w) {}
   std::vector<BigInt> mul_u64(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) override;
+  const U256 *mul_u64_raw(const std::vector<uint64_t> &a, const std::vector<uint64_t> &b) override;
+
+ private:
+  std::vector<U256> pageable;   // the product when it does not fit the pinned block
 };
 
 
