@@ -7,8 +7,7 @@
 // everything except the S-box x_t = (s0_t + pc0_t)^5 and the product row0_t x_t depends on x_{t-1} only: five products by
 // constants (plus two by one, which keep W bounded) that have a whole round of slack.  They run as ONE eight-lane
 // Montgomery product in radix 2^52 (vpmadd52luq / vpmadd52huq, 115 of them) beside the scalar chain -- the integer multiplier
-// and the vector unit work in parallel.  The chain itself is three products a round: row0_t x_t is formed as u^4 (row0_t u), with
-// row0_t u computed beside the squarings (x_t = u^4 u, which only the next round's job needs, likewise off the chain).  Data lanes hold the same x * 2^256 representatives as the scalar code, re-limbed;
+// and the vector unit work in parallel.  Data lanes hold the same x * 2^256 representatives as the scalar code, re-limbed;
 // the constants are held as c * 2^260, so a lane product (x 2^256)(c 2^260) / 2^260 is again a data value.
 // Checked against the scalar rounds on every permutation of tests/test_poseidon.py (ZKFHE_POSEIDON_SCALAR=1 runs without).
 #include <immintrin.h>
@@ -234,7 +233,6 @@ ZK_IFMA void rounds(F s[T]) {
     ZK_MUL8_ITER(0);
     ZK_MUL8_ITER(1);
     const F u2 = sqrw(u);
-    const F ru = mulw(c.s_row[t][0], u);   // row0 u, beside the squarings: the chain below is u^2, u^4, u^4 (row0 u) -- three products, not four
     ZK_MUL8_ITER(2);
     ZK_MUL8_ITER(3);
     const F u4 = sqrw(u2);
@@ -242,8 +240,7 @@ ZK_IFMA void rounds(F s[T]) {
     R5 o;
     o.l[0] = t0, o.l[1] = t1, o.l[2] = t2, o.l[3] = t3, o.l[4] = t4;
     normalise(o);
-    const F m = mulw(u4, ru);   // row0 x_t, on the chain
-    x = mulw(u4, u);            // x_t itself feeds the NEXT round's vector job and the last round's s1, s2: off the chain
+    x = mulw(u4, u);
     // Y_t = col0 x + W (lanes 0 + 5 -> lanes 3 and 5), Z likewise, plus the next round's constants: W_{t+1}; A_t = lanes 2 + 3 + 4
     R5 sum;
     for (int j = 0; j < 5; ++j) {
@@ -258,6 +255,7 @@ ZK_IFMA void rounds(F s[T]) {
     const uint64_t al[5] = {buf[0][2], buf[1][2], buf[2][2], buf[3][2], buf[4][2]};
     const F A = from_l5(al);   // below 3.2 r
     // s0_{t+1} = row0_t x_t + A_t: below 1.4 r + 3.2 r, folded below 2.6 r; the next S-box's addw folds again
+    const F m = mulw(c.s_row[t][0], x);
     unsigned long long cy;
     const uint64_t w0 = __builtin_addcll(m.l[0], A.l[0], 0, &cy);
     const uint64_t w1 = __builtin_addcll(m.l[1], A.l[1], cy, &cy);
