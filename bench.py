@@ -214,16 +214,15 @@ def main():
     direct = ctx.prof_read(2)
     ctx.prof_enable(False)
 
-    traffic = None
-    try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, rocprofv3 --pmc)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))["bytes_per_launch"] if (not big and table_wide) else None
-    except Exception:  # noqa: BLE001
-        pass
-    ntt_traffic = None
-    try:  # the same for the 2^13 NTT tile (second kernel of every configuration)
-        ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))["ntt13"] if not big else None
-    except Exception:  # noqa: BLE001
-        pass
+    traffic = ntt_traffic = None
+    for fn in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes (profiles/, rocprofv3 --pmc)
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            traffic = pt["bytes_per_launch"] if (not big and table_wide) else None
+            ntt_traffic = pt["ntt13"] if not big else None   # the same for the 2^13 NTT tile (second kernel of every configuration)
+            break
+        except Exception:  # noqa: BLE001
+            continue
     if rank == 0:
         ach = msm["algorithmic_bytes"] / (msm["total_ms"] * 1e-3) / 1e9
         ntt_ach = ntt["algorithmic_bytes"] / (ntt["total_ms"] * 1e-3) / 1e9 if ntt["launches"] else None
@@ -278,6 +277,7 @@ def main():
                                     "inputs: the reference's data/bfv/bfv.in + 3 seeded synthetic encryptions") if not big else
                                    "one proof per step, k=%d, N=%d, Q=2^60-93 (BASELINE configs[%d]); columns by halo2-base auto-configuration"
                                    % (conf["k"], conf["N"], 3 if args.config == "k16" else 4),
+                       "columns": {"gate0": zcfg.n_gate0, "gate1": zcfg.n_gate1, "lookup": zcfg.n_lookup, "rlc": zcfg.n_rlc},
                        "mode": args.mode if world > 1 else "batch", "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
                        "host_cpu_ms_per_proof_by_rank": host_cpu_by_rank, "host": host, "verified": bool(verified),
                        "steady_state_proofs_per_s": steady,
