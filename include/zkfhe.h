@@ -271,6 +271,12 @@ int zkfhe_bfv_tables_copy_instance(const zkfhe_bfv_tables *t, uint64_t *out);   
 int zkfhe_bfv_tables_copy_copies(const zkfhe_bfv_tables *t, uint64_t *out);     /* n_copies * 2 (cell = perm_col * n + row) */
 int zkfhe_bfv_tables_copy_break_points(const zkfhe_bfv_tables *t, int which, uint32_t *out);
 
+/* Process-wide admission gate of the proofs in flight: at most n of them inside the GPU-heavy middle of a proof (grand products,
+ * their commitment, coset extension, quotient) at a time, first come first served; 0 = no gate (default, or ZKFHE_GATE), n < 0 =
+ * query.  Returns the previous setting.  Spreads proofs that would otherwise move through the Fiat-Shamir rounds in lockstep; pays
+ * when the streams are kept full, not for a batch that starts and ends together.  Ignored by sharded proofs. */
+int zkfhe_prover_gate(int n);
+
 /* `mock` (README.md:18-22, halo2 MockProver::run(..).assert_satisfied()): evaluates every constraint on every row of
  * tables built with keygen_mode != 0 and the same gamma -- gate and RLC-gate identities under their selectors, lookup
  * membership, and both cells of every copy constraint.  *n_failures = number of violated rows / constraints, err = the

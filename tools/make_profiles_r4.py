@@ -167,7 +167,7 @@ for fn, cmd in (('bench_driver', "`python bench.py --steps 20 --warmup 5` (the d
                 ('bench_k19_poseidon', '`--config k19 --steps 4 --streams 1`'),
                 ('bench_driver_shared', "`ZKFHE_HASH_MODE=shared` + the driver's command (eight-lane Poseidon service)"),
                 ('bench_default_shared', '`ZKFHE_HASH_MODE=shared python bench.py --no-cpu-baseline`'),
-                ('bench_default_gate4', '`ZKFHE_GATE=4 python bench.py --no-cpu-baseline` (admission gate of the heavy middle)'),
+                ('bench_default_gate0', '`ZKFHE_GATE=0 python bench.py --no-cpu-baseline` (without the admission gate bench.py sets for runs with more steps than streams)'),
                 ('bench_single_blake2b_generic_phase0', '`ZKFHE_PHASE0=generic` + `--steps 8 --streams 1 --transcript blake2b` (BigInt phase 0)')):
     d = jl(fn + '.json')
     if not d:
@@ -191,7 +191,7 @@ open(P + 'r4_microbench.md', 'w').write("# r4 -- micro-benchmarks (`python tools
 # ---- wave occupancy --------------------------------------------------------------------------------------------------------
 open(P + 'r4_wave_occupancy.md', 'w').write("""# r4 -- GPU occupancy over the driver's wave of 20 concurrent proofs (2 ms bins)
 
-`rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline` (the run of `r4_a_driver_kernel_stats.md`), `tools/busy_bins.py <db> 400 2`:
+`rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-seconds 0` (`tools/profile_r4b.sh`), `tools/busy_bins.py <db> 260 2`:
 per bin the fraction of time with at least one kernel running, the average number of kernels in flight and the kernel with the largest
 share.  The last ~60 ms of the trace are the two profiled proofs that follow the timed region (one in flight); the wave is the ~100 ms
 block before them: a head of ~14 ms in which the proofs' early work (phase-0 commitment, gadgets, early phase-1 commitment) shares the

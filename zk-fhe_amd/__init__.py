@@ -36,7 +36,7 @@ EXPORTS = [
     "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
     "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
-    "zkfhe_poseidon_permute", "zkfhe_poseidon_constants", "zkfhe_poseidon_hash_many", "zkfhe_host_hash_mode",
+    "zkfhe_poseidon_permute", "zkfhe_poseidon_constants", "zkfhe_poseidon_hash_many", "zkfhe_host_hash_mode", "zkfhe_prover_gate",
     "zkfhe_version",
 ]
 
@@ -447,6 +447,13 @@ def host_hash_mode(mode=None):
     if rc < 0:
         raise ZkfheError("zkfhe_host_hash_mode(%r) failed" % (mode,))
     return ["latency", "shared"][rc]
+
+
+def prover_gate(n=-1):
+    """zkfhe_prover_gate: proofs admitted at once to the GPU-heavy middle of a proof (0 = no gate, negative = query); returns the previous setting"""
+    lib = load_library()
+    lib.zkfhe_prover_gate.argtypes = [ctypes.c_int]
+    return int(lib.zkfhe_prover_gate(int(n)))
 
 
 def poseidon_hash_many(sequences, mode=1):

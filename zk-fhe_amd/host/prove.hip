@@ -468,21 +468,31 @@ class HeavyGate {
     static HeavyGate g;
     return g;
   }
-  void enter() {
-    if (!slots) return;
+  // returns whether a slot was taken (the gate may be switched while proofs are in flight: leave() only gives back what enter() took)
+  bool enter() {
     std::unique_lock<std::mutex> l(mu);
+    if (slots <= 0) return false;
     const uint64_t my = next_ticket++;
-    cv.wait(l, [&] { return my < serving + (uint64_t)slots; });
+    cv.wait(l, [&] { return slots <= 0 || my < serving + (uint64_t)slots; });
+    return true;
   }
   void leave() {
-    if (!slots) return;
     {
       std::lock_guard<std::mutex> l(mu);
       ++serving;
     }
     cv.notify_all();
   }
-  int slots = 0;
+  int set(int n) {
+    int old;
+    {
+      std::lock_guard<std::mutex> l(mu);
+      old = slots;
+      if (n >= 0) slots = n;
+    }
+    cv.notify_all();
+    return old;
+  }
 
  private:
   HeavyGate() {
@@ -490,14 +500,12 @@ class HeavyGate {
   }
   std::mutex mu;
   std::condition_variable cv;
+  int slots = 0;
   uint64_t next_ticket = 0, serving = 0;   // tickets below `serving` have left; FIFO admission of serving .. serving + slots - 1
 };
 struct GateHold {
   bool held = false;
-  void enter() {
-    HeavyGate::get().enter();
-    held = true;
-  }
+  void enter() { held = HeavyGate::get().enter(); }
   void leave() {
     if (held) HeavyGate::get().leave();
     held = false;
@@ -831,8 +839,25 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)ws->den.p, nch * n));
   CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)ws->num.p, (const zkfhe_fr *)ws->den.p, (zkfhe_fr *)ws->num.p, nch * n));
   Fr *totals_dev = (Fr *)ws->small.p + 4096;
-  zkp::k_prefix_product<<<(unsigned)nch, 1024, 0, ctx->stream>>>(ws->num.fr(), ws->pz_l.fr(), totals_dev, n, (unsigned)u);
-  ZK_LAUNCH_CHECK(ctx);
+  // running products per column; long columns in segments (prover_kernels.hip.hpp), the segment products in the dead `den` buffer
+  auto prefix_products = [&](const Fr *ratio, Fr *z, size_t n_cols) -> int {
+    if (n <= 32768) {
+      zkp::k_prefix_product<<<(unsigned)n_cols, 1024, 0, ctx->stream>>>(ratio, z, totals_dev, n, (unsigned)u);
+      ZK_LAUNCH_CHECK(ctx);
+      return ZKFHE_OK;
+    }
+    const unsigned seg_len = 32768, segs = (unsigned)(n / seg_len);   // u < n: the output row z[u] lies inside the last segment
+    Fr *seg = ws->den.fr();
+    if ((size_t)n_cols * segs * 32 > ws->den.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "prefix products: segment buffer too small");
+    zkp::k_prefix_seg_totals<<<dim3(segs, (unsigned)n_cols), 1024, 0, ctx->stream>>>(ratio, seg, n, (unsigned)u, seg_len);
+    ZK_LAUNCH_CHECK(ctx);
+    zkp::k_prefix_seg_scan<<<(unsigned)((n_cols + 63) / 64), 64, 0, ctx->stream>>>(seg, segs, (unsigned)n_cols, totals_dev);
+    ZK_LAUNCH_CHECK(ctx);
+    zkp::k_prefix_seg_apply<<<dim3(segs, (unsigned)n_cols), 1024, 0, ctx->stream>>>(ratio, seg, z, n, (unsigned)u, seg_len);
+    ZK_LAUNCH_CHECK(ctx);
+    return ZKFHE_OK;
+  };
+  CK(prefix_products(ws->num.fr(), ws->pz_l.fr(), nch));
   int *const closes = ws->out_flags();   // pinned: [0] permutation, [1] lookups -- read after the commitment of the products below
   closes[0] = closes[1] = 1;
   {
@@ -854,8 +879,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)ws->den.p, nl * n));
     CK(zkfhe_fr_mul(ctx, (const zkfhe_fr *)ws->num.p, (const zkfhe_fr *)ws->den.p, (zkfhe_fr *)ws->num.p, nl * n));
-    zkp::k_prefix_product<<<(unsigned)nl, 1024, 0, ctx->stream>>>(ws->num.fr(), ws->lz_l.fr(), totals_dev, n, (unsigned)u);
-    ZK_LAUNCH_CHECK(ctx);
+    CK(prefix_products(ws->num.fr(), ws->lz_l.fr(), nl));
     zkp::k_chunk_carry<<<1, 1024, 0, ctx->stream>>>(totals_dev, (unsigned)nl, 1, closes + 1);
     ZK_LAUNCH_CHECK(ctx);
     const size_t nb = n - u - 1;
@@ -1351,6 +1375,11 @@ int zkfhe_bfv_prove(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_bfv_pk *pk
     return zk_fail_msg(ctx, ZKFHE_EINVAL, e.what());
   }
 }
+
+// Admission gate of the GPU-heavy middle of the proofs of this process (HeavyGate above): n > 0 = that many proofs inside at once,
+// 0 = no gate, negative = query.  Returns the previous setting.  For a service that keeps its streams full (measured: 16 streams,
+// 4 slots: 224 proofs/s against 209); a batch that starts and ends together gains nothing from it.
+int zkfhe_prover_gate(int n) { return HeavyGate::get().set(n); }
 
 // halo2's permute_expression_pair for the 8-bit range table, as the prover runs it (gpu_witness.hip.hpp k_lookup_permute): the
 // parity hook of SURVEY.md section 8a row P4.

@@ -210,6 +210,72 @@ static __global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__rest
   }
   if (threadIdx.x == 1023) total[col] = sh[1023];
 }
+// Long columns (k >= 16): the column is cut into `segs` segments of `seg_len` rows, one workgroup each, so that a call fills the chip
+// (at k = 19 one workgroup per column meant 100 workgroups walking 512 rows per thread twice: 3.2 ms per call).  Three launches:
+// k_prefix_seg_totals (product of every segment), k_prefix_seg_scan (per column: exclusive scan of the segment products, `total[col]`),
+// k_prefix_seg_apply (the running product inside a segment, started from its carry).  Same values as k_prefix_product: field
+// multiplication is associative and the results are canonical.
+static __global__ void __launch_bounds__(1024) k_prefix_seg_totals(const Fr *__restrict__ ratio, Fr *__restrict__ seg_total, size_t n, unsigned u, unsigned seg_len) {
+  __shared__ Fr sh[1024];
+  const size_t col = blockIdx.y;
+  const unsigned seg = blockIdx.x, base = seg * seg_len;
+  const Fr *r = ratio + col * n;
+  const unsigned per = (seg_len + 1023) / 1024, lo = base + threadIdx.x * per;
+  Fr local = Fr::one();
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned i = lo + k;
+    if (i < u && i < base + seg_len) local = local * r[i];
+  }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (unsigned d = 512; d > 0; d >>= 1) {   // product reduction (order is irrelevant: commutative)
+    if (threadIdx.x < d) sh[threadIdx.x] = sh[threadIdx.x] * sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) seg_total[col * gridDim.x + seg] = sh[0];
+}
+static __global__ void __launch_bounds__(64) k_prefix_seg_scan(Fr *__restrict__ seg_total, unsigned segs, unsigned n_cols, Fr *__restrict__ total) {
+  const unsigned col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= n_cols) return;
+  Fr acc = Fr::one();
+  for (unsigned s = 0; s < segs; ++s) {
+    const Fr t = seg_total[(size_t)col * segs + s];
+    seg_total[(size_t)col * segs + s] = acc;   // carry into segment s
+    acc = acc * t;
+  }
+  total[col] = acc;
+}
+static __global__ void __launch_bounds__(1024) k_prefix_seg_apply(const Fr *__restrict__ ratio, const Fr *__restrict__ seg_carry, Fr *__restrict__ z, size_t n, unsigned u,
+                                                            unsigned seg_len) {
+  __shared__ Fr sh[1024];
+  const size_t col = blockIdx.y;
+  const unsigned seg = blockIdx.x, base = seg * seg_len, end = base + seg_len;
+  const Fr *r = ratio + col * n;
+  Fr *o = z + col * n;
+  const unsigned per = (seg_len + 1023) / 1024, lo = base + threadIdx.x * per;
+  Fr local = Fr::one();
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned i = lo + k;
+    if (i < u && i < end) local = local * r[i];
+  }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (unsigned d = 1; d < 1024; d <<= 1) {
+    Fr v = sh[threadIdx.x];
+    Fr other = threadIdx.x >= d ? sh[threadIdx.x - d] : Fr::one();
+    __syncthreads();
+    if (threadIdx.x >= d) sh[threadIdx.x] = other * v;
+    __syncthreads();
+  }
+  Fr acc = seg_carry[col * gridDim.x + seg];
+  if (threadIdx.x) acc = acc * sh[threadIdx.x - 1];
+  for (unsigned k = 0; k < per; ++k) {
+    const unsigned i = lo + k;
+    if (i >= end) break;
+    if (i <= u) o[i] = acc;
+    if (i < u) acc = acc * r[i];
+  }
+}
 // Chunk carries of the permutation argument on the device (was: download the totals, multiply on the host, upload):
 // carry[j] = prod_{i < j} total[i] in place, *closes = (the product of all of them == 1).  With check_ones every total itself
 // has to be one (the lookup products) and the array is left alone.  One workgroup of 1024 threads; count <= 4096.
