@@ -841,7 +841,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Fr *totals_dev = (Fr *)ws->small.p + 4096;
   // running products per column; long columns in segments (prover_kernels.hip.hpp), the segment products in the dead `den` buffer
   auto prefix_products = [&](const Fr *ratio, Fr *z, size_t n_cols) -> int {
-    if (n <= 32768) {
+    if (n <= 65536) {   // measured at k = 16 (two segments): no gain over one workgroup per column; k = 19: 6.5 -> 1 ms per proof
       zkp::k_prefix_product<<<(unsigned)n_cols, 1024, 0, ctx->stream>>>(ratio, z, totals_dev, n, (unsigned)u);
       ZK_LAUNCH_CHECK(ctx);
       return ZKFHE_OK;

@@ -210,7 +210,7 @@ static __global__ void __launch_bounds__(1024) k_prefix_product(const Fr *__rest
   }
   if (threadIdx.x == 1023) total[col] = sh[1023];
 }
-// Long columns (k >= 16): the column is cut into `segs` segments of `seg_len` rows, one workgroup each, so that a call fills the chip
+// Long columns (k >= 17): the column is cut into `segs` segments of `seg_len` rows, one workgroup each, so that a call fills the chip
 // (at k = 19 one workgroup per column meant 100 workgroups walking 512 rows per thread twice: 3.2 ms per call).  Three launches:
 // k_prefix_seg_totals (product of every segment), k_prefix_seg_scan (per column: exclusive scan of the segment products, `total[col]`),
 // k_prefix_seg_apply (the running product inside a segment, started from its carry).  Same values as k_prefix_product: field
