@@ -115,6 +115,8 @@ inline hipError_t zk_wait(zkfhe_ctx *ctx) {
 int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev);
 // returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse
 int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
+// zkfhe_basis_create with a share of the digit-multiple table budget (msm.hip)
+int zk_basis_create_scaled(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t n, int window_bits, double table_budget_scale, zkfhe_basis **out);
 // stream-ordered device-to-device copy (own kernel for large blocks)
 int zk_copy_d2d(zkfhe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out);

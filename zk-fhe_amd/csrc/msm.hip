@@ -929,14 +929,16 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
   if (lane == 0) out[slot] = g1x_to_affine(g1x29_to_std(acc));
 }
 
-// Window width of the digit-multiple table: the widest whose table fits the per-basis budget (ZKFHE_TABLE_GB, default 48;
+// Window width of the digit-multiple table: the widest whose table fits the per-basis budget (ZKFHE_TABLE_GB, default 96 -- 14-bit
+// digits at n = 2^13: 86 GB for the Lagrange half of an SRS, whose wide commitment calls then need 6 % fewer additions than with 13
+// bits; the monomial half, which only serves calls of 1-3 columns, is created with half the budget: 13 bits, 43 GB;
 // ZKFHE_TABLE_BITS forces a width, 0 = no table: every call takes the bucket pipeline).
-int table_bits(size_t n) {
+int table_bits(size_t n, double budget_scale) {
   // read per basis (creation is rare): tests switch widths inside one process
   const char *e = getenv("ZKFHE_TABLE_BITS");
   const int forced = e ? atoi(e) : -1;
   const char *g = getenv("ZKFHE_TABLE_GB");
-  const double budget = (g ? atof(g) : 48.0) * 1073741824.0;
+  const double budget = (g ? atof(g) : 96.0) * 1073741824.0 * budget_scale;
   auto fits = [&](int c) {
     const double entries = (double)n * (double)((255 + c - 1) / c) * (double)(1u << (c - 1));
     return c >= 8 && c <= 14 && entries < 2147483648.0 && entries * sizeof(G1Affine) <= budget;
@@ -1033,6 +1035,13 @@ int default_window_bits(size_t n) {
 extern "C" {
 
 int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t n, int window_bits, zkfhe_basis **out) {
+  return zk_basis_create_scaled(ctx, bases_host, n, window_bits, 1.0, out);
+}
+
+}  // extern "C"
+
+// table_budget_scale: share of the per-basis table budget this basis may use (srs.hip: the monomial half of an SRS gets half)
+int zk_basis_create_scaled(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t n, int window_bits, double table_budget_scale, zkfhe_basis **out) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, out != nullptr && bases_host != nullptr && n > 0);
   ZK_ARG(ctx, window_bits == 0 || (window_bits >= 2 && window_bits <= 16));
@@ -1054,7 +1063,7 @@ int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t
   ZK_HIP(ctx, hipMemcpyAsync(tmp, bases_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
   k_basis_table<<<zk_blocks(n, 256), 256, 0, ctx->stream>>>((const G1Affine *)tmp, n, c, windows, b->table);
   ZK_LAUNCH_CHECK(ctx);
-  int mc = window_bits == 0 && n >= 256 ? table_bits(n) : 0;
+  int mc = window_bits == 0 && n >= 256 ? table_bits(n, table_budget_scale) : 0;
   // a digit-multiple table (k_msm_table): every call against this basis becomes a plain sum of table points.  It is an
   // accelerator, not a requirement: on a device that does not have the room (other tenants, many SRS alive) the width drops
   // until it fits, and without any table the calls take the bucket pipeline
@@ -1079,6 +1088,8 @@ int zkfhe_basis_create(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, size_t
   *out = b;
   return ZKFHE_OK;
 }
+
+extern "C" {
 
 int zkfhe_basis_destroy(zkfhe_ctx *ctx, zkfhe_basis *basis) {
   ZK_ENTER(ctx);

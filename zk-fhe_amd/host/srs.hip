@@ -57,7 +57,8 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, nl));
     CK(zkfhe_download(ctx, host.data(), pts.p, nl * 64));
-    CK(zkfhe_basis_create(ctx, (const zkfhe_g1_affine *)host.data(), nl, 0, which == 0 ? &srs->g : &srs->g_lagrange));
+    // the monomial half serves the calls of 1-3 columns only (random polynomial, quotient pieces): half the table budget
+    CK(zk_basis_create_scaled(ctx, (const zkfhe_g1_affine *)host.data(), nl, 0, which == 0 ? 0.5 : 1.0, which == 0 ? &srs->g : &srs->g_lagrange));
     if (!comm) (which == 0 ? srs->g_host : srs->gl_host) = host;   // zkfhe_srs_save writes them
     if (which == 1) {
       static int small_c = -1;
@@ -93,8 +94,8 @@ int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_h
   srs->hi = n;
   srs->g_host.assign((const G1Affine *)g_host, (const G1Affine *)g_host + n);
   srs->gl_host.assign((const G1Affine *)g_lagrange_host, (const G1Affine *)g_lagrange_host + n);
-  int rc = zkfhe_basis_create(ctx, g_host, n, 0, &srs->g);
-  if (!rc) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 0, &srs->g_lagrange);
+  int rc = zk_basis_create_scaled(ctx, g_host, n, 0, 0.5, &srs->g);
+  if (!rc) rc = zk_basis_create_scaled(ctx, g_lagrange_host, n, 0, 1.0, &srs->g_lagrange);
   if (!rc && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
   if (rc) {
     zkfhe_srs_destroy(ctx, srs);
