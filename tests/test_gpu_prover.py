@@ -411,12 +411,15 @@ def test_twelve_concurrent_k13_proofs_match_sequential(ctx):
         assert got[j][0] == alone[j], "proof %d differs when proved concurrently" % j
     # the same again with the transcripts' long runs (public inputs, commitments, evaluations) going through the shared eight-lane
     # Poseidon service (host/poseidon_x8.cpp; zkfhe_host_hash_mode): the same bytes
+    # ... and with the admission gate of the heavy middle of a proof closed to three at a time (zkfhe_prover_gate): scheduling only
     if zk.poseidon_hash_many([[1, 2]], mode=1) is not None:
         assert zk.host_hash_mode("shared") == "shared"
+        assert zk.prover_gate(3) == 0 and zk.prover_gate() == 3
         try:
             shared = batch.run_concurrent(jobs[:24], ctxs, lambda c, j: pk.prove(texts[j % 6], b"c%d" % j, ctx=c))
         finally:
             zk.host_hash_mode("latency")
+            assert zk.prover_gate(0) == 3
         for j in jobs[:24]:
             assert shared[j][0] == got[j][0], "proof %d differs with the shared hash service" % j
     # jobs 12.. repeat the inputs with other seeds: different bytes, same instances, all valid

@@ -17,4 +17,4 @@ ZKFHE_GATE=0 python bench.py --no-cpu-baseline > $OUT/bench_default_gate0.json 2
 python bench.py --transcript blake2b --no-cpu-baseline > $OUT/bench_blake2b.json 2>/dev/null
 ZKFHE_HASH_MODE=shared python bench.py --no-cpu-baseline > $OUT/bench_default_shared.json 2>/dev/null
 rm -f $OUT/bench_default_gate4.json
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $OUT/full_gpu_suite.log
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -5 > $OUT/full_gpu_suite.log
