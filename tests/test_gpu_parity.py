@@ -229,10 +229,10 @@ def test_msm_vs_oracle(ctx, n, c):
 
 
 @pytest.mark.parametrize("n,n_cols,bits", [(256, 1, 0), (1000, 3, 8), (1000, 3, 9), (8192, 1, 0), (8192, 3, 10), (8192, 4, 11), (8192, 17, 13),
-                                           (16384, 2, 8), (65536, 1, 8), (2048, 40, 12), (2048, 300, 10)])
+                                           (16384, 2, 8), (65536, 1, 8), (2048, 40, 12), (2048, 300, 10), (2048, 9, 14), (1024, 5, 15)])
 def test_msm_table_path(ctx, monkeypatch, n, n_cols, bits):
     """A default basis (window_bits = 0) gets a digit-multiple table and every call against it is a plain sum of table
-    points (k_msm_table): forced table widths 8 .. 13 and the budget's own choice, a lone column (butterfly per visit) and
+    points (k_msm_table): forced table widths 8 .. 15 and the budget's own choice, a lone column (butterfly per visit) and
     hundreds (256 partials per visit), non-power-of-two n, an identity base, zero / one / r-1 / (r+-1)/2 scalars, short
     and negative-short columns; called twice (the ticket counters must reset themselves) and against the bucket pipeline
     of the same points (explicit window_bits: no table)."""

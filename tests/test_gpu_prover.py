@@ -91,8 +91,9 @@ def oracle_k13():
 @pytest.mark.parametrize("table_gb", ["4", None])
 def test_bfv_in_k13_proof_bytes_match_oracle(ctx, monkeypatch, table_gb):
     """BASELINE config 2: the reference's data/bfv/bfv.in, k = 13, pinned configs/bfv.json layout.  table_gb = None is the
-    library's DEFAULT table budget -- 14-bit digits for the Lagrange half (86 GB), 13-bit for the monomial half (43 GB), every
-    commitment a sum of table points (k_msm_table): the configuration bench.py and the driver's BENCH line measure.  "4" is the budget the rest of the
+    library's DEFAULT table budget -- 15-bit digits for the Lagrange half (146 GB: more than 2^31 table entries), 13-bit for the
+    monomial half (43 GB), every commitment a sum of table points (k_msm_table): the configuration bench.py and the driver's BENCH
+    line measure (14 bits if the device does not have 146 + 36 GB free when the test runs).  "4" is the budget the rest of the
     suite runs on: 9-bit digits, which serve the calls of a few columns only -- the two wide calls take the bucket pipeline
     (k_msm_accumulate ...).  Between them the two cases prove bfv.in through both MSM paths."""
     import zk_fhe_amd as zk
@@ -105,7 +106,7 @@ def test_bfv_in_k13_proof_bytes_match_oracle(ctx, monkeypatch, table_gb):
     cfgj, prm, text_empty, text = o["cfgj"], o["prm"], o["text_empty"], o["text"]
     srs = zk.Srs(ctx, 13)
     bits, wide = srs.table_bits()
-    assert (bits, wide) == ((14, True) if table_gb is None else (9, False)), (bits, wide)
+    assert (bits in (14, 15) and wide) if table_gb is None else (bits, wide) == (9, False), (bits, wide)
     zcfg = zk.BfvConfig.from_pinning(cfgj)
     zcfg_nobp = zk.BfvConfig(zcfg.k, zcfg.n_gate0, zcfg.n_gate1, zcfg.n_lookup, zcfg.n_rlc, zcfg.unusable_rows, zcfg.lookup_bits)
     pk = zk.BfvProvingKey(ctx, srs, text_empty, (1024, prm.Q, prm.T, prm.B), zcfg_nobp)

@@ -771,7 +771,9 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
       __syncthreads();
       unsigned off = incl - mine;
       for (unsigned v = 0; v < wv; ++v) off += wave_cnt[v];
-      const unsigned row0 = (unsigned)i * (unsigned)W;
+      // table offsets relative to the chunk's first point (31 bits + sign: P * W * 2^(c-1) <= 256 * 32 * 2^14; the whole table of a
+      // 15-bit Lagrange half has more than 2^31 entries)
+      const unsigned row0 = threadIdx.x * (unsigned)W;
       while (mask) {
         const int w = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -783,18 +785,19 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
     const unsigned M = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     total += M;
     // software pipeline: the entry two steps ahead and the table point one step ahead are in flight during an addition
+    const G1Affine *__restrict__ Tc = T + (((size_t)chunk * P * (size_t)W) << (c - 1));   // this chunk's rows of the table
     unsigned e = threadIdx.x, en = 0, en2 = 0;
     G1Affine p;
     if (e < M) {
       en = lst[e];
-      p = T[en & 0x7fffffffu];
+      p = Tc[en & 0x7fffffffu];
     }
     if (e + 256 < M) en2 = lst[e + 256];
     while (e < M) {
       const unsigned e2 = e + 256;
       unsigned en3 = 0;
       G1Affine p2;
-      if (e2 < M) p2 = T[en2 & 0x7fffffffu];
+      if (e2 < M) p2 = Tc[en2 & 0x7fffffffu];
       if (e2 + 256 < M) en3 = lst[e2 + 256];
       g1x29_add_affine(acc, g1a29_load(p), (en >> 31) != 0);
       e = e2;
@@ -929,22 +932,23 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
   if (lane == 0) out[slot] = g1x_to_affine(g1x29_to_std(acc));
 }
 
-// Window width of the digit-multiple table: the widest whose table fits the per-basis budget (ZKFHE_TABLE_GB, default 96 -- 14-bit
-// digits at n = 2^13: 86 GB for the Lagrange half of an SRS, whose wide commitment calls then need 6 % fewer additions than with 13
-// bits; the monomial half, which only serves calls of 1-3 columns, is created with half the budget: 13 bits, 43 GB;
-// ZKFHE_TABLE_BITS forces a width, 0 = no table: every call takes the bucket pipeline).
+// Window width of the digit-multiple table: the widest (<= 15 bits) whose table fits the per-basis budget (ZKFHE_TABLE_GB, default
+// 160 -- 15-bit digits at n = 2^13: 17 windows x 16 384 multiples x 64 B per base point, 146 GB for the Lagrange half of an SRS, whose
+// wide commitment calls then need 21.4 M additions per proof against 24.9 M with 13 bits; the monomial half, which only serves calls
+// of 1-3 columns, is created with half the budget: 13 bits, 43 GB.  A table may hold more than 2^31 entries: k_msm_table addresses
+// it relative to the chunk it is summing.  ZKFHE_TABLE_BITS forces a width, 0 = no table: every call takes the bucket pipeline).
 int table_bits(size_t n, double budget_scale) {
   // read per basis (creation is rare): tests switch widths inside one process
   const char *e = getenv("ZKFHE_TABLE_BITS");
   const int forced = e ? atoi(e) : -1;
   const char *g = getenv("ZKFHE_TABLE_GB");
-  const double budget = (g ? atof(g) : 96.0) * 1073741824.0 * budget_scale;
+  const double budget = (g ? atof(g) : 160.0) * 1073741824.0 * budget_scale;
   auto fits = [&](int c) {
     const double entries = (double)n * (double)((255 + c - 1) / c) * (double)(1u << (c - 1));
-    return c >= 8 && c <= 14 && entries < 2147483648.0 && entries * sizeof(G1Affine) <= budget;
+    return c >= 8 && c <= 15 && entries * sizeof(G1Affine) <= budget;
   };
   if (forced >= 0) return forced > 0 && fits(forced) ? forced : 0;
-  for (int c = 14; c >= 8; --c)
+  for (int c = 15; c >= 8; --c)
     if (fits(c)) return c;
   return 0;
 }

@@ -230,7 +230,7 @@ int main(int argc, char **argv) {
     return 0;
   }
   setenv("ZKFHE_SPIN_WAIT", "1", 0);  // one proof at a time: spinning waits are ~1.4 ms faster per proof than sleeping ones
-  // one command = one keygen or one proof: the 129 GB of digit-multiple tables a proving service builds once (1.6 s) would cost a
+  // one command = one keygen or one proof: the 189 GB of digit-multiple tables a proving service builds once (2.7 s) would cost a
   // hundred proofs' time here; a 2 GB budget builds in ~30 ms and serves the narrow commitments
   setenv("ZKFHE_TABLE_GB", "2", 0);
   zkfhe_ctx *ctx = nullptr;
