@@ -936,14 +936,15 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
 // 160 -- 15-bit digits at n = 2^13: 17 windows x 16 384 multiples x 64 B per base point, 146 GB for the Lagrange half of an SRS, whose
 // wide commitment calls then need 21.4 M additions per proof against 24.9 M with 13 bits; the monomial half, which only serves calls
 // of 1-3 columns, is created with half the budget: 13 bits, 43 GB.  A table may hold more than 2^31 entries: k_msm_table addresses
-// it relative to the chunk it is summing.  Bases longer than 2^14 keep the 48 GB budget of round 3: their wide calls take the bucket
-// pipeline and the table only serves the calls of a few columns.  ZKFHE_TABLE_BITS forces a width, 0 = no table).
+// it relative to the chunk it is summing.  Longer bases get narrower digits from the same budget (2^16: 11 bits, 2^19: 8 bits for the
+// Lagrange half alone); their wide calls take the bucket pipeline and the table serves the calls of a few columns (k = 19: 173 -> 169 ms
+// per proof).  ZKFHE_TABLE_BITS forces a width, 0 = no table).
 int table_bits(size_t n, double budget_scale) {
   // read per basis (creation is rare): tests switch widths inside one process
   const char *e = getenv("ZKFHE_TABLE_BITS");
   const int forced = e ? atoi(e) : -1;
   const char *g = getenv("ZKFHE_TABLE_GB");
-  const double budget = (g ? atof(g) : (n <= 16384 ? 160.0 : 48.0)) * 1073741824.0 * budget_scale;   // longer bases: the round-3 budget (the bucket pipeline serves their wide calls)
+  const double budget = (g ? atof(g) : 160.0) * 1073741824.0 * budget_scale;
   auto fits = [&](int c) {
     const double entries = (double)n * (double)((255 + c - 1) / c) * (double)(1u << (c - 1));
     return c >= 8 && c <= 15 && entries * sizeof(G1Affine) <= budget;
