@@ -22,8 +22,12 @@ def main():
     ap.add_argument("--transcript", default="blake2b")
     ap.add_argument("--inputs", type=int, default=12)
     ap.add_argument("--config", default="k13", choices=["k13", "k16"], help="k16: N = 4096, Q = 2^60 - 93 (auto-configured columns)")
+    ap.add_argument("--hash-mode", default="latency", choices=["latency", "shared"], help="shared: the transcripts' long runs through the eight-lane Poseidon service")
+    ap.add_argument("--gate", type=int, default=0, help="admission gate of the heavy middle of a proof (zkfhe_prover_gate)")
     args = ap.parse_args()
     import zk_fhe_amd as zk
+    zk.host_hash_mode(args.hash_mode)
+    zk.prover_gate(args.gate)
     import zk_fhe_amd.batch as batch
     from zk_fhe_amd import inputs as gen
     T, B = 7, 19
@@ -66,7 +70,8 @@ def main():
     batch.run_concurrent(list(range(args.proofs)), ctxs, one)
     dt = time.time() - t0
     print(json.dumps({"proofs": done[0], "failed": len(bad), "first_failures": bad[:5], "seconds": round(dt, 1),
-                      "distinct_pairs": len(first), "streams": args.streams, "transcript": args.transcript}))
+                      "distinct_pairs": len(first), "streams": args.streams, "transcript": args.transcript,
+                      "hash_mode": zk.host_hash_mode(), "gate": args.gate, "table_bits": srs.table_bits()[0]}))
     return 1 if bad else 0
 
 
