@@ -287,6 +287,32 @@ def test_msm_many_columns_all_reduction_paths(ctx, c):
     B.destroy()
 
 
+@pytest.mark.parametrize("c,sort", [(13, "2:6"), (14, "2:7"), (14, "2"), (16, "0"), (16, "2:7"), (16, "1"), (14, "1")])
+def test_msm_two_level_sort_geometries(ctx, monkeypatch, c, sort):
+    """Bases with K >= 2048 buckets sort their entries in two levels (k_msm_chist / k_msm_cscatter / k_msm_fine): 8 fine bits
+    of the bucket id in the entry word unless the index needs the room -- fewer forced here on n = 4096 (ZKFHE_SORT=2:<bits>), and the one-pass sort (ZKFHE_SORT=1) on the
+    same inputs; full-width, short, negative-short, constant (one bucket holds a whole window) and zero columns, 24 columns."""
+    import zk_fhe_amd as zk
+    monkeypatch.setenv("ZKFHE_SORT", sort)
+    rng = np.random.default_rng(900 + c)
+    n, n_cols = 4096, 24
+    bases = _bases(n, seed=40 + c)
+    bases[7] = 0
+    S = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
+    S[1] = orc.ints_to_mont([int(rng.integers(0, 256)) if i % 3 else (pyref.R - int(rng.integers(1, 1000))) for i in range(n)])
+    S[2] = orc.ints_to_mont([[0, 1, 536870908][int(rng.integers(0, 3))] for _ in range(n)])
+    S[3] = orc.ints_to_mont([0] * n)
+    S[4] = orc.ints_to_mont([1] * n)
+    S[5] = orc.ints_to_mont([pyref.R - 1] * n)
+    S[6] = orc.ints_to_mont([(1 << 253) + 12345] * n)
+    B = zk.Basis(ctx, bases, c)
+    assert not B.has_table
+    got = ctx.msm(B, S)
+    assert np.array_equal(got, orc.msm(S, bases))
+    assert np.array_equal(ctx.msm(B, S[:3]), got[:3])
+    B.destroy()
+
+
 def test_msm_k13_batch_linearity(ctx):
     """BASELINE size: 64 columns x 8192 with the witness scalar mix; oracle on a sample + additivity."""
     import zk_fhe_amd as zk

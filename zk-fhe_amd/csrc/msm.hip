@@ -71,12 +71,13 @@ __device__ __forceinline__ void for_each_digit(const Fr &mont, int c, int window
   if (neg) s = fp_neg<FrP>(s);  // r - s  (s != 0 here)
   u32 carry = 0;
   const u32 mask = (1u << c) - 1, halfv = 1u << (c - 1);
+  // the scalar is shifted down by c bits per window (eight v_alignbit): indexing its limbs by the window's bit position put the
+  // value into scratch memory (48 bytes per lane in every sort kernel)
   for (int w = 0; w < windows; ++w) {
-    const int bit = w * c;
-    const int limb = bit >> 5, sh = bit & 31;
-    u32 v = limb < 8 ? s.l[limb] >> sh : 0u;
-    if (sh + c > 32 && limb + 1 < 8) v |= s.l[limb + 1] << (32 - sh);
-    v = (v & mask) + carry;
+    u32 v = (s.l[0] & mask) + carry;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s.l[i] = __builtin_amdgcn_alignbit(s.l[i + 1], s.l[i], (u32)c);
+    s.l[7] >>= c;
     bool dneg = false;
     if (v > halfv) {
       v = (1u << c) - v;
@@ -176,6 +177,216 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_scatter(const Fr *__restri
       const unsigned pos = atomicAdd(&lh[b], 1u);
       e[pos] = ((unsigned)w * (unsigned)n + (unsigned)i) | (neg ? 0x80000000u : 0u);
     });
+}
+
+// ---- two-level counting sort (K >= 2048 buckets: the long bases, n >= 2^15) -------------------------------------------
+// With K = 8192 ... 32768 buckets a workgroup's 2048 scalars put about one entry into each LDS counter: the privatised
+// histogram above saves nothing (one device-scope atomic per entry and bin, 128 KB of counters = one workgroup per CU) and every
+// sorted entry is a lone 4-byte store into a 33 MB array (k = 19: 20 ms of a 170 ms proof in k_msm_hist + k_msm_scatter).
+// Here the bucket id is split into a coarse part (NB = K >> L bins) and L fine bits that ride in the spare bits of the entry
+// word (entry indices need log2(W n) bits):
+//   k_msm_chist     coarse histogram per column (NB counters per workgroup, NB atomics per 2048 scalars);
+//   k_msm_cscan     exclusive scan -> coarse segment bounds;
+//   k_msm_cscatter  512 scalars per workgroup: entries ranked by coarse bin in LDS and copied out as contiguous runs
+//                   (one reserved range per workgroup and bin) into the staging array, fine bits attached;
+//   k_msm_fine      one workgroup per (column, coarse bin): histogram of the segment over its F = 2^L buckets, scan
+//                   (-> off[], the bucket bounds every later kernel reads), and the placement inside the segment -- a
+//                   window of a few hundred KB that the L2 holds until its lines are complete.
+constexpr unsigned CH_SCALARS = 2048, CS_SCALARS = 512, CS_THREADS = 256, FINE_THREADS = 512, FINE_MAX = 256, FINE_COPIES = 8, FINE_CTRS = FINE_MAX * FINE_COPIES, FINE_TILE = 14336;
+static_assert(FINE_CTRS == 4 * FINE_THREADS && FINE_TILE % (4 * FINE_THREADS) == 0, "k_msm_fine: four counters per thread, whole 16-byte loads per tile");
+constexpr int FINE_BITS_MAX = 8;   // F = 256 buckets per coarse bin: enough workgroups in k_msm_fine on a basis of 2^15 points
+
+__global__ void __launch_bounds__(CS_THREADS) k_msm_chist(const Fr *__restrict__ scalars, size_t col_stride, size_t n, unsigned chunks_per_col, int c, int windows,
+                                                         int L, unsigned NB, unsigned *__restrict__ chist /* [n_cols][NB] */) {
+  extern __shared__ unsigned lh[];
+  const size_t col = blockIdx.x / chunks_per_col;
+  const unsigned chunk = blockIdx.x % chunks_per_col;
+  for (unsigned b = threadIdx.x; b < NB; b += CS_THREADS) lh[b] = 0;
+  __syncthreads();
+  const size_t i0 = (size_t)chunk * CH_SCALARS, i1 = min(n, i0 + CH_SCALARS);
+  for (size_t i = i0 + threadIdx.x; i < i1; i += CS_THREADS)
+    for_each_digit(scalars[col * col_stride + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&lh[(b - 1) >> L], 1u); });
+  __syncthreads();
+  for (unsigned g = threadIdx.x; g < NB; g += CS_THREADS) {
+    const unsigned v = lh[g];
+    if (v) atomicAdd(&chist[col * NB + g], v);
+  }
+}
+
+// one thread per column: coff[col][0..NB] = exclusive scan of the coarse counts, ccursor = the segment starts
+__global__ void __launch_bounds__(64) k_msm_cscan(const unsigned *__restrict__ chist, unsigned NB, size_t n_cols, unsigned *__restrict__ coff /* [n_cols][NB+1] */,
+                                                  unsigned *__restrict__ ccursor /* [n_cols][NB] */) {
+  const size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (col >= n_cols) return;
+  unsigned acc = 0;
+  for (unsigned g = 0; g < NB; ++g) {
+    coff[col * (NB + 1) + g] = acc;
+    ccursor[col * NB + g] = acc;
+    acc += chist[col * NB + g];
+  }
+  coff[col * (NB + 1) + NB] = acc;
+}
+
+__global__ void __launch_bounds__(CS_THREADS) k_msm_cscatter(const Fr *__restrict__ scalars, size_t col_stride, size_t n, unsigned chunks_per_col, int c, int windows,
+                                                            int L, unsigned NB, unsigned *__restrict__ ccursor, unsigned *__restrict__ stage, size_t col_entries) {
+  extern __shared__ unsigned sh[];
+  unsigned *cnt = sh, *loff = sh + NB, *gb = sh + 2 * NB, *buf = sh + 3 * NB;   // buf: CS_SCALARS * windows words
+  const size_t col = blockIdx.x / chunks_per_col;
+  const unsigned chunk = blockIdx.x % chunks_per_col;
+  for (unsigned b = threadIdx.x; b < NB; b += CS_THREADS) cnt[b] = 0;
+  __syncthreads();
+  const size_t i0 = (size_t)chunk * CS_SCALARS, i1 = min(n, i0 + CS_SCALARS);
+  for (size_t i = i0 + threadIdx.x; i < i1; i += CS_THREADS)
+    for_each_digit(scalars[col * col_stride + i], c, windows, [&](int, u32 b, bool) { atomicAdd(&cnt[(b - 1) >> L], 1u); });
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive scan of cnt[0..NB) by the first wave: `per` consecutive bins per lane
+    const unsigned per = (NB + 63) / 64, lo = threadIdx.x * per, hi = min(lo + per, NB);
+    unsigned s = 0;
+    for (unsigned g = lo; g < hi; ++g) s += cnt[g];
+    unsigned inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = __shfl_up(inc, d);
+      if ((int)threadIdx.x >= d) inc += t;
+    }
+    unsigned acc = inc - s;
+    for (unsigned g = lo; g < hi; ++g) {
+      loff[g] = acc;
+      acc += cnt[g];
+    }
+  }
+  __syncthreads();
+  for (unsigned g = threadIdx.x; g < NB; g += CS_THREADS) {
+    const unsigned v = cnt[g];
+    gb[g] = v ? atomicAdd(&ccursor[col * NB + g], v) : 0u;   // this workgroup's run inside the coarse segment
+    cnt[g] = loff[g];                                        // from here on: the running position inside buf
+  }
+  __syncthreads();
+  const unsigned fmask = (1u << L) - 1;
+  const int fsh = 31 - L;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += CS_THREADS)
+    for_each_digit(scalars[col * col_stride + i], c, windows, [&](int w, u32 b, bool neg) {
+      const unsigned key = b - 1;
+      const unsigned pos = atomicAdd(&cnt[key >> L], 1u);
+      buf[pos] = ((unsigned)w * (unsigned)n + (unsigned)i) | ((key & fmask) << fsh) | (neg ? 0x80000000u : 0u);
+    });
+  __syncthreads();
+  unsigned *dst_col = stage + col * col_entries;
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (unsigned g = wv; g < NB; g += CS_THREADS / 64) {
+    const unsigned base = loff[g], len = cnt[g] - base;
+    unsigned *dst = dst_col + gb[g];
+    for (unsigned k = lane; k < len; k += 64) dst[k] = buf[base + k];
+  }
+}
+
+// exclusive scan over FINE_CTRS = 4 * FINE_THREADS counters in place (four consecutive counters per thread); returns nothing,
+// every thread calls it
+__device__ __forceinline__ void fine_scan_inplace(unsigned *ctr, unsigned *wsum /* [FINE_THREADS / 64] */) {
+  const unsigned t = threadIdx.x, lane = t & 63;
+  const uint4 c = *(const uint4 *)(ctr + 4 * t);
+  const unsigned s = c.x + c.y + c.z + c.w;
+  unsigned inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned u = __shfl_up(inc, d);
+    if ((int)lane >= d) inc += u;
+  }
+  if (lane == 63) wsum[t >> 6] = inc;
+  __syncthreads();
+  unsigned pre = inc - s;
+  for (unsigned w = 0; w < (t >> 6); ++w) pre += wsum[w];
+  *(uint4 *)(ctr + 4 * t) = make_uint4(pre, pre + c.x, pre + c.x + c.y, pre + c.x + c.y + c.z);
+  __syncthreads();
+}
+
+// One workgroup per (column, coarse bin).  Scattering the entries of the segment straight to their buckets is a lone 4-byte store
+// per entry, and the chip retires ~105 G of those per second whatever the window they fall into (measured: 3.0 ms per 32 columns of
+// 2^19, 0.46 ms with the stores left out).  So the segment is sorted tile by tile in LDS -- FINE_TILE entries: one returning atomic
+// per entry gives its arrival rank, a scan the run starts, then placement in the LDS buffer -- and leaves as one contiguous run per
+// bucket and tile (~56 entries on a full-width column).
+// Witness columns and narrow top windows pile thousands of entries onto a few buckets, and LDS atomics on one address serialise
+// (~10 cycles per lane, measured): every bucket has FINE_COPIES counters, lane l uses copy l % FINE_COPIES -- sub-buckets that sort
+// next to each other, so the order inside a bucket changes and nothing else.
+__global__ void __launch_bounds__(FINE_THREADS, 4) k_msm_fine(const unsigned *__restrict__ coff, unsigned NB, int L, const unsigned *__restrict__ stage, size_t col_entries,
+                                                             unsigned K1, unsigned *__restrict__ off, unsigned *__restrict__ entries) {
+  extern __shared__ unsigned buf[];   // FINE_TILE words
+  __shared__ __attribute__((aligned(16))) unsigned ctr[FINE_CTRS + 4];
+  __shared__ unsigned gcur[FINE_MAX], wsum[FINE_THREADS / 64];
+  const size_t col = blockIdx.x / NB;
+  const unsigned g = blockIdx.x % NB;
+  const unsigned F = 1u << L;
+  const unsigned lo = coff[col * (NB + 1) + g], hi = coff[col * (NB + 1) + g + 1];
+  const unsigned *src = stage + col * col_entries;   // 16-byte aligned: col_entries is a multiple of four
+  const int fsh = 31 - L;
+  const unsigned fmask = F - 1;
+  const unsigned t = threadIdx.x, lane = t & 63, copy = lane % FINE_COPIES;
+  for (unsigned i = t; i < FINE_CTRS + 4; i += FINE_THREADS) ctr[i] = 0;
+  __syncthreads();
+  const unsigned a0 = lo & ~3u;
+  for (unsigned p0 = a0; p0 < hi; p0 += 4 * FINE_THREADS) {   // histogram of the whole segment
+    const unsigned p = p0 + 4 * t;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p < hi) v = *(const uint4 *)(src + p);
+    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (p + j >= lo && p + j < hi) atomicAdd(&ctr[((w4[j] >> fsh) & fmask) * FINE_COPIES + copy], 1u);
+  }
+  __syncthreads();
+  fine_scan_inplace(ctr, wsum);
+  if (t < F) {
+    const unsigned pre = lo + ctr[t * FINE_COPIES];
+    off[col * K1 + (size_t)g * F + t] = pre;
+    gcur[t] = pre;                       // where the next run of bucket t goes
+  }
+  if (g == NB - 1 && t == 0) off[col * K1 + (K1 - 1)] = hi;   // the column's total
+  unsigned *e = entries + col * col_entries;
+  const unsigned keep = 0x80000000u | ((1u << fsh) - 1);
+  constexpr unsigned R = FINE_TILE / (4 * FINE_THREADS);
+  for (unsigned t0 = a0; t0 < hi; t0 += FINE_TILE) {
+    uint4 v[R];
+#pragma unroll
+    for (unsigned r = 0; r < R; ++r) {
+      const unsigned p = t0 + 4 * (r * FINE_THREADS + t);
+      v[r] = make_uint4(0, 0, 0, 0);
+      if (p < hi) v[r] = *(const uint4 *)(src + p);
+    }
+    __syncthreads();   // the previous tile's runs are out, ctr is free
+    for (unsigned i = t; i < FINE_CTRS + 4; i += FINE_THREADS) ctr[i] = 0;
+    __syncthreads();
+    unsigned arr[R][4];   // arrival rank of the entry inside its sub-bucket's run of this tile
+#pragma unroll
+    for (unsigned r = 0; r < R; ++r) {
+      const unsigned p = t0 + 4 * (r * FINE_THREADS + t);
+      const unsigned w4[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        arr[r][j] = 0;
+        if (p + j >= lo && p + j < hi) arr[r][j] = atomicAdd(&ctr[((w4[j] >> fsh) & fmask) * FINE_COPIES + copy], 1u);
+      }
+    }
+    __syncthreads();
+    fine_scan_inplace(ctr, wsum);   // ctr[FINE_CTRS] stays 0: the last bucket's end comes from the tile's length below
+#pragma unroll
+    for (unsigned r = 0; r < R; ++r) {
+      const unsigned p = t0 + 4 * (r * FINE_THREADS + t);
+      const unsigned w4[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p + j >= lo && p + j < hi) buf[ctr[((w4[j] >> fsh) & fmask) * FINE_COPIES + copy] + arr[r][j]] = w4[j] & keep;
+    }
+    __syncthreads();
+    const unsigned tile_lo = t0 < lo ? lo : t0, tile_hi = t0 + FINE_TILE < hi ? t0 + FINE_TILE : hi;
+    for (unsigned f = t >> 6; f < F; f += FINE_THREADS / 64) {   // one wave per bucket run
+      const unsigned b0 = ctr[f * FINE_COPIES], b1 = f + 1 < F ? ctr[(f + 1) * FINE_COPIES] : tile_hi - tile_lo;
+      const unsigned *sp = buf + b0;
+      unsigned *d = e + gcur[f];
+      for (unsigned k = lane; k < b1 - b0; k += 64) d[k] = sp[k];
+    }
+    __syncthreads();
+    if (t < F) gcur[t] += (t + 1 < F ? ctr[(t + 1) * FINE_COPIES] : tile_hi - tile_lo) - ctr[t * FINE_COPIES];
+  }
 }
 
 // ---- bounded-length accumulation tasks -------------------------------------------------------------
@@ -1027,7 +1238,16 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
   return ZKFHE_OK;
 }
 
+// Smallest bucket count that takes the two-level sort.  K = 8192 (n = 2^15 .. 2^17, 14-bit windows) stays with the one-pass sort:
+// 32 KB of counters, four workgroups per CU, eight entries per counter and workgroup -- measured equal (k = 16: 3.3 ms of sorting per
+// proof either way); at K = 32768 the two-level sort halves it (k = 19: 19 -> 13 ms).  ZKFHE_SORT=2:<bits> lowers it to 2048 (tests).
+static unsigned two_level_min_k() {
+  const char *e = getenv("ZKFHE_SORT");
+  return e && e[0] == '2' ? 2048u : 16384u;
+}
+
 int default_window_bits(size_t n) {
+  if (const char *e = getenv("ZKFHE_WINDOW_BITS")) if (atoi(e) >= 8 && atoi(e) <= 16 && n >= 32768) return atoi(e);
   if (n <= 64) return 5;
   if (n <= 1024) return 8;
   if (n <= 4096) return 11;
@@ -1144,7 +1364,19 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
   if (rc) return rc;
   rc = zk_scratch(ctx, 2, n_cols * col_entries * sizeof(unsigned) + 64, &p2);
   if (rc) return rc;
-  rc = zk_scratch(ctx, 0, (n_cols * (size_t)K + max_tasks) * sizeof(G1X), &p0);
+  // two-level sort (see k_msm_chist): L fine bits of the bucket id travel in the entry word above the log2(W n) index bits
+  int idx_bits = 1;
+  while (((size_t)1 << idx_bits) < col_entries) ++idx_bits;
+  int L = 31 - idx_bits;
+  if (L > FINE_BITS_MAX) L = FINE_BITS_MAX;
+  const char *sort_env = getenv("ZKFHE_SORT");   // "1": the one-pass sort for every basis; "2:<bits>": fewer fine bits (tests: the geometry of n = 2^19 on a short basis)
+  if (sort_env && sort_env[0] == '2' && sort_env[1] == ':' && atoi(sort_env + 2) >= 6 && atoi(sort_env + 2) < L) L = atoi(sort_env + 2);
+  const bool two_level = K >= two_level_min_k() && L >= 6 && !(sort_env && sort_env[0] == '1');
+  const unsigned NB = two_level ? K >> L : 0;
+  // the staging array of the two-level sort lives where the buckets and partials will be (dead before they are written)
+  size_t s0 = (n_cols * (size_t)K + max_tasks) * sizeof(G1X);
+  if (two_level && s0 < n_cols * col_entries * sizeof(unsigned)) s0 = n_cols * col_entries * sizeof(unsigned);
+  rc = zk_scratch(ctx, 0, s0, &p0);
   if (rc) return rc;
   unsigned *hist = (unsigned *)p1;
   unsigned *off = hist + n_cols * K1;
@@ -1161,27 +1393,55 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
   unsigned *entries = (unsigned *)p2;
   G1X *buckets = (G1X *)p0;
   G1X *partials = buckets + n_cols * (size_t)K;
-  {
-    unsigned gc = zk_blocks(n_cols * K1, 256);
-    if (gc > (unsigned)ctx->num_cu * 8) gc = (unsigned)ctx->num_cu * 8;
-    k_msm_clear<<<gc, 256, 0, ctx->stream>>>(hist, n_cols * K1, heavy_count);
+  if (two_level) {
+    unsigned *chist = hist, *coff = cursor, *ccursor = cursor + n_cols * (NB + 1);   // inside the regions of the one-pass sort
+    unsigned *stage = (unsigned *)p0;
+    k_msm_clear<<<zk_blocks(n_cols * NB, 256), 256, 0, ctx->stream>>>(chist, n_cols * NB, heavy_count);
+    ZK_LAUNCH_CHECK(ctx);
+    const unsigned ch_chunks = (unsigned)((n + CH_SCALARS - 1) / CH_SCALARS), cs_chunks = (unsigned)((n + CS_SCALARS - 1) / CS_SCALARS);
+    k_msm_chist<<<(unsigned)(n_cols * ch_chunks), CS_THREADS, NB * sizeof(unsigned), ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, ch_chunks, c, W, L, NB, chist);
+    ZK_LAUNCH_CHECK(ctx);
+    k_msm_cscan<<<zk_blocks(n_cols, 64), 64, 0, ctx->stream>>>(chist, NB, n_cols, coff, ccursor);
+    ZK_LAUNCH_CHECK(ctx);
+    const size_t cs_lds = ((size_t)3 * NB + (size_t)CS_SCALARS * W) * sizeof(unsigned);
+    static bool cs_attr = false;
+    if (!cs_attr && cs_lds > 48 * 1024) {
+      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_cscatter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      cs_attr = true;
+    }
+    k_msm_cscatter<<<(unsigned)(n_cols * cs_chunks), CS_THREADS, cs_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, cs_chunks, c, W, L, NB, ccursor, stage,
+                                                                                         col_entries);
+    ZK_LAUNCH_CHECK(ctx);
+    static bool fine_attr = false;
+    if (!fine_attr) {
+      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_fine, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_TILE * sizeof(unsigned)));
+      fine_attr = true;
+    }
+    k_msm_fine<<<(unsigned)(n_cols * NB), FINE_THREADS, FINE_TILE * sizeof(unsigned), ctx->stream>>>(coff, NB, L, stage, col_entries, K1, off, entries);
+    ZK_LAUNCH_CHECK(ctx);
+  } else {
+    {
+      unsigned gc = zk_blocks(n_cols * K1, 256);
+      if (gc > (unsigned)ctx->num_cu * 8) gc = (unsigned)ctx->num_cu * 8;
+      k_msm_clear<<<gc, 256, 0, ctx->stream>>>(hist, n_cols * K1, heavy_count);
+      ZK_LAUNCH_CHECK(ctx);
+    }
+    const unsigned chunks_per_col = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+    const unsigned grid = (unsigned)(n_cols * chunks_per_col);
+    const size_t sort_lds = (size_t)K1 * sizeof(unsigned);
+    static bool sort_attr = false;
+    if (!sort_attr && sort_lds > 48 * 1024) {
+      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      sort_attr = true;
+    }
+    k_msm_hist<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, hist, K1);
+    ZK_LAUNCH_CHECK(ctx);
+    k_msm_scan<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(hist, off, cursor, K1);
+    ZK_LAUNCH_CHECK(ctx);
+    k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
     ZK_LAUNCH_CHECK(ctx);
   }
-  const unsigned chunks_per_col = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
-  const unsigned grid = (unsigned)(n_cols * chunks_per_col);
-  const size_t sort_lds = (size_t)K1 * sizeof(unsigned);
-  static bool sort_attr = false;
-  if (!sort_attr && sort_lds > 48 * 1024) {
-    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    sort_attr = true;
-  }
-  k_msm_hist<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, hist, K1);
-  ZK_LAUNCH_CHECK(ctx);
-  k_msm_scan<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(hist, off, cursor, K1);
-  ZK_LAUNCH_CHECK(ctx);
-  k_msm_scatter<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, cursor, K1, entries, col_entries);
-  ZK_LAUNCH_CHECK(ctx);
   k_msm_task_count<<<(unsigned)n_cols, 256, 0, ctx->stream>>>(off, K, TASK_E, col_hist);
   ZK_LAUNCH_CHECK(ctx);
   k_msm_task_colscan<<<1, 128, 0, ctx->stream>>>(col_hist, (unsigned)n_cols, col_base, n_tasks_dev);
