@@ -127,6 +127,88 @@ __global__ void __launch_bounds__(256) k_dif_fused(const Fr *src, Fr *data, size
   }
 }
 
+// 3 + SB radix-2 DIF stages in ONE pass over memory (rows of 2^17 .. 2^19: the four to six stages above the 2^13 tile were two
+// passes of k_dif_fused, each a full read and write of every row -- 18.7 ms of a k = 19 proof at 2.5 TB/s).  A workgroup of 128
+// threads owns a tile of M = 2^(3+SB) positions m (stride q = 2^(log_half - 2 - SB) elements) x JJ = 1024 / M consecutive
+// offsets: a thread runs three levels on m = g + (M/8) r in registers, the tile goes through LDS (two 16-byte halves per element,
+// each half array contiguous across the lanes: no bank conflicts), and the thread runs the last SB levels on the eight
+// consecutive m = 8u + r.  Loads and stores are runs of JJ * 32 bytes.
+template <int SB>
+__global__ void __launch_bounds__(128) k_dif_lds(const Fr *src, Fr *data, size_t n_cols, int log_n, int log_half, const Fr *__restrict__ tw_n,
+                                                 const Fr *__restrict__ pre = nullptr, unsigned rows = 1 /* as in k_dif_stage */) {
+  constexpr int S = 3 + SB, M = 1 << S, JJ = 1024 / M, G = M / 8;
+  __shared__ uint4 sh_lo[1024], sh_hi[1024];
+  const int log_q = log_half - S + 1;
+  const int sh0 = log_n - 1 - log_half;
+  const size_t tiles_per_col = (size_t)1 << (log_n - 10);
+  const size_t total = n_cols * tiles_per_col;
+  const unsigned jj = threadIdx.x % JJ, gu = threadIdx.x / JJ;   // gu: g in the first half, u in the second
+  for (size_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const size_t c = tile >> (log_n - 10);
+    const size_t i = (tile & (tiles_per_col - 1)) * JJ + jj;     // position among the n / M of the column
+    const size_t j0 = i & (((size_t)1 << log_q) - 1);
+    const size_t w = ((i >> log_q) << (log_half + 1)) + j0;
+    const size_t o = (c << log_n) + w;
+    Fr x[8];
+    if (pre) {
+      const size_t cs = c / rows, k1 = c - cs * rows;
+      const Fr *ps = src + (cs << log_n) + w, *pp = pre + (k1 << log_n) + w;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) x[r] = fr29_mul_const(ps[(size_t)(gu + G * r) << log_q], pp[(size_t)(gu + G * r) << log_q]);
+    } else {
+      const Fr *ps = src + o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) x[r] = ps[(size_t)(gu + G * r) << log_q];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int hr = 4 >> t;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r & hr) continue;
+        const size_t j = j0 + ((size_t)(gu + G * (r & (hr - 1))) << log_q);
+        const Fr a = x[r], b = x[r + hr];
+        x[r] = a + b;
+        const Fr d = a - b;
+        const size_t e = j << (sh0 + t);
+        x[r + hr] = e ? fr29_mul_const(d, tw_n[e]) : d;
+      }
+    }
+    __syncthreads();   // the previous tile has been read
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const unsigned idx = (gu + G * r) * JJ + jj;
+      sh_lo[idx] = make_uint4(x[r].l[0], x[r].l[1], x[r].l[2], x[r].l[3]);
+      sh_hi[idx] = make_uint4(x[r].l[4], x[r].l[5], x[r].l[6], x[r].l[7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const unsigned idx = (8 * gu + r) * JJ + jj;
+      const uint4 lo = sh_lo[idx], hi = sh_hi[idx];
+      x[r].l[0] = lo.x, x[r].l[1] = lo.y, x[r].l[2] = lo.z, x[r].l[3] = lo.w;
+      x[r].l[4] = hi.x, x[r].l[5] = hi.y, x[r].l[6] = hi.z, x[r].l[7] = hi.w;
+    }
+#pragma unroll
+    for (int t = 3; t < S; ++t) {
+      const int hm = M >> (t + 1);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r & hm) continue;
+        const size_t j = j0 + ((size_t)(r & (hm - 1)) << log_q);
+        const Fr a = x[r], b = x[r + hm];
+        x[r] = a + b;
+        const Fr d = a - b;
+        const size_t e = j << (sh0 + t);
+        x[r + hm] = e ? fr29_mul_const(d, tw_n[e]) : d;
+      }
+    }
+    Fr *p = data + o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p[(size_t)(8 * gu + r) << log_q] = x[r];
+  }
+}
+
 __global__ void __launch_bounds__(256) k_pow_table(Fr base, Fr *__restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr r = Fr::one();
@@ -359,6 +441,20 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
   const Fr *tw = inverse ? dom->inv29 : dom->fwd29;
   for (int s = log_n - 1; s >= MAX_TILE_LOG;) {
     const int left = s - MAX_TILE_LOG + 1;
+    static const bool lds_pass = !(getenv("ZKFHE_NTT_LDS_PASS") && getenv("ZKFHE_NTT_LDS_PASS")[0] == '0');
+    if (left >= 4 && lds_pass) {   // four to six stages in one pass through LDS (seven: four, then three in registers)
+      const int S = left == 7 ? 4 : (left > 6 ? 6 : left);
+      const size_t tiles = n_cols * (n >> 10);
+      unsigned grid = (unsigned)(tiles < (size_t)ctx->num_cu * 64 ? tiles : (size_t)ctx->num_cu * 64);
+      if (S == 6) k_dif_lds<3><<<grid, 128, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw, pre, rows);
+      else if (S == 5) k_dif_lds<2><<<grid, 128, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw, pre, rows);
+      else k_dif_lds<1><<<grid, 128, 0, ctx->stream>>>(pass_in, work, n_cols, log_n, s, tw, pre, rows);
+      ZK_LAUNCH_CHECK(ctx);
+      pre = nullptr;
+      pass_in = work;
+      s -= S;
+      continue;
+    }
     const int S = left >= 3 ? 3 : left;       // fuse up to three stages per pass over memory
     size_t wk = n_cols * (n >> S);
     unsigned grid = zk_blocks(wk, 256);

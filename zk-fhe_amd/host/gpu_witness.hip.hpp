@@ -33,9 +33,10 @@ ZK_HD Fr c_u64(u64 v) {
   t.l[1] = (zk::u32)(v >> 32);
   return t;
 }
+// limbs are selected, not indexed: a limb index computed at run time puts the value into scratch memory on the device
 ZK_HD Fr c_pow2(unsigned bits) {
-  Fr t = Fr::zero();
-  t.l[bits >> 5] = 1u << (bits & 31);
+  Fr t;
+  for (unsigned i = 0; i < 8; ++i) t.l[i] = i == (bits >> 5) ? 1u << (bits & 31) : 0u;
   return t;
 }
 ZK_HD unsigned c_bits(const Fr &a) {
@@ -43,7 +44,12 @@ ZK_HD unsigned c_bits(const Fr &a) {
     if (a.l[i]) return 32 * i + (32 - (unsigned)__builtin_clz(a.l[i]));
   return 0;
 }
-ZK_HD zk::u32 c_byte(const Fr &a, unsigned shift) { return (a.l[shift >> 5] >> (shift & 31)) & 0xffu; }
+ZK_HD zk::u32 c_byte(const Fr &a, unsigned shift) {
+  zk::u32 w = 0;
+  for (unsigned i = 0; i < 8; ++i)
+    if (i == (shift >> 5)) w = a.l[i];
+  return (w >> (shift & 31)) & 0xffu;
+}
 // low `bits` bits of a (bits multiple of 8, < 256)
 ZK_HD Fr c_low(const Fr &a, unsigned bits) {
   Fr t = Fr::zero();

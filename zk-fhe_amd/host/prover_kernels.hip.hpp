@@ -296,13 +296,15 @@ static __global__ void __launch_bounds__(1024) k_chunk_carry(Fr *__restrict__ to
   }
   Fr vals[4];
   Fr local = Fr::one();
-  for (unsigned k = 0; k < per; ++k) {
-    vals[k] = lo + k < count ? total[lo + k] : Fr::one();
+#pragma unroll
+  for (unsigned k = 0; k < 4; ++k) {   // per <= 4; unrolled so that vals stays in registers
+    vals[k] = k < per && lo + k < count ? total[lo + k] : Fr::one();
     local = local * vals[k];
   }
   sh[t] = local;
   __syncthreads();
-  for (unsigned d = 1; d < 1024; d <<= 1) {
+  const unsigned active = (count + per - 1) / per;   // threads that hold totals: the scan stops once it spans them (66 chunks: 7 steps, not 10)
+  for (unsigned d = 1; d < active; d <<= 1) {
     const Fr v = sh[t];
     const Fr other = t >= d ? sh[t - d] : Fr::one();
     __syncthreads();
@@ -310,11 +312,12 @@ static __global__ void __launch_bounds__(1024) k_chunk_carry(Fr *__restrict__ to
     __syncthreads();
   }
   Fr acc = t ? sh[t - 1] : Fr::one();
-  for (unsigned k = 0; k < per; ++k) {
-    if (lo + k < count) total[lo + k] = acc;
+#pragma unroll
+  for (unsigned k = 0; k < 4; ++k) {
+    if (k < per && lo + k < count) total[lo + k] = acc;
     acc = acc * vals[k];
   }
-  if (t == 1023) *closes = (sh[1023] == Fr::one()) ? 1 : 0;
+  if (active == 0 ? t == 0 : t == active - 1) *closes = (active == 0 || sh[t] == Fr::one()) ? 1 : 0;   // the threads past it hold ones: sh[active - 1] is the product of all
 }
 // z[col][0..u] *= carry[col]
 static __global__ void __launch_bounds__(256) k_scale_rows(Fr *__restrict__ z, const Fr *__restrict__ carry, size_t n, unsigned rows, unsigned n_cols) {
@@ -476,11 +479,17 @@ static __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = Fr::zero();
   const size_t lo = (n / gridDim.y) * blockIdx.y, hi = blockIdx.y + 1 == gridDim.y ? n : lo + n / gridDim.y;
+  // r < n_rot is tested inside fully unrolled loops: with a loop bound read from the job the four accumulators were indexed
+  // dynamically and lived in scratch memory (144 bytes per lane; 5.4 ms of a k = 19 proof)
   for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
     const Fr v = job.col[i];
-    for (int r = 0; r < job.n_rot; ++r) acc[r] = acc[r] + v * bw[(size_t)job.rot[r] * n + i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < job.n_rot) acc[r] = acc[r] + v * bw[(size_t)job.rot[r] * n + i];
   }
-  for (int r = 0; r < job.n_rot; ++r) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r >= job.n_rot) break;
     sh[threadIdx.x] = acc[r];
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
