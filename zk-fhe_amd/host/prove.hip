@@ -628,9 +628,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   // see "Early phase-1 commitment" below.  On with the Poseidon transcript, whose challenge after the phase-0 commitment is
   // 2561 sequential permutations (the public inputs, ~20 ms of host time) away: measured on a wave of 20 concurrent proofs
   // +9 % (the GPU commits while every proof hashes), -1.5 % in steady state (two extra small commitments per proof).  With
-  // Blake2b there is nothing to hide.  ZKFHE_EARLY_P1=0 / 1 overrides.
+  // Blake2b there is no hash to hide -- but on long rows (k >= 18) the RLC witness the host computes from that challenge is
+  // (k = 19: 6 ms of Horner chains and placement with the GPU idle): 155.8 -> 151.5 ms per proof; at k = 16 it costs 0.7 ms.
+  // ZKFHE_EARLY_P1=0 / 1 overrides.
   const char *early_env = getenv("ZKFHE_EARLY_P1");
-  const bool early_want = early_env ? early_env[0] == '1' : cfg.transcript == TR_POSEIDON;
+  const bool early_want = early_env ? early_env[0] == '1' : (cfg.transcript == TR_POSEIDON || k >= 18);
   const bool early_p1 = early_want && !host_witness && cfg.n_lookup > 0 && cfg.lookup_bits == 8;
   GpuPhase1 g1(ctx, pk, ws);
   const zkfhe_basis *p0_basis = small_basis;
