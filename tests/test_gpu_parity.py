@@ -378,16 +378,18 @@ def test_msm_point_range_sharding(ctx):
     full.destroy()
 
 
-def test_lookup_permute_matches_halo2_semantics(ctx):
-    """SURVEY.md 8a row P4 in isolation: k_lookup_permute against the oracle's restatement of halo2's
+@pytest.mark.parametrize("k", [13, 16])
+def test_lookup_permute_matches_halo2_semantics(ctx, k):
+    """SURVEY.md 8a row P4 in isolation: k_lookup_permute (k = 16: the row-sliced k_lookup_count / k_lookup_fill of long columns)
+    against the oracle's restatement of halo2's
     permute_expression_pair (oracle/halo2_ref.py permute_lookup) -- sorted inputs, table aligned at every first occurrence,
     leftover table values in ascending order -- on uniform, constant, two-valued and saturated columns; an input above 255
     raises the flag."""
     import ctypes
     from oracle import halo2_ref as H
     rng = np.random.default_rng(4)
-    n, u = 8192, 8192 - 107
-    cfg = H.Config(13, 1, 1, 1, 1, 109)
+    n, u = 1 << k, (1 << k) - 107
+    cfg = H.Config(k, 1, 1, 1, 1, 109)
     assert cfg.u == u
     table = list(range(256)) + [0] * (n - 256)
     cols = [[int(v) for v in rng.integers(0, 256, u)],

@@ -396,4 +396,98 @@ static __global__ void __launch_bounds__(1024) k_lookup_permute(const Fr *__rest
   }
 }
 
+// The same for long columns (n > 2^15: one workgroup per column walks 2^19 rows twice -- 2 ms of a k = 19 proof on 17 of the 256
+// CUs): gridDim.y row slices count into a global histogram, a second launch rebuilds the run tables from it and fills its slice.
+static __global__ void __launch_bounds__(1024) k_lookup_count(const Fr *__restrict__ in, size_t n, unsigned u, unsigned *__restrict__ gcnt /* [cols][256], zero */,
+                                                      int *__restrict__ err) {
+  __shared__ unsigned cnt[256];
+  const Fr *col = in + (size_t)blockIdx.x * n;
+  const unsigned t = threadIdx.x;
+  if (t < 256) cnt[t] = 0;
+  __syncthreads();
+  const unsigned per = (u + gridDim.y - 1) / gridDim.y, lo = per * blockIdx.y, hi = min(u, lo + per);
+  for (unsigned i = lo + t; i < hi; i += blockDim.x) {
+    const Fr v = zk::fp_from_mont<FrP>(col[i]);
+    if (v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7] || v.l[0] > 255u) {
+      *(volatile int *)err = 1;
+      continue;
+    }
+    atomicAdd(&cnt[v.l[0]], 1u);
+  }
+  __syncthreads();
+  if (t < 256 && cnt[t]) atomicAdd(&gcnt[blockIdx.x * 256 + t], cnt[t]);
+}
+static __global__ void __launch_bounds__(1024) k_lookup_fill(const unsigned *__restrict__ gcnt, size_t n, unsigned u, Fr *__restrict__ out_a, Fr *__restrict__ out_s) {
+  __shared__ unsigned cnt[256], start[257], hole0[257], left0[257];
+  __shared__ Fr mont[256];
+  Fr *oa = out_a + (size_t)blockIdx.x * n, *os = out_s + (size_t)blockIdx.x * n;
+  const unsigned t = threadIdx.x;
+  if (t < 256) {
+    cnt[t] = gcnt[blockIdx.x * 256 + t];
+    mont[t] = zk::fp_to_mont<FrP>(c_u64(t));
+  }
+  __syncthreads();
+  if (t == 0) {   // as in k_lookup_permute
+    unsigned s = 0, h = 0, l = 0;
+    for (unsigned v = 0; v < 256; ++v) {
+      start[v] = s;
+      hole0[v] = h;
+      left0[v] = l;
+      s += cnt[v];
+      h += cnt[v] ? cnt[v] - 1 : 0;
+      const unsigned in_table = v == 0 ? u - 255u : 1u;
+      l += in_table - (cnt[v] ? 1u : 0u);
+    }
+    start[256] = s;
+    hole0[256] = h;
+    left0[256] = l;
+  }
+  __syncthreads();
+  const unsigned per = (u + gridDim.y - 1) / gridDim.y, lo_r = per * blockIdx.y, hi_r = min(u, lo_r + per);
+  for (unsigned i = lo_r + t; i < hi_r; i += blockDim.x) {
+    if (i >= start[256]) continue;
+    unsigned lo = 0, hi = 256;
+    while (hi - lo > 1) {
+      const unsigned mid = (lo + hi) / 2;
+      if (start[mid] <= i) lo = mid; else hi = mid;
+    }
+    while (cnt[lo] == 0) --lo;
+    const unsigned v = lo, k = i - start[v];
+    oa[i] = mont[v];
+    if (k == 0) {
+      os[i] = mont[v];
+    } else {
+      const unsigned j = hole0[v] + k - 1;
+      unsigned a = 0, b = 256;
+      while (b - a > 1) {
+        const unsigned mid = (a + b) / 2;
+        if (left0[mid] <= j) a = mid; else b = mid;
+      }
+      os[i] = mont[a];
+    }
+  }
+}
+// the launch: one workgroup per column up to n = 2^15, row slices of 2^14 beyond
+static inline int lookup_permute(zkfhe_ctx *ctx, const Fr *in, size_t n, unsigned u, unsigned n_cols, Fr *out_a, Fr *out_s, int *err,
+                                 unsigned *hist = nullptr /* n_cols * 256 words of the caller's, or scratch slot 3 */) {
+  if (!n_cols) return ZKFHE_OK;
+  if (n <= 32768) {
+    k_lookup_permute<<<n_cols, 1024, 0, ctx->stream>>>(in, n, u, out_a, out_s, err);
+    ZK_LAUNCH_CHECK(ctx);
+    return ZKFHE_OK;
+  }
+  void *p = hist;
+  if (!p) {
+    const int rc = zk_scratch(ctx, 3, (size_t)n_cols * 256 * sizeof(unsigned), &p);
+    if (rc) return rc;
+  }
+  ZK_HIP(ctx, hipMemsetAsync(p, 0, (size_t)n_cols * 256 * sizeof(unsigned), ctx->stream));
+  const dim3 grid(n_cols, (unsigned)(n >> 14));
+  k_lookup_count<<<grid, 1024, 0, ctx->stream>>>(in, n, u, (unsigned *)p, err);
+  ZK_LAUNCH_CHECK(ctx);
+  k_lookup_fill<<<grid, 1024, 0, ctx->stream>>>((const unsigned *)p, n, u, out_a, out_s);
+  ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
 }  // namespace zkw

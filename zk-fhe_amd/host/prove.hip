@@ -656,8 +656,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       ZK_HIP(ctx, hipMemsetAsync(ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, 0, (size_t)cfg.n_rlc * n * 32, ctx->stream));
       int *err_dev = ws->host_early_err;   // pinned: written by the kernel, read by the host after ev_early
       *err_dev = 0;
-      zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), err_dev);
-      ZK_LAUNCH_CHECK(ctx);
+      CK(zkw::lookup_permute(ctx, ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, cfg.n_lookup, ws->la_l.fr(), ws->ls_l.fr(), err_dev));
       CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl0, ws->la_l.fr() + u, nbl0, n, cfg.n_lookup));
       CK(rng_fill(ctx->stream, ctr_lk + nbl0, 2 * nbl0, ws->ls_l.fr() + u, nbl0, n, cfg.n_lookup));
       CK(srs_msm(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, ws->host_early));
@@ -757,8 +756,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     if (cfg.lookup_bits != 8) return zk_fail_msg(ctx, ZKFHE_EINVAL, "the device lookup permutation is built for lookup_bits = 8");
     lookup_err = ws->out_flags() + 2;   // pinned
     *lookup_err = 0;
-    zkw::k_lookup_permute<<<cfg.n_lookup, 1024, 0, ctx->stream>>>(ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, ws->la_l.fr(), ws->ls_l.fr(), lookup_err);
-    ZK_LAUNCH_CHECK(ctx);
+    CK(zkw::lookup_permute(ctx, ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, cfg.n_lookup, ws->la_l.fr(), ws->ls_l.fr(), lookup_err));
     // blinding rows: la_i then ls_i, lookup by lookup -- two interleaved runs of the stream
     CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl, ws->la_l.fr() + u, nbl, n, cfg.n_lookup));
     CK(rng_fill(ctx->stream, ctr_lk + nbl, 2 * nbl, ws->ls_l.fr() + u, nbl, n, cfg.n_lookup));
@@ -1097,7 +1095,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   Fr *pts_dev = nullptr;
   {
     // H(X) = h0 + x^n h1 + x^2n h2, and the random polynomial, in Lagrange form
-    const Fr sc[3] = {Fr::one(), xn, xn * xn};
+    const Fr sc[3] = {zk::zk_fr_to_29(Fr::one()), zk::zk_fr_to_29(xn), zk::zk_fr_to_29(xn * xn)};   // k_lincomb_ptrs takes its scalars in the 2^261 form
     const Fr *ptrs[3] = {ws->h_c.fr(), ws->h_c.fr() + n, ws->h_c.fr() + 2 * n};
     STAGE(ptrs_dev, const Fr *, ws, ptrs, sizeof(ptrs));
     STAGE(sc_dev, Fr, ws, sc, sizeof(sc));
@@ -1114,7 +1112,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     zkp::k_bary_den<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, pts_dev, 6, n, bw);
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_fr_batch_invert(ctx, (zkfhe_fr *)bw, 6 * n));
-    const Fr c = (xn - Fr::one()) * dom->n_inv;
+    const Fr c = zk::zk_fr_to_29((xn - Fr::one()) * dom->n_inv);   // the weights in the 2^261 form: the constant operand of k_eval_jobs' nine-limb products
     zkp::k_bary_weights<<<grid_for(ctx, 6 * n), 256, 0, ctx->stream>>>(dom->fwd, c, 6 * n, n, bw);
     ZK_LAUNCH_CHECK(ctx);
   }
@@ -1221,7 +1219,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       std::vector<Fr> comb(np, Fr::zero());
       for (size_t m = 0; m < mem.size(); ++m) {
         ptrs[m] = items[mem[m]].lagr;
-        pw[m] = cur;
+        pw[m] = zk::zk_fr_to_29(cur);   // 2^261 form: the constant operand of k_lincomb_ptrs
         for (size_t t = 0; t < np; ++t) comb[t] = comb[t] + cur * mont(items[mem[m]].ev[layout.eval_slot(mem[m], sets[j].rots[t])]);
         cur = cur * yq;
       }
@@ -1388,11 +1386,10 @@ int zkfhe_prover_gate(int n) { return HeavyGate::get().set(n); }
 int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols, size_t n, uint32_t usable_rows, zkfhe_fr *a_dev, zkfhe_fr *s_dev, int *not_in_table) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, cols_dev && a_dev && s_dev && not_in_table && n_cols > 0 && n_cols < 65536 && usable_rows <= n && usable_rows >= 256);
-  void *flag;
-  CK(zk_scratch(ctx, 3, 64, &flag));
+  void *flag;   // the flag, then the histogram of the sliced kernels (long columns)
+  CK(zk_scratch(ctx, 3, 64 + n_cols * 256 * sizeof(unsigned), &flag));
   ZK_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-  zkw::k_lookup_permute<<<(unsigned)n_cols, 1024, 0, ctx->stream>>>((const Fr *)cols_dev, n, usable_rows, (Fr *)a_dev, (Fr *)s_dev, (int *)flag);
-  ZK_LAUNCH_CHECK(ctx);
+  CK(zkw::lookup_permute(ctx, (const Fr *)cols_dev, n, usable_rows, (unsigned)n_cols, (Fr *)a_dev, (Fr *)s_dev, (int *)flag, (unsigned *)((char *)flag + 64)));
   return zkfhe_download(ctx, not_in_table, flag, 4);
 }
 

@@ -4,6 +4,7 @@
 // omega is an index shift inside a row and X^n - 1 is constant per row.
 #pragma once
 #include "../csrc/ctx.hpp"
+#include "../csrc/fr29.hip.hpp"
 
 namespace zkp {
 
@@ -472,25 +473,40 @@ struct EvalJob {
   int rot[4];  // indices into the weight table
 };
 // gridDim.y row slices (long columns): slice y sums rows [y n / Y, (y + 1) n / Y) into out[(y * jobs + job) * 4 + r]
-static __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ jobs, const Fr *__restrict__ bw, size_t n, Fr *__restrict__ out) {
+static __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restrict__ jobs, const Fr *__restrict__ bw /* 2^261 form: k_bary_weights with c * 32 */,
+                                                          size_t n, Fr *__restrict__ out) {
   __shared__ Fr sh[256];
   const EvalJob job = jobs[blockIdx.x];
-  Fr acc[4];
+  // Nine-limb products (csrc/fr29.hip.hpp): the weights are the constant operand, stored in the 2^261 form, and two rows share one
+  // Montgomery reduction (fr29_mul2); the accumulators stay below 2 r in limb form.  r < n_rot is tested inside fully unrolled
+  // loops: with a loop bound read from the job the four accumulators were indexed dynamically and lived in scratch memory (144
+  // bytes per lane; 5.4 ms of a k = 19 proof, 3.8 ms without the scratch, with the 8 x 32-bit product).
+  zk::F29 acc[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = Fr::zero();
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int l = 0; l < 9; ++l) acc[r].l[l] = 0;
   const size_t lo = (n / gridDim.y) * blockIdx.y, hi = blockIdx.y + 1 == gridDim.y ? n : lo + n / gridDim.y;
-  // r < n_rot is tested inside fully unrolled loops: with a loop bound read from the job the four accumulators were indexed
-  // dynamically and lived in scratch memory (144 bytes per lane; 5.4 ms of a k = 19 proof)
-  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const Fr v = job.col[i];
+  size_t i = lo + threadIdx.x;
+  for (; i + 256 < hi; i += 512) {
+    const zk::F29 v0 = zk::fr29_unpack(job.col[i]), v1 = zk::fr29_unpack(job.col[i + 256]);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (r < job.n_rot) acc[r] = acc[r] + v * bw[(size_t)job.rot[r] * n + i];
+      if (r < job.n_rot) {
+        const Fr *w = bw + (size_t)job.rot[r] * n + i;
+        acc[r] = zk::fr29_weak_reduce(zk::f29_add(acc[r], zk::fr29_mul2(v0, zk::fr29_unpack(w[0]), v1, zk::fr29_unpack(w[256]))));
+      }
+  }
+  if (i < hi) {
+    const zk::F29 v0 = zk::fr29_unpack(job.col[i]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < job.n_rot) acc[r] = zk::fr29_weak_reduce(zk::f29_add(acc[r], zk::fr29_mul(v0, zk::fr29_unpack(bw[(size_t)job.rot[r] * n + i]))));
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (r >= job.n_rot) break;
-    sh[threadIdx.x] = acc[r];
+    sh[threadIdx.x] = zk::fr29_pack(zk::fr29_canonical(acc[r]));
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
       if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
@@ -502,25 +518,30 @@ static __global__ void __launch_bounds__(256) k_eval_jobs(const EvalJob *__restr
 }
 
 // ------------------------------------------------------------------------------------------- SHPLONK
-// out[i] = sum_m s[m] * ptr[m][i]
-static __global__ void __launch_bounds__(256) k_lincomb_ptrs(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, size_t n,
+// out[i] = sum_m s[m] * ptr[m][i].  The scalars are constants of the call, uploaded in the 2^261 form (zk_fr_to_29): nine-limb
+// products, two columns per Montgomery reduction (fr29_mul2), the sum kept below 2 r in limb form (csrc/fr29.hip.hpp) -- these
+// sums were 6 % of the summed kernel time of the k = 13 wave with the 8 x 32-bit product and an addition mod r per term.
+static __device__ __forceinline__ Fr lincomb29(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s29, unsigned k0, unsigned k1, size_t i) {
+  zk::F29 acc;
+#pragma unroll
+  for (int l = 0; l < 9; ++l) acc.l[l] = 0;
+  unsigned k = k0;
+  for (; k + 1 < k1; k += 2)
+    acc = zk::fr29_weak_reduce(zk::f29_add(acc, zk::fr29_mul2(zk::fr29_unpack(ptrs[k][i]), zk::fr29_unpack(s29[k]), zk::fr29_unpack(ptrs[k + 1][i]), zk::fr29_unpack(s29[k + 1]))));
+  if (k < k1) acc = zk::fr29_weak_reduce(zk::f29_add(acc, zk::fr29_mul(zk::fr29_unpack(ptrs[k][i]), zk::fr29_unpack(s29[k]))));
+  return zk::fr29_pack(zk::fr29_canonical(acc));
+}
+static __global__ void __launch_bounds__(256) k_lincomb_ptrs(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s29, unsigned m, size_t n,
                                                       Fr *__restrict__ out) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Fr acc = Fr::zero();
-    for (unsigned k = 0; k < m; ++k) acc = acc + s[k] * ptrs[k][i];
-    out[i] = acc;
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = lincomb29(ptrs, s29, 0, m, i);
 }
 // the same sum split over blockIdx.y chunks of `per` pointers: partial[chunk][i]; k_sum_rows adds the chunks up.  One thread
 // looping over ~600 columns is a 0.7 ms dependent chain; 13 chunks of 48 run side by side.
-static __global__ void __launch_bounds__(256) k_lincomb_ptrs_chunked(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s, unsigned m, unsigned per, size_t n,
+static __global__ void __launch_bounds__(256) k_lincomb_ptrs_chunked(const Fr *const *__restrict__ ptrs, const Fr *__restrict__ s29, unsigned m, unsigned per, size_t n,
                                                               Fr *__restrict__ partial) {
   const unsigned k0 = blockIdx.y * per, k1 = min(k0 + per, m);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Fr acc = Fr::zero();
-    for (unsigned k = k0; k < k1; ++k) acc = acc + s[k] * ptrs[k][i];
-    partial[(size_t)blockIdx.y * n + i] = acc;
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    partial[(size_t)blockIdx.y * n + i] = lincomb29(ptrs, s29, k0, k1, i);
 }
 static __global__ void __launch_bounds__(256) k_sum_rows(const Fr *__restrict__ partial, unsigned rows, size_t n, Fr *__restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
