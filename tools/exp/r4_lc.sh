@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/r4lc
+OUT=$REPO/gpurun_out/r4lc2
 mkdir -p $OUT
 cd $REPO
 timeout 900 python -m pytest tests/test_gpu_prover.py -m gpu -x -q > $OUT/tests.log 2>&1

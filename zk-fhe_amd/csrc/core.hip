@@ -6,6 +6,7 @@
 
 #include "ctx.hpp"
 #include "fq29.hip.hpp"
+#include "fr29.hip.hpp"
 
 using namespace zk;
 
@@ -289,7 +290,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_fr_unop(const Fr *__restrict__ a, Fr s, Fr *__restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr x = a[i];
-    out[i] = MODE == 0 ? x * s : MODE == 1 ? fp_to_mont<FrP>(x) : fp_from_mont<FrP>(x);
+    out[i] = MODE == 0 ? x * s : MODE == 1 ? fr29_to_mont(x) : fp_from_mont<FrP>(x);
   }
 }
 

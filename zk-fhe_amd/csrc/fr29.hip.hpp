@@ -68,4 +68,15 @@ ZK_HD Fr fr29_mul_const(const Fr &x, const Fr &w29) {
   return r;
 }
 
+// canonical integer -> standard form (x 2^256) through the nine-limb product: the constant operand is 2^517 mod r.  A dependent
+// chain of these issues three times as fast as the 8 x 32-bit fp_to_mont (0.37 against 1.2 us per product in a lone wave): the
+// witness gadgets store ~100 cells per thread one after the other.
+ZK_HD Fr fr29_to_mont(const Fr &x) {
+  const u32 c[8] = {0xd42db4dfu, 0x333ad321u, 0xf1d1cbd2u, 0x57936df3u, 0xf5eeb84du, 0xd0e021f3u, 0x0896f487u, 0x1275c7bdu};
+  Fr w;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w.l[i] = c[i];
+  return fr29_mul_const(x, w);
+}
+
 }  // namespace zk

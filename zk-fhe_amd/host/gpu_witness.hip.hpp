@@ -11,6 +11,7 @@
 // stored.  The deferred 1/x cells of is_zero are written as denominators and inverted afterwards in one batch.
 #pragma once
 #include "../csrc/ctx.hpp"
+#include "../csrc/fr29.hip.hpp"
 
 namespace zkw {
 
@@ -20,7 +21,7 @@ typedef unsigned long long u64;
 
 struct DevWriter {
   Fr *o;
-  __device__ __forceinline__ void put(const Fr &canon) { *o++ = zk::fp_to_mont<FrP>(canon); }
+  __device__ __forceinline__ void put(const Fr &canon) { *o++ = zk::fr29_to_mont(canon); }
 };
 struct CountWriter {
   size_t n = 0;

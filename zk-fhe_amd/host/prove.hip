@@ -977,14 +977,14 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     const size_t E = e, G = groups.size();
     if (G > 96) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
     std::vector<Fr> ypow(G);
-    for (size_t g = 0; g < G; ++g) ypow[g] = fr_pow(y, E - 1 - last_e[g]);
+    for (size_t g = 0; g < G; ++g) ypow[g] = zk::zk_fr_to_29(fr_pow(y, E - 1 - last_e[g]));   // 2^261 form: constant operands of k_quotient_combine
     STAGE(groups_dev, zkp::QGroup, ws, groups.data(), G * sizeof(zkp::QGroup));
     STAGE(ypow_dev, Fr, ws, ypow.data(), G * 32);
     const Fr wext = zk_fr_root_of_unity((int)k + 2);
     const Fr gn = fr_pow(mont_u64(COSET_G), n), i4 = fr_pow(wext, n);
     Fr zinv[4], cur = gn;
     for (int t = 0; t < 4; ++t) {
-      zinv[t] = fr_inv(cur - Fr::one());
+      zinv[t] = zk::zk_fr_to_29(fr_inv(cur - Fr::one()));
       cur = cur * i4;
     }
     STAGE(zinv_dev, Fr, ws, zinv, 4 * 32);

@@ -432,9 +432,16 @@ static __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__res
   const size_t n = (size_t)1 << log_n, ne = n * rows;
   const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (p >= ne) return;
-  Fr acc = Fr::zero();
-  for (unsigned g = 0; g < n_groups; ++g) acc = acc + ypow[g] * partials[(size_t)g * ne + p];
-  h_ext[p] = acc * zinv[p >> log_n];
+  // ypow and zinv come in the 2^261 form (constants of the call): nine-limb products, two groups per reduction, a lazy sum
+  zk::F29 acc;
+#pragma unroll
+  for (int l = 0; l < 9; ++l) acc.l[l] = 0;
+  unsigned g = 0;
+  for (; g + 1 < n_groups; g += 2)
+    acc = zk::fr29_weak_reduce(zk::f29_add(acc, zk::fr29_mul2(zk::fr29_unpack(partials[(size_t)g * ne + p]), zk::fr29_unpack(ypow[g]),
+                                                             zk::fr29_unpack(partials[(size_t)(g + 1) * ne + p]), zk::fr29_unpack(ypow[g + 1]))));
+  if (g < n_groups) acc = zk::fr29_weak_reduce(zk::f29_add(acc, zk::fr29_mul(zk::fr29_unpack(partials[(size_t)g * ne + p]), zk::fr29_unpack(ypow[g]))));
+  h_ext[p] = zk::fr29_pack(zk::fr29_canonical(zk::fr29_mul(acc, zk::fr29_unpack(zinv[p >> log_n]))));
 }
 
 // Quotient from three cosets.  rows3[k1][i] = i-th coefficient (already scaled by 1/n) of h restricted to the coset
