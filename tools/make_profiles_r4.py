@@ -259,6 +259,11 @@ for cfg, stats_f, bench_f, pre, n in (('k13', 'b_single_last_proof.txt', 'bench_
                                      "32 B x 3 n points x (advice + fixed + sigma + products + lookup polynomials + l_0 / l_last / l_active / X + 1 output)"),
         'k_fr_batch_invert': (64.0 * n * (cc['chunks'] + cc['lookup'] + 6 + 8 + 1), "64 B per element: grand-product denominators, barycentric weights, SHPLONK denominators"),
         'k_msm_scatter': ((32.0 + 4.0 * 16) * n * (wide + small), "(32 B scalar + 4 B x ~16 entries) per scalar"),
+        'k_msm_cscatter': ((32.0 + 4.0 * 16) * n * (wide + small), "(32 B scalar + 4 B x ~16 staged entries) per scalar"),
+        'k_msm_fine': ((3 * 4.0 * 16) * n * (wide + small), "4 B x ~16 entries per scalar: two reads of the staged segment, one write of the sorted entries"),
+        'k_dif_lds<3>': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform, six stages in one pass (+ 32 n of coset factors on the forward rows)"),
+        'k_dif_lds<2>': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform, five stages in one pass"),
+        'k_dif_lds<1>': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform, four stages in one pass"),
         'k_msm_table_fold': (None, "latency-bound: sums the partial lists (128 B per partial), one workgroup per column"),
         'zkp::k_prefix_product': (64.0 * n * (cc['chunks'] + cc['lookup']), "64 B per element of the grand products"),
     }
