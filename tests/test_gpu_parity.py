@@ -313,6 +313,22 @@ def test_msm_two_level_sort_geometries(ctx, monkeypatch, c, sort):
     B.destroy()
 
 
+def test_msm_two_level_sort_odd_length(ctx):
+    """n = 1001 points, 15-bit windows: 17 017 entries per column -- not a multiple of four, and k_msm_fine reads the staged
+    entries in 16-byte loads (the staging stride is rounded up)."""
+    import zk_fhe_amd as zk
+    rng = np.random.default_rng(77)
+    n = 1001
+    bases = _bases(n, seed=5)
+    S = rand_fr(rng, 5 * n).reshape(5, n, 4)
+    S[1] = orc.ints_to_mont([int(rng.integers(0, 256)) for _ in range(n)])
+    S[4] = orc.ints_to_mont([3] * n)
+    B = zk.Basis(ctx, bases, 15)
+    assert not B.has_table
+    assert np.array_equal(ctx.msm(B, S), orc.msm(S, bases))
+    B.destroy()
+
+
 def test_msm_k13_batch_linearity(ctx):
     """BASELINE size: 64 columns x 8192 with the witness scalar mix; oracle on a sample + additivity."""
     import zk_fhe_amd as zk

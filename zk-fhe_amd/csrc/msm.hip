@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64) k_msm_cscan(const unsigned *__restrict__ c
 }
 
 __global__ void __launch_bounds__(CS_THREADS) k_msm_cscatter(const Fr *__restrict__ scalars, size_t col_stride, size_t n, unsigned chunks_per_col, int c, int windows,
-                                                            int L, unsigned NB, unsigned *__restrict__ ccursor, unsigned *__restrict__ stage, size_t col_entries) {
+                                                            int L, unsigned NB, unsigned *__restrict__ ccursor, unsigned *__restrict__ stage, size_t stage_stride /* col_entries rounded up to four */) {
   extern __shared__ unsigned sh[];
   unsigned *cnt = sh, *loff = sh + NB, *gb = sh + 2 * NB, *buf = sh + 3 * NB;   // buf: CS_SCALARS * windows words
   const size_t col = blockIdx.x / chunks_per_col;
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(CS_THREADS) k_msm_cscatter(const Fr *__restric
       buf[pos] = ((unsigned)w * (unsigned)n + (unsigned)i) | ((key & fmask) << fsh) | (neg ? 0x80000000u : 0u);
     });
   __syncthreads();
-  unsigned *dst_col = stage + col * col_entries;
+  unsigned *dst_col = stage + col * stage_stride;
   const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (unsigned g = wv; g < NB; g += CS_THREADS / 64) {
     const unsigned base = loff[g], len = cnt[g] - base;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void fine_scan_inplace(unsigned *ctr, unsigned *wsum 
 // Witness columns and narrow top windows pile thousands of entries onto a few buckets, and LDS atomics on one address serialise
 // (~10 cycles per lane, measured): every bucket has FINE_COPIES counters, lane l uses copy l % FINE_COPIES -- sub-buckets that sort
 // next to each other, so the order inside a bucket changes and nothing else.
-__global__ void __launch_bounds__(FINE_THREADS, 4) k_msm_fine(const unsigned *__restrict__ coff, unsigned NB, int L, const unsigned *__restrict__ stage, size_t col_entries,
+__global__ void __launch_bounds__(FINE_THREADS, 4) k_msm_fine(const unsigned *__restrict__ coff, unsigned NB, int L, const unsigned *__restrict__ stage, size_t stage_stride, size_t col_entries,
                                                              unsigned K1, unsigned *__restrict__ off, unsigned *__restrict__ entries) {
   extern __shared__ unsigned buf[];   // FINE_TILE words
   __shared__ __attribute__((aligned(16))) unsigned ctr[FINE_CTRS + 4];
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(FINE_THREADS, 4) k_msm_fine(const unsigned *__
   const unsigned g = blockIdx.x % NB;
   const unsigned F = 1u << L;
   const unsigned lo = coff[col * (NB + 1) + g], hi = coff[col * (NB + 1) + g + 1];
-  const unsigned *src = stage + col * col_entries;   // 16-byte aligned: col_entries is a multiple of four
+  const unsigned *src = stage + col * stage_stride;   // 16-byte aligned: the staging stride is a multiple of four entries
   const int fsh = 31 - L;
   const unsigned fmask = F - 1;
   const unsigned t = threadIdx.x, lane = t & 63, copy = lane % FINE_COPIES;
@@ -1247,7 +1247,6 @@ static unsigned two_level_min_k() {
 }
 
 int default_window_bits(size_t n) {
-  if (const char *e = getenv("ZKFHE_WINDOW_BITS")) if (atoi(e) >= 8 && atoi(e) <= 16 && n >= 32768) return atoi(e);
   if (n <= 64) return 5;
   if (n <= 1024) return 8;
   if (n <= 4096) return 11;
@@ -1375,7 +1374,8 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
   const unsigned NB = two_level ? K >> L : 0;
   // the staging array of the two-level sort lives where the buckets and partials will be (dead before they are written)
   size_t s0 = (n_cols * (size_t)K + max_tasks) * sizeof(G1X);
-  if (two_level && s0 < n_cols * col_entries * sizeof(unsigned)) s0 = n_cols * col_entries * sizeof(unsigned);
+  const size_t stage_stride = (col_entries + 3) & ~(size_t)3;   // k_msm_fine reads the staged entries in 16-byte loads
+  if (two_level && s0 < n_cols * stage_stride * sizeof(unsigned)) s0 = n_cols * stage_stride * sizeof(unsigned);
   rc = zk_scratch(ctx, 0, s0, &p0);
   if (rc) return rc;
   unsigned *hist = (unsigned *)p1;
@@ -1410,14 +1410,14 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
       cs_attr = true;
     }
     k_msm_cscatter<<<(unsigned)(n_cols * cs_chunks), CS_THREADS, cs_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, cs_chunks, c, W, L, NB, ccursor, stage,
-                                                                                         col_entries);
+                                                                                         stage_stride);
     ZK_LAUNCH_CHECK(ctx);
     static bool fine_attr = false;
     if (!fine_attr) {
       ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_fine, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_TILE * sizeof(unsigned)));
       fine_attr = true;
     }
-    k_msm_fine<<<(unsigned)(n_cols * NB), FINE_THREADS, FINE_TILE * sizeof(unsigned), ctx->stream>>>(coff, NB, L, stage, col_entries, K1, off, entries);
+    k_msm_fine<<<(unsigned)(n_cols * NB), FINE_THREADS, FINE_TILE * sizeof(unsigned), ctx->stream>>>(coff, NB, L, stage, stage_stride, col_entries, K1, off, entries);
     ZK_LAUNCH_CHECK(ctx);
   } else {
     {
