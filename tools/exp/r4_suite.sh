@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/r4suite2
+OUT=$REPO/gpurun_out/r4suite3
 mkdir -p $OUT
 cd $REPO
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1
