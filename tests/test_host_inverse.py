@@ -49,3 +49,17 @@ def test_lazy_signed_limb_arithmetic(tmp_path):
                     "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "native", "lz29_check.hip"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "lz29: 0 bad" in out, out
+
+
+def test_fr_nine_limb_sums_of_the_element_wise_kernels(tmp_path):
+    """csrc/fr29.hip.hpp as k_eval_jobs / k_lincomb_ptrs / k_quotient_combine and the witness cell writer use it (round 4):
+    fr29_to_mont against fp_to_mont, and lazy sums with 2^261-form constants, two terms per reduction, against the standard
+    8 x 32-bit arithmetic -- 1 to 97 terms, short, negative-short and full-width operands.  Host instantiation (no GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "fr29_sum_check")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "zk-fhe_amd", "csrc"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "native", "fr29_sum_check.hip"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "fr29 sums: 0 bad" in out, out
