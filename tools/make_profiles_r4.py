@@ -194,9 +194,11 @@ open(P + 'r4_wave_occupancy.md', 'w').write("""# r4 -- GPU occupancy over the dr
 `rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-seconds 0` (`tools/profile_r4b.sh`), `tools/busy_bins.py <db> 260 2`:
 per bin the fraction of time with at least one kernel running, the average number of kernels in flight and the kernel with the largest
 share.  The last ~60 ms of the trace are the two profiled proofs that follow the timed region (one in flight); the wave is the ~100 ms
-block before them: a head of ~14 ms in which the proofs' early work (phase-0 commitment, gadgets, early phase-1 commitment) shares the
-chip while every proof hashes its 5 121 public inputs, ~75 ms with 12-16 kernels in flight, and a tail of ~14 ms in which the last
-proofs run their serial end (evaluations, 758 Poseidon permutations on the host, two one-column commitments) with 1-3 kernels in flight.
+block before them: a head of 14-18 ms in which the proofs' early work (phase-0 commitment, gadgets, early phase-1 commitment) shares the
+chip while every proof hashes its 5 121 public inputs, 50-75 ms with 12-16 kernels in flight -- the proofs move through their rounds
+together, so this block is one phase after the other (the 2^13 tiles of all twenty proofs alone fill ~35 ms of it) -- and 14-25 ms in
+which the kernels in flight fall from ten to one: the proofs' serial ends (evaluations, 758 Poseidon permutations on the host, two
+one-column commitments).
 
 ```
 %s```
