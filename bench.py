@@ -18,6 +18,10 @@ import time
 # queues, and streams that share a queue run their kernels in order.  Must be set before the HIP runtime initialises
 # (i.e. before torch is imported).  Measured: 123 proofs/s with 4 queues, 145 with >= 12 (12 proofs in flight).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# The service profile of the digit-multiple tables: this process owns its GPU, so the SRS may take 189 GB of it (15-bit digits for
+# the Lagrange half at k = 13).  The library's own default is 48 GB and a quarter of the free memory (csrc/msm.hip table_bits;
+# profiles/r5_table_budget.md has the rate against the resident GB).  Several ranks on ONE device (the gloo tests) set their own.
+os.environ.setdefault("ZKFHE_TABLE_GB", "160")
 
 import numpy as np
 
@@ -37,30 +41,10 @@ CONFIGS = {"k13": dict(k=13, N=1024, Q=536870909), "k16": dict(k=16, N=4096, Q=(
 
 
 def synth_bfv_input(seed):
-    """A valid BFV encryption (c0 = pk0*u + floor(Q/T)*m + e0, c1 = pk1*u + e1 in Z_Q[x]/(x^N+1)), as the JSON text the
-    reference's CircuitInput (examples/bfv.rs:50-61) parses.  Formula checked against data/bfv/bfv.in (tests, KAT 1)."""
-    rng = np.random.default_rng(seed)
-    pk0 = rng.integers(0, Q, N, dtype=np.int64)
-    pk1 = rng.integers(0, Q, N, dtype=np.int64)
-    u = rng.choice(np.array([0, 1, Q - 1], dtype=np.int64), N)
-    m = rng.choice(np.array(list(range(0, T // 2 + 1)) + [Q - i for i in range(1, T // 2 + 1)], dtype=np.int64), N)
-    e = np.clip(np.rint(rng.normal(0, 3.2, (2, N))), -B, B).astype(np.int64) % Q
-
-    def negacyclic(a, b):  # big-endian coefficient order in, out; b taken as residues in [0, Q)
-        a, b = a[::-1], b[::-1]
-        out = np.zeros(N, dtype=np.int64)
-        for i in np.nonzero(b)[0]:
-            sh = np.empty(N, dtype=np.int64)
-            sh[i:] = a[: N - i]
-            sh[:i] = (Q - a[N - i:]) % Q
-            out = (out + (sh * int(b[i])) % Q) % Q
-        return out[::-1]
-    c0 = (negacyclic(pk0, u) + (Q // T) * m % Q + e[0]) % Q
-    c1 = (negacyclic(pk1, u) + e[1]) % Q
-    cyclo = np.zeros(N + 1, dtype=np.int64)
-    cyclo[0] = cyclo[N] = 1
-    s = lambda v: [str(int(x)) for x in v]  # noqa: E731
-    return json.dumps(dict(pk0=s(pk0), pk1=s(pk1), m=s(m), u=s(u), e0=s(e[0]), e1=s(e[1]), c0=s(c0), c1=s(c1), cyclo=s(cyclo)))
+    """A valid BFV encryption as the JSON text the reference's CircuitInput (examples/bfv.rs:50-61) parses: SURVEY.md 8(d) config 3's
+    seeded vector (zk_fhe_amd.inputs.config3_vector)."""
+    from zk_fhe_amd import inputs as gen
+    return gen.config3_vector(seed, N, Q, T, B)
 
 
 def main():
@@ -173,6 +157,7 @@ def main():
     gate_timed = int(os.environ["ZKFHE_GATE"]) if "ZKFHE_GATE" in os.environ else (4 if (not big and not sharded and args.steps > n_streams >= 8) else 0)
     zk.prover_gate(gate_timed)
     barrier()
+    pc0 = pk.prefix_cache()
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     batch.run_concurrent(list(range(si, si + args.steps)), ctxs, one_proof, stagger_s=(args.stagger_ms or 0.0) * 1e-3)   # exactly K proofs, n_streams in flight
@@ -181,6 +166,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     host_cpu_ms = (time.process_time() - cpu0) * 1e3 / max(1, args.steps)   # all threads of this rank
+    # the per-public-key transcript cache over the timed region (host/prefix_cache.hpp: the sponge state behind vk digest | pk0 | pk1,
+    # nothing beyond the public key): the bench cycles four inputs = four public keys, all remembered after the warm-up
+    pc1 = pk.prefix_cache()
+    host["prefix_cache_hits"] = pc1["hits"] - pc0["hits"]
+    host["prefix_cache_misses"] = pc1["misses"] - pc0["misses"]
+    host["prefix_cache_keys"] = pc1["entries"]
     # outside the clock: the LAST proof made inside the timed region goes through the host verifier (transcript replay, quotient
     # identity, SHPLONK, one pairing-product check -- zkfhe_bfv_verify); its public inputs are the ones the prover returned
     v_proof, v_inst = last[si + args.steps - 1]
@@ -211,6 +202,8 @@ def main():
     # table points of a commitment batch) when the SRS holds a digit-multiple table wide enough for such calls, else the
     # bucket pipeline's k_msm_accumulate
     table_bits, table_wide = srs.table_bits()
+    table_info = srs.table_info()   # digit widths (monomial, Lagrange), resident GB, whether the device forced a narrower table
+    table_info["budget_gb"] = float(os.environ["ZKFHE_TABLE_GB"])
     msm_kernel = "k_msm_table" if table_wide else "k_msm_accumulate"
     ctx.prof_enable(True)
     for _ in range(2):
@@ -220,12 +213,13 @@ def main():
     direct = ctx.prof_read(2)
     ctx.prof_enable(False)
 
-    traffic = ntt_traffic = None
-    for fn in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes (profiles/, rocprofv3 --pmc)
+    traffic = ntt_traffic = traffic_source = None
+    for fn in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes (profiles/, rocprofv3 --pmc)
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", fn)))
             traffic = pt["bytes_per_launch"] if (not big and table_wide) else None
             ntt_traffic = pt["ntt13"] if not big else None   # the same for the 2^13 NTT tile (second kernel of every configuration)
+            traffic_source = "profiles/%s (a committed rocprofv3 --pmc pass of this command, not measured in this run)" % fn
             break
         except Exception:  # noqa: BLE001
             continue
@@ -291,12 +285,14 @@ def main():
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 -- DIFFERENT HARDWARE and a LARGER constraint system "
                                            "(axiom-eth always configures a Keccak sub-circuit whose columns this prover does not have, DESIGN.md 6.1); "
                                            "a batch rate against a single-proof latency: not a like-for-like speed-up"},
-            "roofline": {"bound": "hbm", "kernel": msm_kernel, "table_digit_bits": table_bits, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
+            "roofline": {"bound": "hbm", "kernel": msm_kernel, "table_digit_bits": table_bits, "tables": table_info, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": msm["total_ms"] / max(1, msm["launches"]),
                          "launches_per_proof": msm["launches"] / 2,
                          # the bound that actually binds this kernel (SURVEY.md 8(d) "secondary, honest bound"): 256-bit modular
                          # multiplications, 10 per mixed XYZZ addition, against the multiply-add issue bound (MODMUL_PEAK_G above)
                          "int_alu": {"achieved": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9, "peak": MODMUL_PEAK_G,
+                                     "peak_kind": "multiply-add issue estimate from the builder's own probe (5.3 cycles per v_mad_u64_u32, 162 per product; "
+                                                  "a bare product loop measures 168 G/s, tools/exp/mad_rate.hip) -- NOT a published hardware bound",
                                      "unit": "G modmul/s", "frac": msm["ops"] * MODMUL_PER_MIXED_ADD / (msm["total_ms"] * 1e-3) / 1e9 / MODMUL_PEAK_G,
                                      "mixed_additions_per_proof": msm["ops"] / 2},
                          "msm_few_columns": {"avg_launch_ms": direct["total_ms"] / max(1, direct["launches"]), "launches_per_proof": direct["launches"] / 2},

@@ -48,6 +48,9 @@ typedef struct zkfhe_basis zkfhe_basis;
 typedef struct { uint64_t l[4]; } zkfhe_fr;
 typedef struct { uint64_t l[4]; } zkfhe_fq;
 typedef struct { zkfhe_fq x, y; } zkfhe_g1_affine;
+/* accumulator form of a G1 point (EFD "XYZZ"): x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; the identity has ZZ = ZZZ = 0.  128 bytes,
+ * raw Montgomery coordinates.  What an MSM holds before its one field inversion. */
+typedef struct { zkfhe_fq x, y, zz, zzz; } zkfhe_g1_xyzz;
 
 /* ---- context / memory -------------------------------------------------------------------- */
 /* hip_stream: an existing hipStream_t to run on, or NULL to let the context create its own. */
@@ -134,11 +137,26 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
 typedef struct { zkfhe_fr scalar; uint32_t row; uint32_t slot; } zkfhe_sparse_term;
 int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots,
                      zkfhe_g1_affine *out_dev);
+/* The same two calls with the sums left in the accumulator form: the call's last kernel skips its field inversion (a 40 us
+ * dependent chain in one lane at the end of every call) and the caller normalises many points with ONE inversion on the host --
+ * what halo2's create_proof does with a round's commitments (`commit_lagrange` returns projective points, the round is
+ * batch-normalised: SURVEY.md Appendix B step 2).  out_dev may be pinned host memory, like every *_dev output of this header.
+ * zkfhe_g1_xyzz_to_affine runs on the calling thread (no device work): Montgomery's trick over the ZZZ, one inversion for the
+ * array; in / out are host pointers and must not overlap. */
+int zkfhe_msm_batch_xyzz(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols,
+                         zkfhe_g1_xyzz *out_dev);
+int zkfhe_msm_sparse_xyzz(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots,
+                          zkfhe_g1_xyzz *out_dev);
+int zkfhe_g1_xyzz_to_affine(const zkfhe_g1_xyzz *in, size_t n, zkfhe_g1_affine *out);
 int zkfhe_basis_has_multiples(const zkfhe_basis *basis);
 /* Digit width of the basis' digit-multiple table (0: none).  *wide_calls (optional) = 1 when calls of many columns take the
  * table path too (k_msm_table), 0 when they take the bucket pipeline (k_msm_accumulate ...) and only calls of <= 8 columns
  * go through the table. */
 int zkfhe_basis_table_bits(const zkfhe_basis *basis, int *wide_calls);
+/* Resident bytes of that table; *narrowed (optional) = 1 when it is narrower than its budget allowed because the device did not
+ * have the room when the basis was made (ZKFHE_TABLE_GB: default 48 and at most a quarter of the free memory; a reserve of an
+ * eighth of the device, at least 24 GB, always stays free for keys and workspaces -- ZKFHE_TABLE_RESERVE_GB). */
+size_t zkfhe_basis_table_bytes(const zkfhe_basis *basis, int *narrowed);
 
 /* ---- intra-proof multi-GPU: commitments sharded by point range (replaces nothing in the reference,
  * whose prover is single-process -- the seam is again best_multiexp inside ParamsKZG::{commit, commit_lagrange}) ----------
@@ -318,6 +336,9 @@ int zkfhe_srs_create_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs);
 /* zkfhe_basis_table_bits of the Lagrange half of the SRS (the basis of the advice / permutation / lookup commitments). */
 int zkfhe_srs_table_bits(const zkfhe_srs *srs, int *wide_calls);
+/* bits[0] / bits[1]: digit width of the monomial / Lagrange half's table (0 = none); *bytes: resident bytes of both; *narrowed: a
+ * half is narrower than its budget allowed (no room on the device at creation: slower calls, same results).  Outputs optional. */
+int zkfhe_srs_table_info(const zkfhe_srs *srs, int bits[2], uint64_t *bytes, int *narrowed);
 
 /* keygen (README.md:28-38): circuit structure from the (empty) input, fixed + sigma polynomials, their
  * commitments, the vk digest; everything the prover needs stays resident in HBM. */
@@ -331,6 +352,13 @@ int zkfhe_bfv_pk_release_ctx(zkfhe_ctx *ctx, zkfhe_bfv_pk *pk);
 /* 32-byte LE vk digest; counts of fixed / sigma commitments; the commitments as canonical affine (x||y, 64 B each) */
 int zkfhe_bfv_pk_info(const zkfhe_bfv_pk *pk, uint8_t vk_digest[32], uint32_t *n_fixed, uint32_t *n_sigma);
 int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t *sigma_out);
+/* Per-public-key transcript cache.  The instance column starts with pk0 | pk1 (reference examples/bfv.rs:118-119), the same
+ * 2 N values for every encryption under one BFV public key; the prover keeps the Fiat-Shamir state after `vk digest | pk0 | pk1`
+ * for the last few public keys it has seen with this proving key and starts a proof whose pk0 | pk1 match from there (k = 13:
+ * 1 024 of the 2 561 sequential Poseidon permutations before the first challenge).  Same state, same bytes.  Nothing beyond the
+ * public key is cached.  capacity >= 0 sets how many keys are remembered (default 8, ZKFHE_PREFIX_CACHE; 0 = off; at most 64),
+ * negative only queries; hits / misses / entries are optional outputs. */
+int zkfhe_bfv_pk_prefix_cache(const zkfhe_bfv_pk *pk, int capacity, uint64_t *hits, uint64_t *misses, uint64_t *entries);
 int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count);
 
 /* Serialised verifying key: magic "ZKFHEVK2", 8 x u32 configuration (k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows,

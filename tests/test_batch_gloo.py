@@ -323,3 +323,74 @@ def test_proof_through_one_rank_rccl_communicator_matches_plain():
             assert out[0] == out[1], (which, transcript)
     comm.destroy()
     ctx.close()
+
+
+# ---- BASELINE configs[2]: a batch of 64 independent k = 13 proofs through batch.shard_indices / prove_batch / gather_proofs with
+# the REAL prover.  Eight gloo ranks sharing GPU 0 (the shape of the 8-GPU run: proof i -> rank i mod 8, no data-path collective,
+# the proofs gathered on every rank), and one rank with 16 streams.  The 64 inputs are SURVEY.md 8(d) config 3's: the
+# reference's bfv.in and 63 seeded vectors, every one under its own public key.
+def _batch64_worker(rank, world, port, n_streams, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("ZKFHE_TABLE_GB", "1" if world > 1 else "4")   # per SRS half and per rank: the ranks share this one GPU
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    from zk_fhe_amd import inputs as gen
+    text_kg, text, params, cfg, k = _circuit("bfv13")
+    inputs = gen.config3_batch(text, 64)
+    seeds = [b"batch64-%d" % i for i in range(64)]
+    ctxs = [zk.Context(0) for _ in range(n_streams)]
+    host = B.configure_host(zk, world)
+    srs = zk.Srs(ctxs[0], k)
+    pk = zk.BfvProvingKey(ctxs[0], srs, text_kg, params, cfg)
+    vk = pk.export_vk()
+    mine = B.shard_indices(64, rank, world)
+    got = B.prove_batch(pk, [inputs[i] for i in mine], [seeds[i] for i in mine], ctxs, with_instances=True)
+    verdicts = [zk.bfv_verify(vk, inst, proof) for proof, inst in got]            # every proof of this rank: zkfhe_bfv_verify (pairing check)
+    allp = B.gather_proofs({i: p for i, (p, _) in zip(mine, got)}, 64, rank, world)
+    res = {"rank": rank, "mine": mine, "verified": [v[0] for v in verdicts], "why": [v[1] for v in verdicts if not v[0]],
+           "inst_len": [len(inst) for _, inst in got], "host": host, "all": allp if rank == 0 else None, "n_all": len(allp),
+           "all_sha": hashlib.sha256(b"".join(allp)).hexdigest()}
+    out.put(res)
+    dist.barrier()
+    pk.destroy()
+    srs.destroy()
+    for c in ctxs:
+        c.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_batch_of_64_eight_ranks_equals_one_rank_and_cpu_prover():
+    """configs[2] on the hardware there is: 64 distinct encryptions, proof i -> rank i mod 8 over eight processes sharing GPU 0
+    (two streams each), against ONE process with 16 streams.  Every proof passes zkfhe_bfv_verify on the rank that made it; rank 0's
+    gathered list is complete and in input order, identical on all ranks, identical between the 8-rank and the 1-rank run; and
+    four sampled proofs (bfv.in's and three synthetic ones, from different ranks) equal the native CPU prover's bytes
+    (oracle/cpu_prover.cpp with the oracle's key and SRS)."""
+    from oracle import cpu_prover as CP
+    from oracle import halo2_ref as H
+    from tests.test_gpu_prover import oracle_k13
+    from zk_fhe_amd import inputs as gen
+    got8 = _run_ranks(_batch64_worker, 8, 2, timeout=1500)
+    got1 = _run_ranks(_batch64_worker, 1, 16, timeout=1500)
+    for got, world in ((got8, 8), (got1, 1)):
+        assert sorted(i for g in got for i in g["mine"]) == list(range(64))
+        for g in got:
+            assert g["mine"] == list(range(g["rank"], 64, world))
+            assert all(g["verified"]), g["why"][:2]
+            assert all(n == 5121 for n in g["inst_len"])                                   # pk0, pk1, c0, c1, cyclo (examples/bfv.rs:118-122)
+            assert g["n_all"] == 64 and g["all_sha"] == got[0]["all_sha"]                  # every rank holds the same gathered list
+    assert got8[0]["host"]["hash_mode"] == "shared" or got8[0]["host"]["cpus_per_rank"] >= B.CPUS_PER_GPU_FOR_LATENCY_MODE
+    all8, all1 = got8[0]["all"], got1[0]["all"]
+    assert all8 == all1                                                                     # same bytes whichever rank / stream made a proof
+    assert len(set(all8)) == 64                                                             # 64 different proofs
+    o = oracle_k13()
+    hcfg = H.Config.from_pinning(o["cfgj"])
+    cp = CP.CpuProver(hcfg, o["pk_o"], o["srs_o"], o["prm"])
+    inputs = gen.config3_batch(o["text"], 64)
+    for i in (0, 13, 38, 63):                                                               # ranks 0, 5, 6, 7 of the 8-rank run
+        assert cp.prove(inputs[i].decode(), b"batch64-%d" % i) == all8[i], "proof %d differs from the CPU prover's" % i
+    cp.close()
+

@@ -24,7 +24,7 @@ def _free_port():
 def test_bench_two_ranks_one_gpu_gloo():
     env = dict(os.environ)
     env["ZKFHE_BENCH_BACKEND"] = "gloo"
-    env["ZKFHE_TABLE_GB"] = "4"          # two SRS on one device: the suite's budget, not the 86 GB default
+    env["ZKFHE_TABLE_GB"] = "4"          # two SRS on one device: the suite's budget, not a service's table profile
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
@@ -62,3 +62,31 @@ def test_bench_one_proof_sharded_two_ranks_one_gpu_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "one-proof-sharded" and d["config"]["verified"] is True
     assert abs(d["value"] - 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6      # three proofs of the JOB over the wall time
     assert len(d["config"]["host_cpu_ms_per_proof_by_rank"]) == 2 and d["config"]["host"]["usable_cpus"] >= 1
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_one_gpu_gloo():
+    """The driver's N = 8 launch of bench.py (BASELINE configs[2]: independent proofs, one replica per rank) with the eight ranks
+    sharing GPU 0 over gloo: one JSON line from rank 0 with n_gpus = 8, the whole-job rate, one host-CPU figure per rank, and the
+    hashing mode batch.configure_host chose from the CPUs each rank can count on (fewer than six per rank: the shared eight-lane
+    service).  The rate itself means nothing here (eight ranks on one chip); the contract and the control flow are under test."""
+    env = dict(os.environ)
+    env["ZKFHE_BENCH_BACKEND"] = "gloo"
+    env["ZKFHE_TABLE_GB"] = "1"
+    env.pop("ZKFHE_HASH_MODE", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "1", "--streams", "4",
+           "--no-cpu-baseline", "--steady-seconds", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 8 and d["scaling"] == "weak" and d["config"]["mode"] == "batch"
+    assert abs(d["value"] - 8 * 8 / (d["ms_per_step"] * 8 / 1e3)) / d["value"] < 1e-6          # 64 proofs of the job over the slowest rank's time
+    assert len(d["config"]["host_cpu_ms_per_proof_by_rank"]) == 8 and all(v > 0 for v in d["config"]["host_cpu_ms_per_proof_by_rank"])
+    host = d["config"]["host"]
+    assert host["cpus_per_rank"] == host["usable_cpus"] / 8
+    assert host["hash_mode"] == ("shared" if host["cpus_per_rank"] < 6 else "latency")
+    assert d["config"]["verified"] is True and d["vs_baseline"] is None

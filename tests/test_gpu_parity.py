@@ -228,6 +228,33 @@ def test_msm_vs_oracle(ctx, n, c):
     B.destroy()
 
 
+@pytest.mark.parametrize("n,c,n_cols", [(48, 5, 3), (1000, 0, 4), (1000, 7, 20), (8192, 0, 3), (8192, 0, 40), (8192, 13, 5)])
+def test_msm_accumulator_form_and_host_normalisation(ctx, monkeypatch, n, c, n_cols):
+    """zkfhe_msm_batch_xyzz + zkfhe_g1_xyzz_to_affine (what the prover's commitments go through on one GPU: the MSM stores the
+    XYZZ sum, the host normalises a round's points with one inversion) against the oracle MSM, on every tail kernel: k_msm_small
+    (K < 64), k_msm_weighted (bucket pipeline, c given), k_msm_table_fold with one partial per visit (<= 16 columns) and with 256;
+    a zero column (the identity: ZZ = 0 -> (0, 0)), and the same call through the affine entry point."""
+    import zk_fhe_amd as zk
+    monkeypatch.setenv("ZKFHE_TABLE_GB", "2")
+    rng = np.random.default_rng(7 * n + n_cols)
+    bases = _bases(n, seed=n + 3)
+    bases[n // 7] = 0
+    sc = [[int.from_bytes(rng.bytes(32), "little") % pyref.R for _ in range(n)] for _ in range(3)]
+    sc[1] = [int(rng.integers(0, 256)) if i % 3 else (pyref.R - int(rng.integers(1, 1000))) for i in range(n)]
+    sc[2] = [0] * n
+    S = np.stack([orc.ints_to_mont(sc[j % 3]) for j in range(n_cols)])
+    for j in range(3, n_cols):                                       # more columns: the same three kinds, rotated so that they differ
+        S[j] = np.roll(S[j], j, axis=0)
+    B = zk.Basis(ctx, bases, c)
+    aff, raw = ctx.msm_xyzz(B, S)
+    want = orc.msm(S, bases)
+    assert np.array_equal(aff, want)
+    assert np.array_equal(ctx.msm(B, S), want)
+    assert not aff[2].any() and not raw[2, 8:].any()                # the zero column: identity, ZZ = ZZZ = 0
+    assert raw[0, 8:12].any() and not np.array_equal(raw[0, :8], want[0])   # really the accumulator form (ZZ != 1)
+    B.destroy()
+
+
 @pytest.mark.parametrize("n,n_cols,bits", [(256, 1, 0), (1000, 3, 8), (1000, 3, 9), (8192, 1, 0), (8192, 3, 10), (8192, 4, 11), (8192, 17, 13),
                                            (16384, 2, 8), (65536, 1, 8), (2048, 40, 12), (2048, 300, 10), (2048, 9, 14), (1024, 5, 15)])
 def test_msm_table_path(ctx, monkeypatch, n, n_cols, bits):

@@ -88,25 +88,33 @@ def oracle_k13():
     return _ORACLE_K13
 
 
-@pytest.mark.parametrize("table_gb", ["4", None])
+@pytest.mark.parametrize("table_gb", ["4", None, "160"])
 def test_bfv_in_k13_proof_bytes_match_oracle(ctx, monkeypatch, table_gb):
-    """BASELINE config 2: the reference's data/bfv/bfv.in, k = 13, pinned configs/bfv.json layout.  table_gb = None is the
-    library's DEFAULT table budget -- 15-bit digits for the Lagrange half (146 GB: more than 2^31 table entries), 13-bit for the
-    monomial half (43 GB), every commitment a sum of table points (k_msm_table): the configuration bench.py and the driver's BENCH
-    line measure (14 bits if the device does not have 146 + 36 GB free when the test runs).  "4" is the budget the rest of the
-    suite runs on: 9-bit digits, which serve the calls of a few columns only -- the two wide calls take the bucket pipeline
-    (k_msm_accumulate ...).  Between them the two cases prove bfv.in through both MSM paths."""
+    """BASELINE config 2: the reference's data/bfv/bfv.in, k = 13, pinned configs/bfv.json layout, at three table budgets.
+    "160" is the SERVICE profile bench.py and the driver's BENCH line measure: 15-bit digits for the Lagrange half (146 GB: more
+    than 2^31 table entries), 13-bit for the monomial half (43 GB), every commitment a sum of table points (k_msm_table) -- 14 bits
+    if the device does not have the room when the test runs.  None is the library's own DEFAULT (48 GB and at most a quarter of the
+    free memory: 13 / 12 bits, 67 GB).  "4" is the budget the rest of the suite runs on: 9-bit digits, which serve the calls of a
+    few columns only -- the two wide calls take the bucket pipeline (k_msm_accumulate ...).  Between them the cases prove bfv.in
+    through both MSM paths and three table geometries."""
     import zk_fhe_amd as zk
+    monkeypatch.delenv("ZKFHE_TABLE_BITS", raising=False)
     if table_gb is None:
         monkeypatch.delenv("ZKFHE_TABLE_GB", raising=False)
-        monkeypatch.delenv("ZKFHE_TABLE_BITS", raising=False)
     else:
         monkeypatch.setenv("ZKFHE_TABLE_GB", table_gb)
     o = oracle_k13()
     cfgj, prm, text_empty, text = o["cfgj"], o["prm"], o["text_empty"], o["text"]
     srs = zk.Srs(ctx, 13)
     bits, wide = srs.table_bits()
-    assert (bits in (14, 15) and wide) if table_gb is None else (bits, wide) == (9, False), (bits, wide)
+    ti = srs.table_info()
+    print("tables at ZKFHE_TABLE_GB=%s: %s" % (table_gb, ti))
+    if table_gb == "160":
+        assert bits in (14, 15) and wide and ti["bits"][1] == bits and ti["gb"] > 100
+    elif table_gb is None:
+        assert (bits, wide) == (13, True) and ti["bits"] == (12, 13) and 60 < ti["gb"] < 72 and not ti["narrowed"]
+    else:
+        assert (bits, wide) == (9, False), (bits, wide)
     zcfg = zk.BfvConfig.from_pinning(cfgj)
     zcfg_nobp = zk.BfvConfig(zcfg.k, zcfg.n_gate0, zcfg.n_gate1, zcfg.n_lookup, zcfg.n_rlc, zcfg.unusable_rows, zcfg.lookup_bits)
     pk = zk.BfvProvingKey(ctx, srs, text_empty, (1024, prm.Q, prm.T, prm.B), zcfg_nobp)
@@ -572,3 +580,88 @@ def test_config5_k19_n16384(ctx, tmp_path):
     """BASELINE config 5: N = 16384, k = 19 (n = 524288 rows): MSM-dominated, long-row NTTs everywhere."""
     cols, cells = _prove_and_verify_large(ctx, 16384, 19, "config5", tmp_path)
     assert cols[1] <= 64
+
+
+@pytest.mark.parametrize("transcript", ["poseidon", "blake2b"])
+def test_prefix_cache_hit_and_miss_give_the_same_bytes(ctx, transcript):
+    """The per-public-key transcript cache (host/prefix_cache.hpp, zkfhe_bfv_pk_prefix_cache): a proof that restores the state
+    behind `vk digest | pk0 | pk1` (hit), one that computes and stores it (miss) and one made with the cache off are the same
+    bytes; two public keys interleaved, several encryptions each, sequentially and with four proofs in flight; the counters
+    count.  Toy circuit (k = 9, N = 8: a 16-value key prefix of 41 public inputs), both transcripts."""
+    import zk_fhe_amd as zk
+    import zk_fhe_amd.batch as batch
+    from zk_fhe_amd import inputs as gen
+    prm = C.BfvParams(N=8)
+    par = (8, prm.Q, prm.T, prm.B)
+    texts = {(key, s): json.dumps(gen.generate(8, prm.Q, prm.T, prm.B, seed=s, key_seed=key)) for key in (100, 200) for s in (1, 2, 3)}
+    order = [(100, 1), (200, 1), (100, 2), (200, 2), (100, 3), (200, 3), (100, 1)]
+    cfg = zk.bfv_auto_config(texts[(100, 1)], par, 9, unusable_rows=9, transcript=transcript)
+    srs = zk.Srs(ctx, 9)
+    pk = zk.BfvProvingKey(ctx, srs, texts[(100, 1)], par, cfg)
+    assert pk.prefix_cache() == {"hits": 0, "misses": 0, "entries": 0}
+    pk.prefix_cache(0)
+    plain = [pk.prove(texts[o], b"pc-%d" % i)[0] for i, o in enumerate(order)]
+    assert pk.prefix_cache() == {"hits": 0, "misses": 0, "entries": 0}            # off: nothing looked up, nothing stored
+    pk.prefix_cache(8)
+    cached = [pk.prove(texts[o], b"pc-%d" % i)[0] for i, o in enumerate(order)]
+    assert cached == plain
+    assert pk.prefix_cache() == {"hits": 5, "misses": 2, "entries": 2}            # one miss per public key
+    # four proofs in flight on their own contexts, all hits now
+    ctxs = [zk.Context(0) for _ in range(4)]
+    conc = batch.run_concurrent(list(range(len(order))), ctxs, lambda c, i: pk.prove(texts[order[i]], b"pc-%d" % i, ctx=c)[0])
+    assert conc == plain and pk.prefix_cache()["hits"] == 12
+    # one remembered key: the two keys evict each other, still the same bytes
+    pk.prefix_cache(1)
+    assert pk.prefix_cache()["entries"] == 1
+    again = [pk.prove(texts[o], b"pc-%d" % i)[0] for i, o in enumerate(order)]
+    assert again == plain
+    st = pk.prefix_cache()
+    # the keys alternate: every proof misses, except the first when its key is the entry that survived the shrink
+    assert st["entries"] == 1 and st["hits"] in (12, 13) and st["hits"] + st["misses"] == 12 + 2 + len(order)
+    for c in ctxs:
+        c.close()
+    pk.destroy()
+    srs.destroy()
+
+
+def test_prefix_cache_hit_matches_the_oracle_proof_k13(ctx):
+    """bfv.in at k = 13 (2 048 of the 5 121 public inputs are the key): the first proof misses and stores, the second hits, a
+    third with the cache off recomputes -- all three are the ORACLE prover's bytes for that seed."""
+    import zk_fhe_amd as zk
+    o = oracle_k13()
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, o["text_empty"], (1024, o["prm"].Q, o["prm"].T, o["prm"].B), zk.BfvConfig.from_pinning(o["cfgj"]))
+    for want in ({"hits": 0, "misses": 1, "entries": 1}, {"hits": 1, "misses": 1, "entries": 1}):
+        proof, inst, _ = pk.prove(o["text"], b"seed-1")
+        assert proof == o["proof_o"] and inst == o["inst_o"]
+        assert pk.prefix_cache() == want
+    pk.prefix_cache(0)
+    assert pk.prove(o["text"], b"seed-1")[0] == o["proof_o"]
+    pk.destroy()
+    srs.destroy()
+
+
+def test_second_srs_on_a_full_device_gets_narrower_tables_same_bytes(ctx, monkeypatch):
+    """Behaviour under memory pressure (README "Table budget"): with the service profile (ZKFHE_TABLE_GB=160) one k = 13 SRS takes
+    189 GB of the 288; a SECOND one made while it is alive cannot have that -- the library leaves a reserve for keys and workspaces,
+    narrows the second SRS's tables until they fit, says so (zkfhe_srs_table_info: narrowed) and proves the same bytes with it."""
+    import zk_fhe_amd as zk
+    monkeypatch.delenv("ZKFHE_TABLE_BITS", raising=False)
+    monkeypatch.setenv("ZKFHE_TABLE_GB", "160")
+    o = oracle_k13()
+    a = zk.Srs(ctx, 13)
+    ia = a.table_info()
+    if ia["bits"][1] < 15:
+        a.destroy()
+        pytest.skip("the device is not empty enough for the 189 GB profile: %s" % ia)
+    b = zk.Srs(ctx, 13)
+    ib = b.table_info()
+    print("first SRS %s, second SRS %s" % (ia, ib))
+    assert not ia["narrowed"] and ib["narrowed"] and ib["bits"][1] < 15 and ib["gb"] < ia["gb"]
+    cfg = zk.BfvConfig.from_pinning(o["cfgj"])
+    for srs in (a, b):
+        pk = zk.BfvProvingKey(ctx, srs, o["text_empty"], (1024, o["prm"].Q, o["prm"].T, o["prm"].B), cfg)
+        assert pk.prove(o["text"], b"seed-1")[0] == o["proof_o"]
+        pk.destroy()
+    b.destroy()
+    a.destroy()

@@ -63,3 +63,44 @@ def test_fr_nine_limb_sums_of_the_element_wise_kernels(tmp_path):
                     "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "native", "fr29_sum_check.hip"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "fr29 sums: 0 bad" in out, out
+
+
+def test_xyzz_batch_normalisation_on_the_host():
+    """zkfhe_g1_xyzz_to_affine (host only: Montgomery's trick over the ZZZ of the array, one Bernstein-Yang inversion; the prover
+    normalises a round's commitments with it) against the big-integer oracle: random multiples of the generator, each blown up
+    to an accumulator form with its own random Z (X = x Z^2, Y = y Z^3, ZZ = Z^2, ZZZ = Z^3), identities (ZZ = 0) in between,
+    n = 1 and n = 0 included."""
+    import ctypes
+    import random
+
+    import numpy as np
+
+    import zk_fhe_amd as zk
+    from oracle import pyref
+    lib = zk.load_library()
+    lib.zkfhe_g1_xyzz_to_affine.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    rnd = random.Random(5)
+    Q = pyref.Q
+
+    def limbs(v):
+        m = pyref.to_mont(v, Q)
+        return [(m >> (64 * j)) & ((1 << 64) - 1) for j in range(4)]
+    for n in (0, 1, 2, 37):
+        pts, rows = [], []
+        for i in range(n):
+            if n > 2 and i % 5 == 3:
+                pts.append(None)
+                rows.append(limbs(rnd.randrange(Q)) + limbs(rnd.randrange(Q)) + [0] * 8)      # identity: only ZZ = 0 matters
+                continue
+            P = pyref.g1_mul((1, 2), rnd.randrange(1, pyref.R))
+            z = rnd.randrange(1, Q)
+            zz, zzz = z * z % Q, z * z * z % Q
+            pts.append(P)
+            rows.append(limbs(P[0] * zz % Q) + limbs(P[1] * zzz % Q) + limbs(zz) + limbs(zzz))
+        raw = np.array(rows, dtype=np.uint64).reshape(n, 16)
+        out = np.full((n, 8), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        assert lib.zkfhe_g1_xyzz_to_affine(raw.ctypes.data_as(ctypes.c_void_p), n, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        for i, P in enumerate(pts):
+            want = [0] * 8 if P is None else limbs(P[0]) + limbs(P[1])
+            assert [int(v) for v in out[i]] == want, (n, i)
+    assert lib.zkfhe_g1_xyzz_to_affine(None, 3, None) != 0

@@ -55,3 +55,23 @@ def test_generator_is_deterministic_and_seed_sensitive(inputs):
     assert a != inputs.generate(16, 536870909, 7, 19, seed=4)
     e = inputs.empty(16)
     assert len(e["cyclo"]) == 17 and set(e["pk0"]) == {"0"}
+
+
+def test_one_key_many_encryptions_and_config3_batch(inputs):
+    """key_seed fixes the key pair: different seeds encrypt different messages under one public key, and each still decrypts.
+    config3_batch = SURVEY.md 8(d) config 3: the reference's bfv.in first, then seeded vectors that are valid encryptions
+    (c0 = pk0 u + floor(Q/T) m + e0, c1 = pk1 u + e1) with a public key of their own each."""
+    q, t, b = 536870909, 7, 19
+    (a, sa), (c, sc) = (inputs.generate(32, q, t, b, seed=s, with_secret=True, key_seed=77) for s in (1, 2))
+    assert a["pk0"] == c["pk0"] and a["pk1"] == c["pk1"] and a["c0"] != c["c0"] and (sa["sk"] == sc["sk"]).all()
+    for s in (sa, sc):
+        assert (inputs.decrypt(s["sk"], s["c0"], s["c1"], q, t) == s["m"]).all()
+    ref = open(os.path.join(HERE, "golden", "bfv", "bfv.in"), "rb").read()
+    batch = inputs.config3_batch(ref, 5)
+    assert batch[0] == ref and len(batch) == 5 and len({x for x in batch}) == 5
+    prm = C.BfvParams()
+    for text in batch[1:3]:
+        inp = json.loads(text)
+        assert inp["pk0"] != json.loads(batch[0])["pk0"]
+        C.bfv_phase0(inp, prm)      # asserts the ciphertext identity (division by the cyclotomic polynomial leaves the stated remainder)
+    assert batch[1] == inputs.config3_vector(20240613 + 1).encode()

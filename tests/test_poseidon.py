@@ -172,3 +172,22 @@ def test_eight_lane_sponges_match_oracle_and_single_path():
     sp = P.Sponge()
     sp.update(long_seqs[0])
     assert zk.poseidon_hash_many(long_seqs, mode=2)[0] == sp.squeeze()
+
+
+def test_transcript_mid_state_and_prefix_cache(tmp_path):
+    """host/transcript.hpp State / restore / common_scalars_async_marked and host/prefix_cache.hpp (the per-public-key transcript
+    cache of the prover) on the CPU: restoring the state behind `digest | pk0 | pk1` and absorbing the rest squeezes the same
+    challenges as absorbing everything, for both hashers and odd / even cuts; the cache hits on equal keys only and evicts the
+    least recently used entry (tests/native/transcript_prefix_check.cpp)."""
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    host = os.path.join(here, "..", "zk-fhe_amd", "host")
+    cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else shutil.which("clang++")
+    if not cxx:
+        pytest.skip("no clang++ (the host headers use clang's carry builtins)")
+    exe = str(tmp_path / "transcript_prefix_check")
+    subprocess.run([cxx, "-O2", "-std=c++17", "-I", host, os.path.join(here, "native", "transcript_prefix_check.cpp"),
+                    os.path.join(host, "poseidon_ifma.cpp"), os.path.join(host, "poseidon_x8.cpp"), "-o", exe, "-lpthread"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "transcript prefix check: ok" in out.stdout, out.stdout + out.stderr

@@ -24,7 +24,7 @@ EXPORTS = [
     "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain", "zkfhe_fq29_sqr_chain",
     "zkfhe_ntt_batch", "zkfhe_ntt_batch_to", "zkfhe_coset_ntt_batch",
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
-    "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_basis_has_multiples", "zkfhe_basis_table_bits", "zkfhe_srs_table_bits",
+    "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_msm_batch_xyzz", "zkfhe_msm_sparse_xyzz", "zkfhe_g1_xyzz_to_affine", "zkfhe_basis_has_multiples", "zkfhe_basis_table_bits", "zkfhe_basis_table_bytes", "zkfhe_srs_table_bits", "zkfhe_srs_table_info",
     "zkfhe_comm_unique_id", "zkfhe_comm_create", "zkfhe_comm_create_with_transport", "zkfhe_comm_destroy", "zkfhe_comm_rank", "zkfhe_comm_world", "zkfhe_comm_active",
     "zkfhe_comm_point_range", "zkfhe_comm_all_gather", "zkfhe_msm_batch_sharded", "zkfhe_msm_batch_sharded_async", "zkfhe_comm_join", "zkfhe_comm_record_event", "zkfhe_srs_create_sharded",
     "zkfhe_witness_poly_mul_u64", "zkfhe_host_poly_mul_u32", "zkfhe_witness_div_mod",
@@ -32,7 +32,7 @@ EXPORTS = [
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points", "zkfhe_bfv_mock_check", "zkfhe_bfv_tables_poke_advice",
     "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_srs_save", "zkfhe_srs_load", "zkfhe_srs_g2", "zkfhe_srs_set_g2", "zkfhe_srs_file_g2",
-    "zkfhe_chacha20_block", "zkfhe_snark_encode", "zkfhe_snark_decode", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info",
+    "zkfhe_chacha20_block", "zkfhe_snark_encode", "zkfhe_snark_decode", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info", "zkfhe_bfv_pk_prefix_cache",
     "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
     "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
@@ -303,6 +303,23 @@ class Context:
         out = do.download(shape=(n_cols, 8))
         ds.free(), do.free()
         return out
+
+    def msm_xyzz(self, basis, scalars):
+        """zkfhe_msm_batch_xyzz + zkfhe_g1_xyzz_to_affine: the sums in accumulator form from the GPU, ONE inversion for all of them
+        on the host.  Returns (affine (n_cols, 8) uint64, raw xyzz (n_cols, 16) uint64)."""
+        scalars = self._fr(scalars)
+        n_cols = scalars.size // 4 // basis.n
+        vp = ctypes.c_void_p
+        self.lib.zkfhe_msm_batch_xyzz.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+        self.lib.zkfhe_g1_xyzz_to_affine.argtypes = [vp, ctypes.c_size_t, vp]
+        d = self.to_device(scalars)
+        out = self.alloc(n_cols * 128)
+        self._check(self.lib.zkfhe_msm_batch_xyzz(self.h, basis.h, d.ptr, n_cols, out.ptr))
+        raw = np.ascontiguousarray(out.download(dtype=np.uint64, shape=(n_cols, 16)))
+        aff = np.empty((n_cols, 8), dtype=np.uint64)
+        self._check(self.lib.zkfhe_g1_xyzz_to_affine(raw.ctypes.data_as(vp), n_cols, aff.ctypes.data_as(vp)))
+        d.free(), out.free()
+        return aff, raw
 
     def msm_sharded(self, comm, basis_slice, scalars, lo):
         """zkfhe_msm_batch_sharded: `scalars` = the FULL columns (n_cols, n_full, 4); this rank's basis slice covers rows
@@ -827,6 +844,15 @@ class Srs:
         bits = lib.zkfhe_srs_table_bits(self.h, ctypes.byref(wide))
         return int(bits), bool(wide.value)
 
+    def table_info(self):
+        """zkfhe_srs_table_info: {"bits": (monomial half, Lagrange half), "gb": resident GB of both tables, "narrowed": whether a half
+        got a narrower table than its budget allowed because the device did not have the room}."""
+        lib = self.ctx.lib
+        lib.zkfhe_srs_table_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int * 2), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+        bits, nbytes, narrowed = (ctypes.c_int * 2)(), ctypes.c_uint64(), ctypes.c_int()
+        self.ctx._check(lib.zkfhe_srs_table_info(self.h, ctypes.byref(bits), ctypes.byref(nbytes), ctypes.byref(narrowed)))
+        return {"bits": (int(bits[0]), int(bits[1])), "gb": nbytes.value / 2.0 ** 30, "narrowed": bool(narrowed.value)}
+
     def destroy(self):
         if self.h:
             self.ctx.lib.zkfhe_srs_destroy(self.ctx.h, self.h)
@@ -983,6 +1009,16 @@ class BfvProvingKey:
         out = np.empty((n.value, 4), dtype=np.uint64)
         self.ctx._check(lib.zkfhe_bfv_witness_stream(self.ctx.h, self.h, text, g, out.ctypes.data_as(vp), n.value, ctypes.byref(n)))
         return out
+
+    def prefix_cache(self, capacity=-1):
+        """zkfhe_bfv_pk_prefix_cache: the per-public-key transcript cache of this key (state after vk digest | pk0 | pk1).
+        capacity >= 0 sets the number of public keys remembered (0 = off); returns {"hits", "misses", "entries"}."""
+        lib = self.ctx.lib
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        lib.zkfhe_bfv_pk_prefix_cache.argtypes = [ctypes.c_void_p, ctypes.c_int, u64p, u64p, u64p]
+        h, m, e = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self.ctx._check(lib.zkfhe_bfv_pk_prefix_cache(self.h, int(capacity), ctypes.byref(h), ctypes.byref(m), ctypes.byref(e)))
+        return {"hits": h.value, "misses": m.value, "entries": e.value}
 
     def export_vk(self):
         lib = self.ctx.lib

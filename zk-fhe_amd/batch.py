@@ -85,8 +85,11 @@ def run_concurrent(jobs, workers, fn, stagger_s=0.0):
     return results
 
 
-def prove_batch(pk, inputs, seeds, contexts):
-    """All proofs of this rank: inputs[i] (JSON text), seeds[i]; `contexts` = zk.Context objects of this rank's GPU."""
+def prove_batch(pk, inputs, seeds, contexts, with_instances=False):
+    """All proofs of this rank: inputs[i] (JSON text), seeds[i]; `contexts` = zk.Context objects of this rank's GPU (one proof in
+    flight per context).  Returns the proof bytes in input order -- (proof, public inputs) pairs with with_instances."""
+    if with_instances:
+        return run_concurrent(list(range(len(inputs))), contexts, lambda c, i: pk.prove(inputs[i], seeds[i], ctx=c)[:2])
     return run_concurrent(list(range(len(inputs))), contexts, lambda c, i: pk.prove(inputs[i], seeds[i], ctx=c)[0])
 
 

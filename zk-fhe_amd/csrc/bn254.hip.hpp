@@ -13,6 +13,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <vector>
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ZK_HD __host__ __device__ __forceinline__
@@ -696,6 +698,31 @@ ZK_HD G1Affine g1x_to_affine(const G1X& p) {
   r.x = p.x * izz;
   r.y = p.y * izzz;
   return r;
+}
+
+// Host: n accumulator-form sums -> affine points with ONE field inversion (Montgomery's trick over the non-zero ZZZ: three
+// products per point), x = X (ZZ / ZZZ)^2, y = Y / ZZZ as in g1x_to_affine; identity (ZZ = 0) -> (0, 0).  The prover normalises
+// the commitments of a Fiat-Shamir round this way (the MSM's last kernel stores the XYZZ sum and skips its own inversion).
+inline void g1x_normalize_batch(const G1X *in, size_t n, G1Affine *out) {
+  std::vector<Fq> pre(n);
+  Fq acc = Fq::one();
+  for (size_t i = 0; i < n; ++i) {
+    pre[i] = acc;
+    if (!in[i].is_identity()) acc = acc * in[i].zzz;
+  }
+  Fq inv = fp_inv<FqP>(acc);   // 1 / (product of all ZZZ)
+  for (size_t i = n; i-- > 0;) {
+    if (in[i].is_identity()) {
+      out[i].x = Fq::zero();
+      out[i].y = Fq::zero();
+      continue;
+    }
+    const Fq izzz = inv * pre[i];
+    inv = inv * in[i].zzz;
+    const Fq izz = fp_sqr<FqP>(izzz * in[i].zz);
+    out[i].x = in[i].x * izz;
+    out[i].y = in[i].y * izzz;
+  }
 }
 
 // XYZZ -> Jacobian {X,Y,Z} with Z = ZZZ/ZZ:  X_j = x Z^2 = X*ZZZ^2/ZZ^3 ... use affine-free map:

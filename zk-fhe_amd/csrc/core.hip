@@ -4,6 +4,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "ctx.hpp"
 #include "fq29.hip.hpp"
 #include "fr29.hip.hpp"
@@ -21,6 +25,17 @@ int zk_fail(zkfhe_ctx *ctx, int code, const char *what, hipError_t e, const char
 int zk_fail_msg(zkfhe_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg; else g_create_err = msg;
   return code;
+}
+
+int zk_func_max_lds(zkfhe_ctx *ctx, const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> done;   // (device, kernel) -> bytes granted
+  std::lock_guard<std::mutex> l(mu);
+  int &have = done[std::make_pair(ctx->device, kernel)];
+  if (have >= bytes) return ZKFHE_OK;
+  ZK_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
+  return ZKFHE_OK;
 }
 
 int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out) {

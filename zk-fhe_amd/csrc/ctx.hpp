@@ -61,6 +61,8 @@ struct zkfhe_basis {
   // mc = 12).  nullptr: calls against this basis take the bucket pipeline over `table`.
   zk::G1Affine *mult = nullptr;
   int mc = 0, mw = 0;
+  size_t mult_bytes = 0;   // resident bytes of `mult`
+  bool narrowed = false;   // the device did not have the room for the width the budget allowed when the basis was made
 };
 
 int zk_fail(zkfhe_ctx *ctx, int code, const char *what, hipError_t e, const char *file, int line);
@@ -113,6 +115,16 @@ inline hipError_t zk_wait(zkfhe_ctx *ctx) {
 
 // zkfhe_msm_batch with a column stride (msm.hip)
 int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev);
+int zk_msm_batch_strided_form(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, void *out_dev, bool xyzz);
+#define ZK_CK(x)             \
+  do {                       \
+    const int rc__ = (x);    \
+    if (rc__) return rc__;   \
+  } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set once per (device, kernel), under a lock --
+// several contexts (devices, threads) may reach a launch site at the same time (core.hip)
+int zk_func_max_lds(zkfhe_ctx *ctx, const void *kernel, int bytes);
 // returns a device scratch arena of at least `bytes` (slot 0..3), grow-only, stream-ordered reuse
 int zk_scratch(zkfhe_ctx *ctx, int slot, size_t bytes, void **out);
 // zkfhe_basis_create with a share of the digit-multiple table budget (msm.hip)

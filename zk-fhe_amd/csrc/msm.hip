@@ -738,7 +738,10 @@ __global__ void __launch_bounds__(256) k_msm_marginals(const G1X *__restrict__ b
 // Every lane runs a double-and-add over exactly the bits its wave needs (log2 A for the rows, 7 for the columns); the row
 // lanes then double six more times (the factor 64) while the column wave is still busy, so that after the butterflies one
 // lane only adds the wave sums and normalises: 30 dependent point operations at K = 4096, 26 at K = 512 (it was 37).
-__global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ marg, unsigned K, G1Affine *__restrict__ out) {
+// XYZZ: the sum leaves the kernel as it is (128 B, standard Montgomery form) and the caller normalises a whole round's points with
+// one inversion on the host (zkfhe_g1_xyzz_to_affine) -- the 40 us Bernstein-Yang inversion of one lane is the tail of every call.
+template <bool XYZZ>
+__global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ marg, unsigned K, void *__restrict__ out) {
   __shared__ G1X sh[9];
   const unsigned A = K >> 6;
   const unsigned row_waves = (A + 63) / 64;
@@ -769,12 +772,15 @@ __global__ void __launch_bounds__(576) k_msm_weighted(const G1X *__restrict__ ma
   if (threadIdx.x == 0) {
     G1X29 t = g1x29_load(sh[0]);
     for (unsigned w = 1; w <= row_waves; ++w) g1x29_add(t, g1x29_load(sh[w]));
-    out[col] = g1x_to_affine(g1x29_to_std(t));   // back to the standard Montgomery form, then one inversion
+    // back to the standard Montgomery form, then one inversion (or none: XYZZ)
+    if (XYZZ) ((G1X *)out)[col] = g1x29_to_std(t);
+    else ((G1Affine *)out)[col] = g1x_to_affine(g1x29_to_std(t));
   }
 }
 
 // K < 64 buckets (window_bits < 7: tiny bases and tests): one wave per MSM, lane b weights bucket b by b + 1
-__global__ void __launch_bounds__(64) k_msm_small(const G1X *__restrict__ buckets, unsigned K, G1Affine *__restrict__ out) {
+template <bool XYZZ>
+__global__ void __launch_bounds__(64) k_msm_small(const G1X *__restrict__ buckets, unsigned K, void *__restrict__ out) {
   const size_t col = blockIdx.x;
   const unsigned lane = threadIdx.x;
   const G1X29 P = g1x29_load(lane < K ? buckets[col * K + lane] : G1X::identity());
@@ -788,7 +794,10 @@ __global__ void __launch_bounds__(64) k_msm_small(const G1X *__restrict__ bucket
     const G1X29 other = g1x_shfl_xor(W, m);
     g1x29_add(W, other);
   }
-  if (lane == 0) out[col] = g1x_to_affine(g1x29_to_std(W));
+  if (lane == 0) {
+    if (XYZZ) ((G1X *)out)[col] = g1x29_to_std(W);
+    else ((G1Affine *)out)[col] = g1x_to_affine(g1x29_to_std(W));
+  }
 }
 
 // ---- digit-multiple table path ---------------------------------------------------------------------------------------
@@ -1025,8 +1034,9 @@ __global__ void __launch_bounds__(256, TREE ? 1 : 3) k_msm_table(const Fr *__res
 // visits -- a column of the wide calls collects 25 to 30 visits (every workgroup that drew a chunk of it), and the visits are
 // the sequential part of this kernel: visits / 2 + 9 dependent point additions instead of visits + 8.  The next partial is in
 // flight during an addition.
+template <bool XYZZ>
 __global__ void __launch_bounds__(512) k_msm_table_fold(const G1X *__restrict__ partials, unsigned max_part, unsigned L, unsigned *__restrict__ n_part,
-                                                        unsigned *__restrict__ col_next, G1Affine *__restrict__ out) {
+                                                        unsigned *__restrict__ col_next, void *__restrict__ out) {
   __shared__ G1X sh[256];
   const unsigned col = blockIdx.x, t = threadIdx.x & 255u, q = threadIdx.x >> 8;
   const unsigned np = n_part[col] * L;
@@ -1065,7 +1075,8 @@ __global__ void __launch_bounds__(512) k_msm_table_fold(const G1X *__restrict__ 
       g1x29_add(f, other);
     }
     if (threadIdx.x == 0) {
-      out[col] = g1x_to_affine(g1x29_to_std(f));
+      if (XYZZ) ((G1X *)out)[col] = g1x29_to_std(f);   // normalised by the caller, a round's points at a time
+      else ((G1Affine *)out)[col] = g1x_to_affine(g1x29_to_std(f));
       n_part[col] = 0;
       col_next[col] = 0;
     }
@@ -1114,8 +1125,9 @@ __global__ void __launch_bounds__(256) k_g1_mul(const G1Affine *__restrict__ p, 
 // A handful of non-zero scalars against a basis with a digit-multiple table: out[slot] = sum over the cells of that slot of
 // scalar * P_row.  One wave per slot, lanes over the windows, a butterfly, one normalisation.  (The prover's early
 // phase-1 commitment: the 16 challenge-dependent gate cells of the constrain_mul gates, as corrections to <= 4 columns.)
+template <bool XYZZ>
 __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__restrict__ terms, unsigned n_terms, const G1Affine *__restrict__ T, int c, int W,
-                                                   BiasArg B, G1Affine *__restrict__ out) {
+                                                   BiasArg B, void *__restrict__ out) {
   const unsigned slot = blockIdx.x, lane = threadIdx.x;
   const int half = 1 << (c - 1);
   G1X29 acc = G1X29::identity();
@@ -1140,22 +1152,36 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
     const G1X29 other = g1x_shfl_xor(acc, m);
     g1x29_add(acc, other);
   }
-  if (lane == 0) out[slot] = g1x_to_affine(g1x29_to_std(acc));
+  if (lane == 0) {
+    if (XYZZ) ((G1X *)out)[slot] = g1x29_to_std(acc);
+    else ((G1Affine *)out)[slot] = g1x_to_affine(g1x29_to_std(acc));
+  }
 }
 
-// Window width of the digit-multiple table: the widest (<= 15 bits) whose table fits the per-basis budget (ZKFHE_TABLE_GB, default
-// 160 -- 15-bit digits at n = 2^13: 17 windows x 16 384 multiples x 64 B per base point, 146 GB for the Lagrange half of an SRS, whose
-// wide commitment calls then need 21.4 M additions per proof against 24.9 M with 13 bits; the monomial half, which only serves calls
-// of 1-3 columns, is created with half the budget: 13 bits, 43 GB.  A table may hold more than 2^31 entries: k_msm_table addresses
-// it relative to the chunk it is summing.  Longer bases get narrower digits from the same budget (2^16: 11 bits, 2^19: 8 bits for the
-// Lagrange half alone); their wide calls take the bucket pipeline and the table serves the calls of a few columns (k = 19: 173 -> 169 ms
-// per proof).  ZKFHE_TABLE_BITS forces a width, 0 = no table).
+// Window width of the digit-multiple table: the widest (<= 15 bits) whose table fits the per-basis budget.
+//   * ZKFHE_TABLE_GB unset (the library default): 48 GB, and never more than a quarter of the memory that is free on the device when
+//     the basis is made -- n = 2^13: 13-bit digits for the Lagrange half of an SRS (43 GB), 12 for the monomial half, which gets half
+//     the budget (24 GB): 67 GB per SRS.  A library that is one tenant of the device among others (a second key, another process, a
+//     k = 16 key next to a k = 13 one) must not take two thirds of it by default.
+//   * ZKFHE_TABLE_GB=<GB>: an explicit budget -- the SERVICE profile of a prover that owns the GPU is 160 (bench.py sets it): 15-bit
+//     digits at n = 2^13, 17 windows x 16 384 multiples x 64 B per base point, 146 GB + 43 GB (13 bits) = 189 GB per SRS; the wide
+//     commitment calls then need 21.4 M additions per proof against 24.9 M with 13 bits (profiles/r5_table_budget.md: rate against
+//     resident GB and build time).  A table may hold more than 2^31 entries: k_msm_table addresses it relative to the chunk it sums.
+// Longer bases get narrower digits from the same budget (2^16: 11 bits, 2^19: 8 bits for the Lagrange half alone); their wide calls
+// take the bucket pipeline and the table serves the calls of a few columns.  ZKFHE_TABLE_BITS forces a width (0 = no table).
+// Whatever the budget says, zk_basis_create_scaled narrows the table until it fits beside a reserve for proving keys and workspaces
+// (table_reserve_bytes) and reports what it built (zkfhe_basis_table_bits / _bytes; one line on stderr with ZKFHE_VERBOSE).
 int table_bits(size_t n, double budget_scale) {
   // read per basis (creation is rare): tests switch widths inside one process
   const char *e = getenv("ZKFHE_TABLE_BITS");
   const int forced = e ? atoi(e) : -1;
   const char *g = getenv("ZKFHE_TABLE_GB");
-  const double budget = (g ? atof(g) : 160.0) * 1073741824.0 * budget_scale;
+  double gb = g ? atof(g) : 48.0;
+  if (!g) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 4.0 < gb * 1073741824.0) gb = (double)free_b / 4.0 / 1073741824.0;
+  }
+  const double budget = gb * 1073741824.0 * budget_scale;
   auto fits = [&](int c) {
     const double entries = (double)n * (double)((255 + c - 1) / c) * (double)(1u << (c - 1));
     return c >= 8 && c <= 15 && entries * sizeof(G1Affine) <= budget;
@@ -1164,6 +1190,15 @@ int table_bits(size_t n, double budget_scale) {
   for (int c = 15; c >= 8; --c)
     if (fits(c)) return c;
   return 0;
+}
+
+// What stays free on the device after a table is allocated: room for proving keys (k = 13: 0.34 GB, k = 19: 11 GB) and prover
+// workspaces (0.5 GB per stream at k = 13, 16 - 20 streams; several GB each at k = 19) -- an eighth of the device, at least 24 GB
+// (ZKFHE_TABLE_RESERVE_GB overrides).
+size_t table_reserve_bytes(size_t total_b) {
+  if (const char *r = getenv("ZKFHE_TABLE_RESERVE_GB")) return (size_t)(atof(r) * 1073741824.0);
+  const size_t eighth = total_b / 8, floor_b = (size_t)24 << 30;
+  return eighth > floor_b ? eighth : floor_b;
 }
 
 BiasArg table_bias(int c, int W) {
@@ -1176,7 +1211,7 @@ BiasArg table_bias(int c, int W) {
   return B;
 }
 
-int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t col_stride, size_t n_cols, G1Affine *out) {
+int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_t col_stride, size_t n_cols, void *out, bool xyzz) {
   const size_t n = basis->n;
   const int c = basis->mc, W = basis->mw;
   // n_part | col_next | adds
@@ -1228,7 +1263,8 @@ int msm_table(zkfhe_ctx *ctx, const zkfhe_basis *basis, const Fr *scalars, size_
       fprintf(stderr, "[msm_table] cols %zu  chunks/col %zu  grid %zu  visits/col avg %.1f max %u\n", n_cols, cpc, grid, (double)sum / n_cols, mx);
     }
   }
-  k_msm_table_fold<<<(unsigned)n_cols, 512, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
+  if (xyzz) k_msm_table_fold<true><<<(unsigned)n_cols, 512, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
+  else k_msm_table_fold<false><<<(unsigned)n_cols, 512, 0, ctx->stream>>>((const G1X *)p0, (unsigned)max_part, L, n_part, col_next, out);
   ZK_LAUNCH_CHECK(ctx);
   if (ctx->prof_on) {
     unsigned long long h = 0;
@@ -1292,24 +1328,35 @@ int zk_basis_create_scaled(zkfhe_ctx *ctx, const zkfhe_g1_affine *bases_host, si
   // a digit-multiple table (k_msm_table): every call against this basis becomes a plain sum of table points.  It is an
   // accelerator, not a requirement: on a device that does not have the room (other tenants, many SRS alive) the width drops
   // until it fits, and without any table the calls take the bucket pipeline
+  const int mc_budget = mc;
+  bool narrowed = false;
   for (; mc >= 8; --mc) {
     const int mw = (255 + mc - 1) / mc;
     const size_t bytes = (n * (size_t)mw << (mc - 1)) * sizeof(G1Affine);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + total_b / 8) continue;   // an eighth of the device stays free for proving keys and workspaces
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + table_reserve_bytes(total_b)) {
+      narrowed = true;   // the device does not have the room right now (other keys, other tenants): the next narrower width
+      continue;
+    }
     e = hipMalloc((void **)&b->mult, bytes);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       b->mult = nullptr;
+      narrowed = true;
       continue;
     }
     b->mc = mc;
     b->mw = mw;
+    b->mult_bytes = bytes;
     k_basis_multiples<<<zk_blocks(n * (size_t)mw, 64), 64, 0, ctx->stream>>>((const G1Affine *)tmp, n, mc, mw, b->mult);
     ZK_LAUNCH_CHECK(ctx);
     break;
   }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  b->narrowed = narrowed && b->mc < mc_budget;
+  if (getenv("ZKFHE_VERBOSE"))
+    fprintf(stderr, "[zkfhe] basis n = %zu: digit-multiple table %d bits, %.1f GB resident%s\n", n, b->mc, (double)b->mult_bytes / 1073741824.0,
+            b->narrowed ? " (narrower than the budget allows: the device did not have the room)" : (b->mc ? "" : " (none: bucket pipeline)"));
   *out = b;
   return ZKFHE_OK;
 }
@@ -1332,11 +1379,24 @@ int zkfhe_msm_batch(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *sc
   return zk_msm_batch_strided(ctx, basis, scalars_dev, basis ? basis->n : 0, n_cols, out_dev);
 }
 
+// The same sums left in the accumulator form (XYZZ, 128 B each, x = X / ZZ, y = Y / ZZZ, identity ZZ = 0): the last kernel of the
+// call skips its field inversion -- one lane, 40 us, at the end of every call -- and the caller normalises the points of a whole
+// Fiat-Shamir round with ONE inversion (zkfhe_g1_xyzz_to_affine, host).  halo2 does the same one level up: `commit_lagrange`
+// returns projective points and create_proof batch-normalises a round's commitments.
+int zkfhe_msm_batch_xyzz(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t n_cols, zkfhe_g1_xyzz *out_dev) {
+  return zk_msm_batch_strided_form(ctx, basis, scalars_dev, basis ? basis->n : 0, n_cols, out_dev, true);
+}
+
 }  // extern "C"
 
 // Column c of the call holds its basis->n scalars at scalars_dev + c * col_stride: col_stride > n selects a row range of longer
 // columns (the point-range shard of one rank, comm.hip) without copying it out.
 int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev) {
+  return zk_msm_batch_strided_form(ctx, basis, scalars_dev, col_stride, n_cols, out_dev, false);
+}
+
+// out_dev: n_cols affine points (64 B each) or, with xyzz, n_cols accumulator-form sums (zkfhe_g1_xyzz, 128 B each)
+int zk_msm_batch_strided_form(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, void *out_dev, bool xyzz) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, basis != nullptr);
   if (!n_cols) return ZKFHE_OK;
@@ -1348,7 +1408,7 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
   static const char *wide_env = getenv("ZKFHE_TABLE_WIDE");   // 1 / 0: force the choice for calls of many columns
   const bool wide = wide_env ? wide_env[0] == '1' : basis->mw <= basis->windows + 2;
   if (basis->mult && (wide || n_cols <= 8))
-    return msm_table(ctx, basis, (const Fr *)scalars_dev, col_stride, n_cols, (G1Affine *)out_dev);
+    return msm_table(ctx, basis, (const Fr *)scalars_dev, col_stride, n_cols, out_dev, xyzz);
   const int c = basis->c, W = basis->windows;
   const unsigned K = 1u << (c - 1), K1 = K + 1;
   const size_t col_entries = n * (size_t)W;
@@ -1404,19 +1464,11 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
     k_msm_cscan<<<zk_blocks(n_cols, 64), 64, 0, ctx->stream>>>(chist, NB, n_cols, coff, ccursor);
     ZK_LAUNCH_CHECK(ctx);
     const size_t cs_lds = ((size_t)3 * NB + (size_t)CS_SCALARS * W) * sizeof(unsigned);
-    static bool cs_attr = false;
-    if (!cs_attr && cs_lds > 48 * 1024) {
-      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_cscatter, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      cs_attr = true;
-    }
+    if (cs_lds > 48 * 1024) ZK_CK(zk_func_max_lds(ctx, (const void *)k_msm_cscatter, 64 * 1024));
     k_msm_cscatter<<<(unsigned)(n_cols * cs_chunks), CS_THREADS, cs_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, cs_chunks, c, W, L, NB, ccursor, stage,
                                                                                          stage_stride);
     ZK_LAUNCH_CHECK(ctx);
-    static bool fine_attr = false;
-    if (!fine_attr) {
-      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_fine, hipFuncAttributeMaxDynamicSharedMemorySize, FINE_TILE * sizeof(unsigned)));
-      fine_attr = true;
-    }
+    ZK_CK(zk_func_max_lds(ctx, (const void *)k_msm_fine, (int)(FINE_TILE * sizeof(unsigned))));
     k_msm_fine<<<(unsigned)(n_cols * NB), FINE_THREADS, FINE_TILE * sizeof(unsigned), ctx->stream>>>(coff, NB, L, stage, stage_stride, col_entries, K1, off, entries);
     ZK_LAUNCH_CHECK(ctx);
   } else {
@@ -1429,11 +1481,9 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
     const unsigned chunks_per_col = (unsigned)((n + SORT_CHUNK - 1) / SORT_CHUNK);
     const unsigned grid = (unsigned)(n_cols * chunks_per_col);
     const size_t sort_lds = (size_t)K1 * sizeof(unsigned);
-    static bool sort_attr = false;
-    if (!sort_attr && sort_lds > 48 * 1024) {
-      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      sort_attr = true;
+    if (sort_lds > 48 * 1024) {
+      ZK_CK(zk_func_max_lds(ctx, (const void *)k_msm_hist, 160 * 1024));
+      ZK_CK(zk_func_max_lds(ctx, (const void *)k_msm_scatter, 160 * 1024));
     }
     k_msm_hist<<<grid, SORT_THREADS, sort_lds, ctx->stream>>>((const Fr *)scalars_dev, col_stride, n, chunks_per_col, c, W, hist, K1);
     ZK_LAUNCH_CHECK(ctx);
@@ -1500,13 +1550,15 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
       k_msm_marginals<<<zk_blocks(waves * 64, 256), 256, 0, ctx->stream>>>(buckets, K, n_cols, Lc, A, 64, marg);
       ZK_LAUNCH_CHECK(ctx);
     }
-    k_msm_weighted<<<(unsigned)n_cols, 64 * ((A + 63) / 64 + 1), 0, ctx->stream>>>(marg, K, (G1Affine *)out_dev);
+    if (xyzz) k_msm_weighted<true><<<(unsigned)n_cols, 64 * ((A + 63) / 64 + 1), 0, ctx->stream>>>(marg, K, out_dev);
+    else k_msm_weighted<false><<<(unsigned)n_cols, 64 * ((A + 63) / 64 + 1), 0, ctx->stream>>>(marg, K, out_dev);
     ZK_LAUNCH_CHECK(ctx);
     (void)per_col;
     return ZKFHE_OK;
   }
   if (K < 64) {
-    k_msm_small<<<(unsigned)n_cols, 64, 0, ctx->stream>>>(buckets, K, (G1Affine *)out_dev);
+    if (xyzz) k_msm_small<true><<<(unsigned)n_cols, 64, 0, ctx->stream>>>(buckets, K, out_dev);
+    else k_msm_small<false><<<(unsigned)n_cols, 64, 0, ctx->stream>>>(buckets, K, out_dev);
     ZK_LAUNCH_CHECK(ctx);
     return ZKFHE_OK;
   }
@@ -1515,12 +1567,30 @@ int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_f
 
 extern "C" {
 
-int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots, zkfhe_g1_affine *out_dev) {
+static int msm_sparse_form(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots, void *out_dev, bool xyzz) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, basis != nullptr && basis->mult != nullptr && terms_dev != nullptr && out_dev != nullptr && n_slots > 0 && n_slots <= 65535 && n_terms <= 4096);
-  k_msm_sparse<<<(unsigned)n_slots, 64, 0, ctx->stream>>>(terms_dev, (unsigned)n_terms, basis->mult, basis->mc, basis->mw, table_bias(basis->mc, basis->mw),
-                                                     (G1Affine *)out_dev);
+  if (xyzz)
+    k_msm_sparse<true><<<(unsigned)n_slots, 64, 0, ctx->stream>>>(terms_dev, (unsigned)n_terms, basis->mult, basis->mc, basis->mw, table_bias(basis->mc, basis->mw), out_dev);
+  else
+    k_msm_sparse<false><<<(unsigned)n_slots, 64, 0, ctx->stream>>>(terms_dev, (unsigned)n_terms, basis->mult, basis->mc, basis->mw, table_bias(basis->mc, basis->mw), out_dev);
   ZK_LAUNCH_CHECK(ctx);
+  return ZKFHE_OK;
+}
+
+int zkfhe_msm_sparse(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots, zkfhe_g1_affine *out_dev) {
+  return msm_sparse_form(ctx, basis, terms_dev, n_terms, n_slots, out_dev, false);
+}
+int zkfhe_msm_sparse_xyzz(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_sparse_term *terms_dev, size_t n_terms, size_t n_slots, zkfhe_g1_xyzz *out_dev) {
+  return msm_sparse_form(ctx, basis, terms_dev, n_terms, n_slots, out_dev, true);
+}
+
+// Accumulator-form sums -> affine points, on the host: Montgomery's trick over the ZZZ of the whole array (3 products per point and
+// ONE Bernstein-Yang inversion), then x = X (ZZ / ZZZ)^2, y = Y / ZZZ; ZZ = 0 -> the identity (0, 0).  In and out are raw Montgomery
+// coordinates (what the kernels store and zkfhe_msm_batch returns).  in == out element-wise aliasing is not supported.
+int zkfhe_g1_xyzz_to_affine(const zkfhe_g1_xyzz *in, size_t n, zkfhe_g1_affine *out) {
+  if ((!in || !out) && n) return ZKFHE_EINVAL;
+  g1x_normalize_batch((const G1X *)in, n, (G1Affine *)out);
   return ZKFHE_OK;
 }
 
@@ -1530,6 +1600,13 @@ int zkfhe_basis_table_bits(const zkfhe_basis *basis, int *wide_calls) {
   const char *wide_env = getenv("ZKFHE_TABLE_WIDE");
   if (wide_calls) *wide_calls = basis && basis->mult && (wide_env ? wide_env[0] == '1' : basis->mw <= basis->windows + 2) ? 1 : 0;
   return basis && basis->mult ? basis->mc : 0;
+}
+
+// bytes of the basis' digit-multiple table resident in HBM; *narrowed (optional) = 1 when the table is narrower than the budget
+// would have allowed because the device did not have the room when the basis was made
+size_t zkfhe_basis_table_bytes(const zkfhe_basis *basis, int *narrowed) {
+  if (narrowed) *narrowed = basis && basis->narrowed ? 1 : 0;
+  return basis ? basis->mult_bytes : 0;
 }
 
 int zkfhe_g1_add(zkfhe_ctx *ctx, const zkfhe_g1_affine *a, const zkfhe_g1_affine *b, zkfhe_g1_affine *out, size_t n) {

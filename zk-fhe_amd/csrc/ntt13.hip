@@ -390,11 +390,7 @@ int zk_launch_tile_13(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsigne
     }
     it = ctx->tw13.emplace((const void *)a.tw, (void *)p).first;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt13, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS13));
-    attr_set = true;
-  }
+  ZK_CK(zk_func_max_lds(ctx, (const void *)k_ntt13, (int)LDS13));
   Tile13Args A;
   A.t = a;
   A.tw = (const LwMem *)it->second;

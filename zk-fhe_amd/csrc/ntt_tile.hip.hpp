@@ -252,11 +252,7 @@ template <int LOGN>
 inline int launch_tile(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsigned cols) {
   constexpr int N = 1 << LOGN;
   constexpr size_t lds_bytes = (size_t)(N + N / 8) * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ZK_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_tile<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  ZK_CK(zk_func_max_lds(ctx, (const void *)k_ntt_tile<LOGN>, (int)lds_bytes));
   dim3 grid(tiles, cols);
   zk_prof_begin(ctx);
   k_ntt_tile<LOGN><<<grid, N / tile_ept<LOGN>(), lds_bytes, ctx->stream>>>(a);

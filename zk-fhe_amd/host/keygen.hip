@@ -540,6 +540,17 @@ int zkfhe_bfv_pk_info(const zkfhe_bfv_pk *pk, uint8_t vk_digest[32], uint32_t *n
   return ZKFHE_OK;
 }
 
+// The per-public-key transcript cache of this proving key (prefix_cache.hpp): capacity >= 0 sets the number of public keys
+// remembered (0 = off, entries beyond it are dropped, at most 64), negative leaves it; hits / misses / entries (each optional)
+// receive the counters since the key was made.
+int zkfhe_bfv_pk_prefix_cache(const zkfhe_bfv_pk *pk_c, int capacity, uint64_t *hits, uint64_t *misses, uint64_t *entries) {
+  if (!pk_c) return ZKFHE_EINVAL;
+  zkfhe_bfv_pk *pk = const_cast<zkfhe_bfv_pk *>(pk_c);
+  if (capacity >= 0) pk->prefix.set_capacity((size_t)capacity);
+  pk->prefix.stats(hits, misses, entries);
+  return ZKFHE_OK;
+}
+
 int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t *sigma_out) {
   if (!pk) return ZKFHE_EINVAL;
   for (size_t i = 0; i < pk->fixed_commit.size() && fixed_out; ++i) {

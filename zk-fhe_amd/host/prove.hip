@@ -23,19 +23,19 @@ int alloc_witness_buffers(zkfhe_ctx *ctx, const zkfhe_bfv_pk *pk, Workspace *ws)
     const CircuitConfig &c = pk->cfg;
     const size_t max_items = (size_t)c.n_advice() + c.n_fixed() + 2 + c.n_perm() + c.n_chunks() + 3 * c.n_lookup;
     ws->out_pts_cap = std::max<size_t>(ws->n_all, c.n_perm()) + 16;
-    ws->out_ev_off = ws->out_pts_cap * sizeof(G1Affine);
+    ws->out_ev_off = ws->out_pts_cap * PT_SLOT;
     ws->out_ev_cap = max_items * 4;
     ws->out_flag_off = ws->out_ev_off + ws->out_ev_cap * 32;
     ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_out, ws->out_flag_off + 256, hipHostMallocDefault));
     memset(ws->host_out, 0, ws->out_flag_off + 256);
   }
-  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * sizeof(G1Affine), hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_pts, ((size_t)pk->cfg.n_gate0 + 1) * PT_SLOT, hipHostMallocDefault));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_pts, hipEventDisableTiming | hipEventBlockingSync));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_rand, hipEventDisableTiming | hipEventBlockingSync));
   ZK_HIP(ctx, hipEventCreateWithFlags(&ws->ev_early, hipEventDisableTiming | hipEventBlockingSync));
-  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_early, ((size_t)pk->cfg.n_advice() + 2 * pk->cfg.n_lookup + 16) * sizeof(G1Affine), hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_early, ((size_t)pk->cfg.n_advice() + 2 * pk->cfg.n_lookup + 16) * PT_SLOT, hipHostMallocDefault));
   ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_early_err, 64, hipHostMallocDefault));
-  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_rand_pt, sizeof(G1Affine), hipHostMallocDefault));
+  ZK_HIP(ctx, hipHostMalloc((void **)&ws->host_rand_pt, PT_SLOT, hipHostMallocDefault));
   if (zkfhe_ctx_create(ctx->device, nullptr, &ws->aux)) return zk_fail_msg(ctx, ZKFHE_EHIP, std::string("auxiliary context: ") + zkfhe_last_error(nullptr));
   return ZKFHE_OK;
 }
@@ -578,7 +578,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     G1Affine *pt_dev = (G1Affine *)ws->points.p + std::max<size_t>(ws->n_all, cfg.n_perm());
     CK(rng_fill(aux->stream, ctr_rand, 0, rand_dev, n, n, 1));
     (void)pt_dev;   // the commitment is stored by the MSM's last kernel into pinned memory: no copy command
-    if (int rc = zkfhe_msm_batch(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_affine *)ws->host_rand_pt))
+    if (int rc = zkfhe_msm_batch_xyzz(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_xyzz *)ws->host_rand_pt))
       return zk_fail_msg(ctx, rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(aux));
     ZK_HIP(ctx, hipEventRecord(ws->ev_rand, aux->stream));
   }
@@ -588,10 +588,24 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   tr.common_scalar(pk->vk_digest);
   // the 5121 public inputs are hashed on a helper thread, started as soon as they are known: it runs beside the phase-0
   // precomputation, upload and commitment (a Poseidon sponge is one sequential chain of 2561 permutations here)
+  // The first 2 N of them are pk0 | pk1 (examples/bfv.rs:118-119), the same for every encryption under one public key: the
+  // transcript state behind them is kept per key (prefix_cache.hpp), and a proof that finds its key there starts from it --
+  // 1 024 of the 2 561 permutations at k = 13.
   const auto on_public = [&](const std::vector<Cell> &pub) {
     instances.reserve(pub.size());
     for (const Cell &c : pub) instances.push_back(c.value);
-    tr.common_scalars_async(instances);
+    const size_t n_key = std::min<size_t>(instances.size(), 2 * (size_t)pk->prm.N);
+    Transcript::State mid;
+    if (!n_key || !pk->prefix.capacity()) {
+      tr.common_scalars_async(instances);
+    } else if (pk->prefix.lookup(instances.data(), n_key, mid)) {
+      tr.restore(mid);
+      tr.common_scalars_async(std::vector<U256>(instances.begin() + (long)n_key, instances.end()));
+    } else {
+      PrefixCache *cache = &pk->prefix;
+      std::vector<U256> key(instances.begin(), instances.begin() + (long)n_key);
+      tr.common_scalars_async_marked(instances, n_key, [cache, key](const Transcript::State &st) { cache->insert(key.data(), key.size(), st); });
+    }
   };
   // machine-word phase 0 (bfv_phase0_fast.hpp) for every input in its domain; anything else goes through the line-by-line
   // restatement of the reference, which also words the errors
@@ -641,7 +655,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   } else {
     // the commitment's points come back through an event; the phase-1 gadget launches queue up behind the MSM
     CK(alloc_witness_buffers(ctx, pk, ws));
-    CK(srs_msm(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, ws->host_pts));   // stored into pinned memory by the MSM itself
+    CK(srs_msm_pts(ctx, srs, p0_basis, ws->adv_l.fr(), cfg.n_gate0, ws->host_pts));   // stored into pinned memory by the MSM itself
     CK(srs_record(ctx, srs, ws->ev_pts));   // sharded: behind the all-gather on the communicator's stream, which the gadget launches below overlap
     CK(g1.launch(st));
     if (early_p1) {
@@ -659,12 +673,12 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       CK(zkw::lookup_permute(ctx, ws->adv_l.fr() + (size_t)cfg.adv_lookup0() * n, n, (unsigned)u, cfg.n_lookup, ws->la_l.fr(), ws->ls_l.fr(), err_dev));
       CK(rng_fill(ctx->stream, ctr_lk, 2 * nbl0, ws->la_l.fr() + u, nbl0, n, cfg.n_lookup));
       CK(rng_fill(ctx->stream, ctr_lk + nbl0, 2 * nbl0, ws->ls_l.fr() + u, nbl0, n, cfg.n_lookup));
-      CK(srs_msm(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, ws->host_early));
+      CK(srs_msm_pts(ctx, srs, small_basis, ws->adv_l.fr() + (size_t)cfg.n_gate0 * n, n_early, ws->host_early));
       CK(srs_record(ctx, srs, ws->ev_early));
     }
     ZK_HIP(ctx, hipEventSynchronize(ws->ev_pts));
     pts.resize(cfg.n_gate0);
-    for (unsigned c = 0; c < cfg.n_gate0; ++c) pts[c] = point_canon(ws->host_pts[c]);
+    points_canon(srs, ws->host_pts, cfg.n_gate0, pts.data());
   }
   trace.mark("commit phase 0 (GPU)");
   for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = pts[c]);
@@ -701,27 +715,33 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       if (np + cfg.n_rlc > ws->out_pts_cap)
         return zk_fail_msg(ctx, ZKFHE_EINVAL, "early phase-1 commitment: correction points do not fit the workspace (set ZKFHE_EARLY_P1=0)");
       (void)n_adv1;
-      G1Affine *fix_dev = ws->out_pts();   // pinned: the correction points are read by the host right below
+      uint8_t *fix_dev = ws->out_pts();   // pinned: the correction points are read by the host right below
+      const size_t ps = pt_stride(srs);
       if (np && sparse) {
         // a dozen non-zero cells: one wave per correction column over the digit-multiple table
         STAGE(terms_dev, zkfhe_sparse_term, ws, terms.data(), terms.size() * sizeof(zkfhe_sparse_term));
         CK(flush_staged(ctx, ws));
-        CK(zkfhe_msm_sparse(ctx, srs->g_lagrange, terms_dev, terms.size(), np, (zkfhe_g1_affine *)fix_dev));
+        CK(zkfhe_msm_sparse_xyzz(ctx, srs->g_lagrange, terms_dev, terms.size(), np, (zkfhe_g1_xyzz *)fix_dev));   // sparse => one GPU => accumulator-form slots
       } else if (np) {
-        CK(srs_msm(ctx, srs, srs->g_lagrange, patch_cols, np, fix_dev));
+        CK(srs_msm_pts(ctx, srs, srs->g_lagrange, patch_cols, np, fix_dev));
       }
-      if (cfg.n_rlc) CK(srs_msm(ctx, srs, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, cfg.n_rlc, fix_dev + np));
+      if (cfg.n_rlc) CK(srs_msm_pts(ctx, srs, srs->g_lagrange, ws->adv_l.fr() + (size_t)cfg.adv_rlc0() * n, cfg.n_rlc, fix_dev + np * ps));
       CK(srs_join(ctx, srs, false));
       ZK_HIP(ctx, zk_wait(ctx));   // everything queued so far, the early commitment (ev_early) included
-      const G1Affine *fix = fix_dev;
       if (*ws->host_early_err) return zk_fail_msg(ctx, ZKFHE_EINVAL, "lookup input not in table: a range check of the witness fails");
-      for (size_t t = 0; t < np; ++t) {   // early commitment + correction, on the host (at most a handful of additions)
-        G1Affine &e = ws->host_early[plan.columns[t]];
-        zk::G1X acc = zk::g1x_from_affine(e);
-        zk::g1x_add_affine(acc, fix[t], false);
-        e = zk::g1x_to_affine(acc);
+      // early commitment + correction, on the host (at most a handful of additions), in the form the slots hold; the sums are
+      // normalised with the rest of the round below
+      for (size_t t = 0; t < np; ++t) {
+        if (srs->sharded()) {
+          G1Affine &e = ((G1Affine *)ws->host_early)[plan.columns[t]];
+          zk::G1X acc = zk::g1x_from_affine(e);
+          zk::g1x_add_affine(acc, ((const G1Affine *)fix_dev)[t], false);
+          e = zk::g1x_to_affine(acc);
+        } else {
+          zk::g1x_add(((zk::G1X *)ws->host_early)[plan.columns[t]], ((const zk::G1X *)fix_dev)[t]);
+        }
       }
-      for (unsigned j = 0; j < cfg.n_rlc; ++j) ws->host_early[cfg.adv_rlc0() - cfg.n_gate0 + j] = fix[np + j];
+      for (unsigned j = 0; j < cfg.n_rlc; ++j) memcpy(ws->host_early + (size_t)(cfg.adv_rlc0() - cfg.n_gate0 + j) * ps, fix_dev + (np + j) * ps, ps);
     }
     trace.mark("gpu phase 1 (enqueue)");
   }
@@ -742,13 +762,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   const bool merged = !host_witness && cfg.n_lookup > 0;   // permuted lookup columns committed together with the advice
   if (early_p1) {
     const size_t n_adv1 = cfg.n_advice() - cfg.n_gate0;
+    pts.resize(n_adv1 + 2 * (size_t)cfg.n_lookup);
+    points_canon(srs, ws->host_early, pts.size(), pts.data());   // one inversion for the round: advice | permuted inputs | permuted tables
+    la_commit.assign(pts.begin() + (long)n_adv1, pts.begin() + (long)(n_adv1 + cfg.n_lookup));
+    ls_commit.assign(pts.begin() + (long)(n_adv1 + cfg.n_lookup), pts.end());
     pts.resize(n_adv1);
-    for (size_t c = 0; c < n_adv1; ++c) pts[c] = point_canon(ws->host_early[c]);
-    la_commit.resize(cfg.n_lookup), ls_commit.resize(cfg.n_lookup);
-    for (unsigned i = 0; i < cfg.n_lookup; ++i) {
-      la_commit[i] = point_canon(ws->host_early[n_adv1 + i]);
-      ls_commit[i] = point_canon(ws->host_early[n_adv1 + cfg.n_lookup + i]);
-    }
   } else if (merged) {
     // Single-expression lookups do not use theta, so the permuted columns can be built before the advice commitment is
     // hashed: one MSM call over [phase-1 advice | la | ls] (contiguous in all_l) instead of two, same points, same
@@ -898,7 +916,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   if (early_rand) {
     ZK_HIP(ctx, hipEventSynchronize(ws->ev_rand));
     ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws->ev_rand, 0));   // later reads of rand_c on the main stream
-    tr.write_point(point_canon(*ws->host_rand_pt));
+    AffinePoint rp;
+    points_canon(srs, ws->host_rand_pt, 1, &rp);
+    tr.write_point(rp);
   } else {
     CK(rng_fill(ctx->stream, ctr_rand, 0, rand_c, n, n, 1));
     std::vector<AffinePoint> rand_commit;

@@ -17,6 +17,7 @@
 #include "prover_kernels.hip.hpp"
 #include "shplonk.hpp"
 #include "transcript.hpp"
+#include "prefix_cache.hpp"
 #include "vk.hpp"
 
 using namespace zkhost;
@@ -61,6 +62,18 @@ static inline int srs_msm(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basi
   if (!srs->sharded()) return zkfhe_msm_batch(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_affine *)dev_out);
   // the collective runs on the communicator's stream: srs_join / srs_record before anything reads dev_out
   return zkfhe_msm_batch_sharded_async(ctx, srs->comm, basis, (const zkfhe_fr *)(cols + srs->lo), (size_t)1 << srs->k, n_cols, (zkfhe_g1_affine *)dev_out);
+}
+
+// Commitments the HOST reads (pinned result blocks of the workspace).  A slot is PT_SLOT = 128 bytes.  One GPU: the MSM stores
+// the accumulator-form sum (zkfhe_g1_xyzz) and the host normalises all points of a Fiat-Shamir round with one field inversion
+// (points_canon) -- halo2's create_proof batch-normalises a round's commitments the same way, and
+// the 40 us inversion in one GPU lane at the end of every MSM call is gone.  Sharded SRS: the all-gathered partials are affine
+// and so is their sum: those results are packed at a 64-byte stride in the same blocks (pt_stride).
+static constexpr size_t PT_SLOT = sizeof(zk::G1X);
+static inline size_t pt_stride(const zkfhe_srs *srs) { return srs->sharded() ? sizeof(G1Affine) : sizeof(zk::G1X); }
+static inline int srs_msm_pts(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, void *pinned_out) {
+  if (!srs->sharded()) return zkfhe_msm_batch_xyzz(ctx, basis, (const zkfhe_fr *)cols, n_cols, (zkfhe_g1_xyzz *)pinned_out);
+  return zkfhe_msm_batch_sharded_async(ctx, srs->comm, basis, (const zkfhe_fr *)(cols + srs->lo), (size_t)1 << srs->k, n_cols, (zkfhe_g1_affine *)pinned_out);
 }
 
 struct DevBuf {
@@ -112,18 +125,18 @@ struct Workspace {
   // device-visible block -- no device-to-host copy commands: [points | evaluations | flags]
   uint8_t *host_out = nullptr;
   size_t out_pts_cap = 0, out_ev_off = 0, out_ev_cap = 0, out_flag_off = 0;
-  G1Affine *out_pts() const { return (G1Affine *)host_out; }
+  uint8_t *out_pts() const { return host_out; }   // out_pts_cap slots of PT_SLOT bytes (prover_internal.hpp "Commitments the HOST reads")
   U256 *out_ev() const { return (U256 *)(host_out + out_ev_off); }
   int *out_flags() const { return (int *)(host_out + out_flag_off); }   // [0] permutation closes, [1] lookups close, [2] lookup input in table
-  G1Affine *host_pts = nullptr; // pinned: commitments copied back asynchronously
+  uint8_t *host_pts = nullptr; // pinned: the phase-0 commitments (PT_SLOT bytes each), read after ev_pts
   hipEvent_t ev_pts = nullptr;
   // the random polynomial of the vanishing argument depends on no challenge: it is uploaded and committed at the start of
   // the proof on an auxiliary context (own stream, scratch and tickets) beside the phase-0 / witness work
   zkfhe_ctx *aux = nullptr;
-  G1Affine *host_rand_pt = nullptr;  // pinned: the commitment
+  uint8_t *host_rand_pt = nullptr;  // pinned: the commitment (one PT_SLOT)
   hipEvent_t ev_rand = nullptr;
   // early phase-1 commitment (everything that does not depend on the phase-1 challenge): points + lookup error flag, pinned
-  G1Affine *host_early = nullptr;
+  uint8_t *host_early = nullptr;   // PT_SLOT bytes per point
   int *host_early_err = nullptr;
   hipEvent_t ev_early = nullptr;
   DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
@@ -247,12 +260,24 @@ static inline int commit_cols(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_
   return ZKFHE_OK;
 }
 
+// n points of a pinned result block (written by srs_msm_pts / zkfhe_msm_sparse_xyzz, complete) -> canonical affine coordinates
+static inline void points_canon(const zkfhe_srs *srs, const void *block, size_t n, AffinePoint *out) {
+  if (srs->sharded()) {
+    const G1Affine *a = (const G1Affine *)block;
+    for (size_t i = 0; i < n; ++i) out[i] = point_canon(a[i]);
+    return;
+  }
+  std::vector<G1Affine> a(n);
+  zk::g1x_normalize_batch((const zk::G1X *)block, n, a.data());
+  for (size_t i = 0; i < n; ++i) out[i] = point_canon(a[i]);
+}
+
 static inline int commit_cols_out(zkfhe_ctx *ctx, const zkfhe_srs *srs, const zkfhe_basis *basis, const Fr *cols, size_t n_cols, Workspace *ws, std::vector<AffinePoint> &out) {
   if (!ws->host_out || n_cols > ws->out_pts_cap) return commit_cols(ctx, srs, basis, cols, n_cols, (G1Affine *)ws->points.p, out);
-  CK(srs_msm(ctx, srs, basis, cols, n_cols, ws->out_pts()));
+  CK(srs_msm_pts(ctx, srs, basis, cols, n_cols, ws->out_pts()));
   CK(srs_join(ctx, srs, true));
   out.resize(n_cols);
-  for (size_t i = 0; i < n_cols; ++i) out[i] = point_canon(ws->out_pts()[i]);
+  points_canon(srs, ws->out_pts(), n_cols, out.data());
   return ZKFHE_OK;
 }
 
@@ -284,5 +309,7 @@ struct zkfhe_bfv_pk {
   // may prove concurrently against the same key (everything above is read-only after keygen)
   std::map<uint64_t, Workspace *> workspaces;   // keyed by zkfhe_ctx::uid (never reused), not by address
   std::mutex mu;
+  // transcript state after `vk digest | pk0 | pk1`, per public key seen (prefix_cache.hpp); shared by the proofs in flight
+  PrefixCache prefix;
 };
 

@@ -1,5 +1,7 @@
 // The structured reference string on one MI355X (include/zkfhe.h "SRS"): replaces halo2-scaffold `gen_srs` /
 // ParamsKZG::setup (third-party, reached from reference examples/bfv.rs:311; README.md:34 "unsafe" seeded setup).
+#include <unistd.h>
+
 #include "prover_internal.hpp"
 #include "srs_secret.hpp"
 
@@ -125,16 +127,21 @@ int zkfhe_srs_save(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, srs && path);
   const size_t n = (size_t)1 << srs->k;
-  if (srs->sharded() || srs->g_host.size() != n || srs->gl_host.size() != n) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: a sharded SRS holds only a slice of the points");
+  if (srs->sharded()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: a sharded SRS holds only a slice of the points");
+  if (srs->g_host.size() != n || srs->gl_host.size() != n)
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: this SRS keeps no host copy of its points (made over a communicator); save the one made without");
   if (!srs->have_g2) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: the SRS has no G2 half (zkfhe_srs_set_g2)");
-  const std::string tmp = std::string(path) + ".tmp";
+  // written aside under a name of this process' own and renamed into place: two ranks (or two CLI runs) that both find the file
+  // missing and derive it at once never write into each other's temporary, and a reader sees the old file, none, or a whole one
+  static std::atomic<unsigned> serial{0};
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("cannot write ") + tmp);
   const uint32_t k = srs->k;
   bool ok = fwrite(&k, 4, 1, f) == 1 && fwrite(srs->g_host.data(), 64, n, f) == n && fwrite(srs->gl_host.data(), 64, n, f) == n &&
             fwrite(srs->g2_raw, 128, 1, f) == 1 && fwrite(srs->sg2_raw, 128, 1, f) == 1;
   ok = (fclose(f) == 0) && ok;
-  if (!ok || rename(tmp.c_str(), path) != 0) {   // written aside and renamed: a reader never sees half a file
+  if (!ok || rename(tmp.c_str(), path) != 0) {
     remove(tmp.c_str());
     return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("writing ") + path + " failed");
   }
@@ -181,6 +188,22 @@ int zkfhe_srs_load(zkfhe_ctx *ctx, const char *path, zkfhe_srs **out) {
 int zkfhe_srs_table_bits(const zkfhe_srs *srs, int *wide_calls) {
   if (wide_calls) *wide_calls = 0;
   return srs ? zkfhe_basis_table_bits(srs->g_lagrange, wide_calls) : 0;
+}
+
+// What the digit-multiple tables of this SRS look like: bits[0] / bits[1] = digit width of the monomial (g) and Lagrange halves
+// (0: none), *bytes = resident bytes of both, *narrowed = 1 when a half got a narrower table than its budget allowed because the
+// device did not have the room (another SRS alive, other tenants) -- the calls are then slower, never wrong.  All outputs optional.
+int zkfhe_srs_table_info(const zkfhe_srs *srs, int bits[2], uint64_t *bytes, int *narrowed) {
+  if (!srs) return ZKFHE_EINVAL;
+  int n0 = 0, n1 = 0;
+  const size_t b0 = zkfhe_basis_table_bytes(srs->g, &n0), b1 = zkfhe_basis_table_bytes(srs->g_lagrange, &n1);
+  if (bits) {
+    bits[0] = zkfhe_basis_table_bits(srs->g, nullptr);
+    bits[1] = zkfhe_basis_table_bits(srs->g_lagrange, nullptr);
+  }
+  if (bytes) *bytes = (uint64_t)b0 + (uint64_t)b1;
+  if (narrowed) *narrowed = (n0 | n1) ? 1 : 0;
+  return ZKFHE_OK;
 }
 
 int zkfhe_srs_destroy(zkfhe_ctx *ctx, zkfhe_srs *srs) {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -208,6 +209,41 @@ class Transcript {
     }
     worker = std::thread([this] {
       for (const U256 &s : pending) absorb_scalar(s);
+    });
+  }
+  // The hash state between two absorptions (both hashers; the byte stream is not part of it): what common_scalars_async_marked
+  // hands to its callback and restore() takes back.  A transcript that restores the state another one had after absorbing the
+  // same values continues exactly as if it had absorbed them itself.
+  struct State {
+    Blake2b h{64, "Halo2-Transcript"};
+    pos::Sponge sp;
+  };
+  State snapshot() {
+    join();
+    return State{h, sp};
+  }
+  void restore(const State &s) {
+    join();
+    h = s.h;
+    sp = s.sp;
+  }
+  // common_scalars_async, with a callback on the helper thread after the first `mark` values: the state at that point (the
+  // prover caches it per public key -- prefix_cache.hpp).  The first `mark` values always take the single-sponge path; the rest
+  // goes to the hash service when common_scalars_async would have sent the run there.
+  void common_scalars_async_marked(std::vector<U256> v, size_t mark, std::function<void(const State &)> on_mark) {
+    join();
+    pending = std::move(v);
+    if (mark > pending.size()) mark = pending.size();
+    worker = std::thread([this, mark, on_mark] {
+      for (size_t i = 0; i < mark; ++i) absorb_scalar(pending[i]);
+      on_mark(State{h, sp});
+      const size_t rest = pending.size() - mark;
+      if (bulk_ok(rest)) {
+        sp.begin_bulk(pending.data() + mark, rest, job);
+        sp.end_bulk(job);
+      } else {
+        for (size_t i = mark; i < pending.size(); ++i) absorb_scalar(pending[i]);
+      }
     });
   }
   // a run of scalars / points written at once (the evaluations, a round's commitments): same bytes and the same sponge state as

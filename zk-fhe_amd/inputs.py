@@ -74,10 +74,12 @@ def decrypt(sk, c0, c1, q, t):
     return out
 
 
-def generate(n=1024, q=536870909, t=7, b=19, seed=0, with_secret=False):
-    """One circuit input as a dict of lists of decimal strings (big-endian), i.e. what json.dumps turns into a *.in file."""
+def generate(n=1024, q=536870909, t=7, b=19, seed=0, with_secret=False, key_seed=None):
+    """One circuit input as a dict of lists of decimal strings (big-endian), i.e. what json.dumps turns into a *.in file.
+    key_seed: draw the key pair from its own stream, so that different `seed`s give different encryptions under ONE public key
+    (the usual shape of a batch: one recipient, many messages); None = a fresh key per input from the same stream."""
     rng = np.random.default_rng(seed)
-    sk, pk = keygen(n, q, b, rng)
+    sk, pk = keygen(n, q, b, rng if key_seed is None else np.random.default_rng(key_seed))
     m = rng.integers(-(t // 2), t // 2 + 1, n, dtype=np.int64)
     ct = encrypt(pk, m, q, t, b, rng)
     cyclo = np.zeros(n + 1, dtype=np.int64)
@@ -92,6 +94,42 @@ def generate(n=1024, q=536870909, t=7, b=19, seed=0, with_secret=False):
     return out
 
 
+def config3_vector(seed, n=1024, q=536870909, t=7, b=19):
+    """One vector of SURVEY.md section 8(d) config 3 as CircuitInput JSON text: rng = numpy.random.default_rng(seed); pk0, pk1 uniform
+    in [0, Q), u uniform in {0, 1, Q-1}, m uniform centred mod T, e0 / e1 a discrete Gaussian (sigma 3.2) clipped to +-B, and
+    c0 = pk0 u + floor(Q/T) m + e0, c1 = pk1 u + e1 in Z_Q[x]/(x^N + 1) (formula checked against data/bfv/bfv.in, KAT 1).
+    Every vector has its own public key; coefficients big-endian as in the reference's files."""
+    rng = np.random.default_rng(seed)
+    pk0 = rng.integers(0, q, n, dtype=np.int64)
+    pk1 = rng.integers(0, q, n, dtype=np.int64)
+    u = rng.choice(np.array([0, 1, q - 1], dtype=np.int64), n)
+    m = rng.choice(np.array(list(range(0, t // 2 + 1)) + [q - i for i in range(1, t // 2 + 1)], dtype=np.int64), n)
+    e = np.clip(np.rint(rng.normal(0, 3.2, (2, n))), -b, b).astype(np.int64) % q
+
+    def negacyclic(a, s):  # big-endian coefficient order in, out; s taken as residues in [0, q)
+        a, s = a[::-1], s[::-1]
+        out = np.zeros(n, dtype=np.int64)
+        for i in np.nonzero(s)[0]:
+            sh = np.empty(n, dtype=np.int64)
+            sh[i:] = a[: n - i]
+            sh[:i] = (q - a[n - i:]) % q
+            out = (out + (sh * int(s[i])) % q) % q
+        return out[::-1]
+    c0 = (negacyclic(pk0, u) + (q // t) * m % q + e[0]) % q
+    c1 = (negacyclic(pk1, u) + e[1]) % q
+    cyclo = np.zeros(n + 1, dtype=np.int64)
+    cyclo[0] = cyclo[n] = 1
+    s = lambda v: [str(int(x)) for x in v]  # noqa: E731
+    return json.dumps(dict(pk0=s(pk0), pk1=s(pk1), m=s(m), u=s(u), e0=s(e[0]), e1=s(e[1]), c0=s(c0), c1=s(c1), cyclo=s(cyclo)))
+
+
+def config3_batch(bfv_in_text, count=64, base_seed=20240613):
+    """BASELINE configs[2] / SURVEY.md section 8(d) config 3: the reference's data/bfv/bfv.in followed by count - 1 seeded vectors
+    (seeds base_seed + 1 ... base_seed + count - 1), as a list of JSON texts (bytes)."""
+    first = bfv_in_text if isinstance(bfv_in_text, bytes) else bfv_in_text.encode()
+    return [first] + [config3_vector(base_seed + i).encode() for i in range(1, count)]
+
+
 def empty(n=1024):
     """The all-zero input the reference uses for keygen (data/bfv/bfv_empty.in)."""
     return {k: ["0"] * (n + 1 if k == "cyclo" else n) for k in ("pk0", "pk1", "m", "u", "e0", "e1", "c0", "c1", "cyclo")}
@@ -104,11 +142,12 @@ def main(argv=None):
     ap.add_argument("--t", type=int, default=7)
     ap.add_argument("--b", type=int, default=19)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--key-seed", type=int, default=None, help="seed of the key pair alone: different --seed values then encrypt under one public key")
     ap.add_argument("--empty", action="store_true", help="all-zero input (keygen)")
     a = ap.parse_args(argv)
     if a.q >= 1 << 62:
         ap.error("q must be below 2^62")
-    json.dump(empty(a.n) if a.empty else generate(a.n, a.q, a.t, a.b, a.seed), sys.stdout)
+    json.dump(empty(a.n) if a.empty else generate(a.n, a.q, a.t, a.b, a.seed, key_seed=a.key_seed), sys.stdout)
     sys.stdout.write("\n")
 
 
