@@ -120,7 +120,9 @@ def main():
         inputs = [json.dumps(gen.generate(n_ring, q_mod, T, B, seed=20240613 + 1000 * seed_rank + i)).encode() for i in range(2)]
         empty = json.dumps(gen.empty(n_ring))
         zcfg = zk.bfv_auto_config(inputs[0], (n_ring, q_mod, T, B), conf["k"], transcript=args.transcript)   # halo2-base auto-configuration
+    t_srs = time.perf_counter()
     srs = zk.Srs(ctx, conf["k"], comm=comm)
+    t_srs = time.perf_counter() - t_srs   # derivation of the points + both halves' digit-multiple tables (once per process, not in the timed region)
     pk = zk.BfvProvingKey(ctx, srs, empty, (n_ring, q_mod, T, B), zcfg, replay=not big)
     seeds = [b"bench-%d-%d" % (seed_rank, i) for i in range(args.steps + args.warmup + 4)]
 
@@ -204,6 +206,7 @@ def main():
     table_bits, table_wide = srs.table_bits()
     table_info = srs.table_info()   # digit widths (monomial, Lagrange), resident GB, whether the device forced a narrower table
     table_info["budget_gb"] = float(os.environ["ZKFHE_TABLE_GB"])
+    table_info["srs_create_s"] = round(t_srs, 2)
     msm_kernel = "k_msm_table" if table_wide else "k_msm_accumulate"
     ctx.prof_enable(True)
     for _ in range(2):

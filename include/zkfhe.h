@@ -181,6 +181,11 @@ int zkfhe_comm_world(const zkfhe_comm *comm);
 int zkfhe_comm_active(const zkfhe_comm *comm);
 void zkfhe_comm_point_range(const zkfhe_comm *comm, size_t n, size_t *lo, size_t *hi);
 int zkfhe_comm_all_gather(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes);
+/* The same collective on the communicator's own stream (RCCL and one-rank communicators; the callback transport completes on the
+ * context's stream as zkfhe_comm_all_gather does): it starts behind everything queued on the context's stream so far and overlaps
+ * what is queued there next; zkfhe_comm_join orders the context's stream or the caller behind it.  Both buffers stay untouched
+ * until then. */
+int zkfhe_comm_all_gather_async(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes);
 /* basis_slice: a basis made of this rank's point range; column c's scalars for that range at scalars_dev + c * col_stride
  * (col_stride = the full column length when scalars_dev points at row lo of column 0).  out_dev[c]: the full MSM, on every rank. */
 int zkfhe_msm_batch_sharded(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev,

@@ -133,6 +133,11 @@ def _circuit(which):
         inp = json.dumps(synth_input(16, prm.Q, prm.T, prm.B, 5))
         cfg = zk.bfv_auto_config(inp, (16, prm.Q, prm.T, prm.B), 14, unusable_rows=109)
         return inp, inp, (16, prm.Q, prm.T, prm.B), cfg, 14
+    if which == "k19":   # BASELINE configs[4]: N = 16384, 60-bit Q, n = 2^19 rows -- the circuit bench.py --config k19 proves
+        from zk_fhe_amd import inputs as gen
+        N, Q = 16384, (1 << 60) - 93
+        inp = json.dumps(gen.generate(N, Q, 7, 19, seed=20240613))
+        return json.dumps(gen.empty(N)), inp, (N, Q, 7, 19), zk.bfv_auto_config(inp, (N, Q, 7, 19), 19, transcript="blake2b"), 19
     prm = C.BfvParams()
     cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
     return (open(os.path.join(G, "bfv_empty.in")).read(), open(os.path.join(G, "bfv.in")).read(), (1024, prm.Q, prm.T, prm.B),
@@ -208,6 +213,24 @@ def test_sharded_prover_ranks_share_one_gpu_same_bytes(which, world):
     assert got[0]["verified"][0], got[0]["verified"][1]
     if which == "bfv13":
         assert all(g["table_bits"][0] >= got[0]["table_bits_1gpu"][0] >= 8 for g in got)   # the table path ran on every slice
+
+
+@pytest.mark.gpu
+def test_whole_k19_proof_over_eight_ranks_equals_single_gpu():
+    """BASELINE configs[4] in the shape north_star gives it -- ONE k = 19 proof (N = 16384, 60-bit Q, 2^19 rows) made by eight ranks:
+    every rank holds an eighth of both SRS halves (point range), commits its row range of every column (bucket pipeline on a slice
+    of 2^16 points; the W partials gathered and summed), extends and evaluates the quotient for its share of the columns (the shares
+    gathered coset row by coset row), takes its slice of the 1 500 evaluations and of the SHPLONK combinations.  Here the eight ranks
+    share GPU 0 and the gathers go through gloo; on an 8-GPU node the same library path runs over RCCL.  All ranks must end with the
+    same proof, it must be the single-GPU proof byte for byte, and the verifier must accept it."""
+    got = _run_ranks(_sharded_worker, 8, "k19", timeout=2400)
+    n = 1 << 19
+    assert [g["range"] for g in got] == [(n * r // 8, n * (r + 1) // 8) for r in range(8)]
+    for g in got[1:]:
+        assert g["proof"] == got[0]["proof"] and g["inst"] == got[0]["inst"] and g["vk"] == got[0]["vk"]
+    assert got[0]["vk"] == got[0]["vk_1gpu"] and got[0]["proof"] == got[0]["proof_1gpu"]
+    assert got[0]["verified"][0], got[0]["verified"][1]
+    assert len(got[0]["inst"]) == 5 * 16384 + 1
 
 
 def _msm_worker(rank, world, port, log_n, n_cols, out):

@@ -90,3 +90,26 @@ def test_bench_eight_ranks_one_gpu_gloo():
     assert host["cpus_per_rank"] == host["usable_cpus"] / 8
     assert host["hash_mode"] == ("shared" if host["cpus_per_rank"] < 6 else "latency")
     assert d["config"]["verified"] is True and d["vs_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_bench_one_k19_proof_sharded_over_eight_ranks_gloo():
+    """bench.py --gpus 8 --mode one-proof-sharded --config k19: BASELINE configs[4] as the driver would launch it on an 8-GPU node
+    (there: one rank per GPU, RCCL), here with the eight ranks on GPU 0 over gloo -- control flow, the JSON contract (strong
+    scaling: value = proofs of the JOB per second) and a verified k = 19 proof made by eight ranks.  The rate means nothing here."""
+    env = dict(os.environ)
+    env["ZKFHE_BENCH_BACKEND"] = "gloo"
+    env["ZKFHE_TABLE_GB"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--steady-seconds", "0", "--mode", "one-proof-sharded", "--config", "k19", "--transcript", "blake2b"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["mode"] == "one-proof-sharded" and d["config"]["verified"] is True
+    assert d["metric"] == "BFV proofs/sec (k=19)" and "k=19, N=16384" in d["config"]["workload"]
+    assert abs(d["value"] - 1 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6            # one proof of the JOB per step
+    assert len(d["config"]["host_cpu_ms_per_proof_by_rank"]) == 8

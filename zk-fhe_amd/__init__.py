@@ -26,7 +26,7 @@ EXPORTS = [
     "zkfhe_basis_create", "zkfhe_basis_destroy", "zkfhe_basis_len", "zkfhe_msm_batch",
     "zkfhe_g1_add", "zkfhe_g1_mul", "zkfhe_msm_sparse", "zkfhe_msm_batch_xyzz", "zkfhe_msm_sparse_xyzz", "zkfhe_g1_xyzz_to_affine", "zkfhe_basis_has_multiples", "zkfhe_basis_table_bits", "zkfhe_basis_table_bytes", "zkfhe_srs_table_bits", "zkfhe_srs_table_info",
     "zkfhe_comm_unique_id", "zkfhe_comm_create", "zkfhe_comm_create_with_transport", "zkfhe_comm_destroy", "zkfhe_comm_rank", "zkfhe_comm_world", "zkfhe_comm_active",
-    "zkfhe_comm_point_range", "zkfhe_comm_all_gather", "zkfhe_msm_batch_sharded", "zkfhe_msm_batch_sharded_async", "zkfhe_comm_join", "zkfhe_comm_record_event", "zkfhe_srs_create_sharded",
+    "zkfhe_comm_point_range", "zkfhe_comm_all_gather", "zkfhe_comm_all_gather_async", "zkfhe_msm_batch_sharded", "zkfhe_msm_batch_sharded_async", "zkfhe_comm_join", "zkfhe_comm_record_event", "zkfhe_srs_create_sharded",
     "zkfhe_witness_poly_mul_u64", "zkfhe_host_poly_mul_u32", "zkfhe_witness_div_mod",
     "zkfhe_bfv_build_tables", "zkfhe_bfv_auto_config", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",

@@ -104,7 +104,7 @@ struct zkfhe_comm {
   // following batch, the witness kernels -- overlaps the collective.  Two gather buffers alternate: batch i + 1 may fill its
   // partials while batch i is still on the wire.
   hipStream_t aux = nullptr;
-  hipEvent_t ev_msm = nullptr, ev_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_msm = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};   // [2]: behind the last zkfhe_comm_all_gather_async
   void *buf[2] = {nullptr, nullptr};
   size_t buf_sz[2] = {0, 0};
   bool pending[2] = {false, false};
@@ -171,10 +171,10 @@ int zkfhe_comm_destroy(zkfhe_ctx *ctx, zkfhe_comm *comm) {
   if (ctx) (void)hipStreamSynchronize(ctx->stream);
   if (comm->aux) (void)hipStreamSynchronize(comm->aux);
   if (comm->nccl) rccl().CommDestroy(comm->nccl);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < 2; ++b)
     if (comm->buf[b]) (void)hipFree(comm->buf[b]);
+  for (int b = 0; b < 3; ++b)
     if (comm->ev_done[b]) (void)hipEventDestroy(comm->ev_done[b]);
-  }
   if (comm->ev_msm) (void)hipEventDestroy(comm->ev_msm);
   if (comm->aux) (void)hipStreamDestroy(comm->aux);
   if (comm->host_send) (void)hipHostFree(comm->host_send);
@@ -241,17 +241,38 @@ static int gather_on(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, voi
   return ZKFHE_OK;
 }
 
+static int comm_aux_init(zkfhe_ctx *ctx, zkfhe_comm *comm) {
+  if (comm->aux) return ZKFHE_OK;
+  ZK_HIP(ctx, hipStreamCreateWithFlags(&comm->aux, hipStreamNonBlocking));
+  ZK_HIP(ctx, hipEventCreateWithFlags(&comm->ev_msm, hipEventDisableTiming));
+  for (int b = 0; b < 3; ++b) ZK_HIP(ctx, hipEventCreateWithFlags(&comm->ev_done[b], hipEventDisableTiming | hipEventBlockingSync));
+  return ZKFHE_OK;
+}
+
+// zkfhe_comm_all_gather on the communicator's own stream: the collective starts when everything queued on the context's stream so
+// far is done and runs beside whatever the caller queues there next (the prover: the quotient of the next coset while the previous
+// coset's share is on the wire); zkfhe_comm_join orders the context's stream (or the caller) behind it.  send_dev and recv_dev must
+// stay untouched until then.  The callback transport blocks the host anyway: it completes on the context's stream as before.
+int zkfhe_comm_all_gather_async(zkfhe_ctx *ctx, zkfhe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, comm != nullptr && send_dev != nullptr && recv_dev != nullptr);
+  if (!comm->has_aux()) return zkfhe_comm_all_gather(ctx, comm, send_dev, recv_dev, bytes);
+  ZK_CK(comm_aux_init(ctx, comm));
+  ZK_HIP(ctx, hipEventRecord(comm->ev_msm, ctx->stream));
+  ZK_HIP(ctx, hipStreamWaitEvent(comm->aux, comm->ev_msm, 0));
+  ZK_CK(gather_on(ctx, comm, send_dev, recv_dev, bytes, comm->aux));
+  ZK_HIP(ctx, hipEventRecord(comm->ev_done[2], comm->aux));
+  comm->last = 2;   // the stream is in order: this event is behind every collective queued before it
+  return ZKFHE_OK;
+}
+
 int zkfhe_msm_batch_sharded_async(zkfhe_ctx *ctx, zkfhe_comm *comm, const zkfhe_basis *basis_slice, const zkfhe_fr *scalars_dev, size_t col_stride,
                                   size_t n_cols, zkfhe_g1_affine *out_dev) {
   ZK_ENTER(ctx);
   ZK_ARG(ctx, comm != nullptr && basis_slice != nullptr);
   if (!n_cols) return ZKFHE_OK;
   if (!comm->has_aux()) return zkfhe_msm_batch_sharded(ctx, comm, basis_slice, scalars_dev, col_stride, n_cols, out_dev);   // complete on the context's stream
-  if (!comm->aux) {
-    ZK_HIP(ctx, hipStreamCreateWithFlags(&comm->aux, hipStreamNonBlocking));
-    ZK_HIP(ctx, hipEventCreateWithFlags(&comm->ev_msm, hipEventDisableTiming));
-    for (int b = 0; b < 2; ++b) ZK_HIP(ctx, hipEventCreateWithFlags(&comm->ev_done[b], hipEventDisableTiming | hipEventBlockingSync));
-  }
+  ZK_CK(comm_aux_init(ctx, comm));
   const int b = comm->next;
   comm->next ^= 1;
   const size_t need = (size_t)(comm->world + 1) * n_cols * sizeof(G1Affine) + 64;

@@ -1160,8 +1160,8 @@ __global__ void __launch_bounds__(64) k_msm_sparse(const zkfhe_sparse_term *__re
 
 // Window width of the digit-multiple table: the widest (<= 15 bits) whose table fits the per-basis budget.
 //   * ZKFHE_TABLE_GB unset (the library default): 48 GB, and never more than a quarter of the memory that is free on the device when
-//     the basis is made -- n = 2^13: 13-bit digits for the Lagrange half of an SRS (43 GB), 12 for the monomial half, which gets half
-//     the budget (24 GB): 67 GB per SRS.  A library that is one tenant of the device among others (a second key, another process, a
+//     the basis is made -- n = 2^13: 13-bit digits for the Lagrange half of an SRS (43 GB), 11 for the monomial half, which gets
+//     0.3 of the budget (srs.hip; 13 GB): 56 GB per SRS.  A library that is one tenant of the device among others (a second key, another process, a
 //     k = 16 key next to a k = 13 one) must not take two thirds of it by default.
 //   * ZKFHE_TABLE_GB=<GB>: an explicit budget -- the SERVICE profile of a prover that owns the GPU is 160 (bench.py sets it): 15-bit
 //     digits at n = 2^13, 17 windows x 16 384 multiples x 64 B per base point, 146 GB + 43 GB (13 bits) = 189 GB per SRS; the wide

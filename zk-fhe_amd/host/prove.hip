@@ -1042,18 +1042,41 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     qa.n_chunks = cfg.n_chunks();
     qa.rows = (unsigned)q_rows;
     const size_t npts = n * (size_t)q_rows;
-    dim3 grid((unsigned)((npts + 255) / 256), (unsigned)G);
-    zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
-    ZK_LAUNCH_CHECK(ctx);
-    zkp::k_quotient_combine<<<(unsigned)((npts + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, ws->h_ext.fr());
-    ZK_LAUNCH_CHECK(ctx);
-    if (W_sh > 1) {
-      // h_ext holds this rank's share of the quotient (the sum over ITS expression groups): gather the W shares (the group
-      // partials are dead, their buffer receives them) and add them up -- field addition is not an RCCL reduction either
-      if ((size_t)W_sh * npts * 32 > ws->partials.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many ranks for the quotient gather buffer");
-      CK(zkfhe_comm_all_gather(ctx, srs->comm, ws->h_ext.p, ws->partials.p, npts * 32));
-      zkp::k_sum_rows<<<grid_for(ctx, npts), 256, 0, ctx->stream>>>(ws->partials.fr(), W_sh, npts, ws->h_ext.fr());
+    if (W_sh == 1) {
+      qa.pt0 = 0;
+      qa.pt_count = npts;
+      dim3 grid((unsigned)((npts + 255) / 256), (unsigned)G);
+      zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
       ZK_LAUNCH_CHECK(ctx);
+      zkp::k_quotient_combine<<<(unsigned)((npts + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, 0, npts, ws->h_ext.fr());
+      ZK_LAUNCH_CHECK(ctx);
+    } else {
+      // h_ext receives this rank's share of the quotient (the sum over ITS expression groups); the W shares are gathered and added up
+      // -- field addition is not an RCCL reduction either.  One coset row at a time: the share of row k1 (n values: 16 MB at k = 19)
+      // goes onto the communicator's stream as soon as it is formed and travels over xGMI while the groups of row k1 + 1 are
+      // evaluated; only the last row's gather is exposed.  (The callback transport of the tests completes each gather in place.)
+      if (ws->qgather.bytes < (size_t)W_sh * npts * 32) {
+        CK(zkfhe_sync(ctx));
+        ws->qgather.release();
+        CK(ws->qgather.alloc(ctx, (size_t)W_sh * npts * 32));
+      }
+      for (int k1 = 0; k1 < q_rows; ++k1) {
+        qa.pt0 = (size_t)k1 * n;
+        qa.pt_count = n;
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)G);
+        if (G) {
+          zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
+          ZK_LAUNCH_CHECK(ctx);
+        }
+        zkp::k_quotient_combine<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, qa.pt0, n, ws->h_ext.fr());
+        ZK_LAUNCH_CHECK(ctx);
+        CK(zkfhe_comm_all_gather_async(ctx, srs->comm, ws->h_ext.fr() + qa.pt0, ws->qgather.fr() + (size_t)k1 * W_sh * n, n * 32));
+      }
+      CK(zkfhe_comm_join(ctx, srs->comm, 0));
+      for (int k1 = 0; k1 < q_rows; ++k1) {
+        zkp::k_sum_rows<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ws->qgather.fr() + (size_t)k1 * W_sh * n, W_sh, n, ws->h_ext.fr() + (size_t)k1 * n);
+        ZK_LAUNCH_CHECK(ctx);
+      }
     }
     const Fr g = mont_u64(COSET_G);
     if (q_rows == 4) {

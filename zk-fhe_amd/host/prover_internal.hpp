@@ -141,8 +141,9 @@ struct Workspace {
   hipEvent_t ev_early = nullptr;
   DevBuf stream, pool, invtmp, wblind;  // device: phase-1 gate stream, coefficient arrays, deferred inverses, blinding rows + flag
   DevBuf tmp_c, partials, h_ext, h_c, misc, points, num, den, small, jobs, evout, polyio;
+  DevBuf qgather;   // one proof over W GPUs: the W shares of the quotient, [coset row][rank][n] (allocated by the first sharded proof)
   std::vector<DevBuf *> all() {
-    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio, &stream, &pool, &invtmp, &wblind, &dev_ring};
+    return {&all_l, &all_ext, &tmp_c, &partials, &h_ext, &h_c, &misc, &points, &num, &den, &small, &jobs, &evout, &polyio, &stream, &pool, &invtmp, &wblind, &dev_ring, &qgather};
   }
 };
 

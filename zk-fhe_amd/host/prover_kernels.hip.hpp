@@ -344,12 +344,15 @@ struct QArgs {
   Fr y, beta, gamma, gamma_rlc;
   unsigned log_n, u, n_gate, n_rlc, adv_rlc0, fix_qrlc0, fix_const, fix_table, adv_lookup0, n_advice, n_perm, chunk, n_chunks;
   unsigned rows;  // cosets evaluated (3 or 4) = rows per column of every extended array (column stride rows * n)
+  // the points of this launch: [pt0, pt0 + pt_count) of the rows * n (everything, or one coset row at a time when the rows'
+  // shares are gathered across ranks while the next row is evaluated)
+  size_t pt0, pt_count;
 };
 
 static __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
   const size_t n = (size_t)1 << a.log_n, ne = n * a.rows;
-  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= ne) return;
+  const size_t p = a.pt0 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= a.pt0 + a.pt_count || p >= ne) return;
   const QGroup g = a.groups[blockIdx.y];
   const size_t row0 = p & ~(n - 1);           // k1 * n
   const size_t k2 = p & (n - 1);
@@ -428,10 +431,10 @@ static __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
 
 // h_ext[p] = (sum_g ypow[g] * partials[g][p]) * zinv[k1]
 static __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
-                                                          const Fr *__restrict__ zinv, unsigned log_n, unsigned rows, Fr *__restrict__ h_ext) {
+                                                          const Fr *__restrict__ zinv, unsigned log_n, unsigned rows, size_t pt0, size_t pt_count, Fr *__restrict__ h_ext) {
   const size_t n = (size_t)1 << log_n, ne = n * rows;
-  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= ne) return;
+  const size_t p = pt0 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= pt0 + pt_count || p >= ne) return;
   // ypow and zinv come in the 2^261 form (constants of the call): nine-limb products, two groups per reduction, a lazy sum
   zk::F29 acc;
 #pragma unroll

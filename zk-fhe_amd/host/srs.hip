@@ -5,6 +5,11 @@
 #include "prover_internal.hpp"
 #include "srs_secret.hpp"
 
+// The monomial half of an SRS (g: the quotient pieces, the random polynomial -- calls of one to three columns) gets this share of
+// the table budget of the Lagrange half (every wide commitment): 13-bit digits (43 GB) under the 160 GB service profile, 11 (13 GB)
+// under the library default of 48 GB.  A wider table there buys nothing a proof can measure and costs tens of GB.
+static constexpr double ZK_MONOMIAL_TABLE_SHARE = 0.3;
+
 extern "C" {
 
 static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const uint8_t *seed, size_t seed_len, zkfhe_srs **out) {
@@ -60,7 +65,7 @@ static int srs_create_impl(zkfhe_ctx *ctx, zkfhe_comm *comm, uint32_t k, const u
     CK(zkfhe_g1_mul(ctx, (const zkfhe_g1_affine *)pts.p, (const zkfhe_fr *)sc.p, (zkfhe_g1_affine *)pts.p, nl));
     CK(zkfhe_download(ctx, host.data(), pts.p, nl * 64));
     // the monomial half serves the calls of 1-3 columns only (random polynomial, quotient pieces): half the table budget
-    CK(zk_basis_create_scaled(ctx, (const zkfhe_g1_affine *)host.data(), nl, 0, which == 0 ? 0.5 : 1.0, which == 0 ? &srs->g : &srs->g_lagrange));
+    CK(zk_basis_create_scaled(ctx, (const zkfhe_g1_affine *)host.data(), nl, 0, which == 0 ? ZK_MONOMIAL_TABLE_SHARE : 1.0, which == 0 ? &srs->g : &srs->g_lagrange));
     if (!comm) (which == 0 ? srs->g_host : srs->gl_host) = host;   // zkfhe_srs_save writes them
     if (which == 1) {
       static int small_c = -1;
@@ -96,7 +101,7 @@ int zkfhe_srs_from_points(zkfhe_ctx *ctx, uint32_t k, const zkfhe_g1_affine *g_h
   srs->hi = n;
   srs->g_host.assign((const G1Affine *)g_host, (const G1Affine *)g_host + n);
   srs->gl_host.assign((const G1Affine *)g_lagrange_host, (const G1Affine *)g_lagrange_host + n);
-  int rc = zk_basis_create_scaled(ctx, g_host, n, 0, 0.5, &srs->g);
+  int rc = zk_basis_create_scaled(ctx, g_host, n, 0, ZK_MONOMIAL_TABLE_SHARE, &srs->g);
   if (!rc) rc = zk_basis_create_scaled(ctx, g_lagrange_host, n, 0, 1.0, &srs->g_lagrange);
   if (!rc && k >= 12 && k <= 14 && !zkfhe_basis_has_multiples(srs->g_lagrange)) rc = zkfhe_basis_create(ctx, g_lagrange_host, n, 10, &srs->g_lagrange_small);
   if (rc) {
