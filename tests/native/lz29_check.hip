@@ -59,6 +59,18 @@ int main() {
     if (!eq(lz_store(lz_mul(p1, V)), fp_mul<FrP>(fp_mul<FrP>(fp_sub<FrP>(fp_add<FrP>(a, b), fp_add<FrP>(c, d)), w), v))) { if (bad++ < 5) printf("mul(mul) mismatch at %d\n", it); }
     if (!eq(lz_store(lz_mul(lz_weak(s16), V)), fp_mul<FrP>(want16, v))) { if (bad++ < 5) printf("mul(weak) mismatch at %d\n", it); }
     if (!eq(lz_store(lz_mul2(A, W, B, V)), fp_add<FrP>(fp_mul<FrP>(a, w), fp_mul<FrP>(b, v)))) { if (bad++ < 5) printf("mul2 mismatch at %d\n", it); }
+    // the two-product form on signed operands (limbs of either sign below 2^29: differences of column values) and the unsigned
+    // four-product form on canonical data -- the radix-4 first stage of the quarter-column 2^13 tile
+    if (!eq(lz_store(lz_mul2(lz_sub(A, C), W, lz_sub(B, D), V)), fp_add<FrP>(fp_mul<FrP>(fp_sub<FrP>(a, c), w), fp_mul<FrP>(fp_sub<FrP>(b, d), v)))) { if (bad++ < 5) printf("mul2(signed) mismatch at %d\n", it); }
+    {
+      const Lw WC = tw_of(c), WD = tw_of(d);   // any canonical constants will do
+      const Fr want = fp_add<FrP>(fp_add<FrP>(fp_mul<FrP>(a, w), fp_mul<FrP>(b, v)), fp_add<FrP>(fp_mul<FrP>(c, c), fp_mul<FrP>(d, d)));
+      const LzT got4 = lz_mul4u(A, W, B, V, C, WC, D, WD);
+      if (!eq(lz_store(got4), want)) { if (bad++ < 5) printf("mul4u mismatch at %d\n", it); }
+      bool ok4 = got4.l[8] >= 0;
+      for (int i = 0; i < 8; ++i) ok4 = ok4 && got4.l[i] >= 0 && got4.l[i] < (1 << 29);
+      if (!ok4) { if (bad++ < 5) printf("mul4u result not tight at %d\n", it); }
+    }
     // weak: result limbs tight, value in [0, 2 r)
     const LzT wk = lz_weak(m16);
     bool tight = wk.l[8] >= 0;

@@ -160,7 +160,9 @@ def _sharded_worker(rank, world, port, which, out):
     proof, inst, _ = pk.prove(text, b"shard")
     info = pk.info()
     res = {"rank": rank, "range": (lo, hi), "proof": proof, "inst": list(inst), "vk": info["vk_digest"], "table_bits": srs.table_bits()}
-    if rank == 0:
+    if rank == 0 and which == "k19":
+        res["vk_bytes"] = pk.export_vk()    # the parent makes the single-GPU proof once the eight ranks have given the device back
+    elif rank == 0:
         # the unsharded reference on the same GPU, same seed
         srs1 = zk.Srs(ctx, k)
         pk1 = zk.BfvProvingKey(ctx, srs1, text_kg, params, cfg)
@@ -181,17 +183,38 @@ def _sharded_worker(rank, world, port, which, out):
 
 
 def _run_ranks(target, world, *args, timeout=900):
+    """Runs target(rank, world, port, *args, queue) in `world` spawned processes and returns their results by rank.  A rank that dies
+    (a failed assertion, an out-of-memory kill) would leave the others waiting in a collective until gloo's own timeout: the
+    survivors are terminated and the test fails at once, with the exit codes."""
+    import queue as queue_mod
+    import time
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     ps = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in ps:
         p.start()
-    got = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda r: r["rank"])
-    for p in ps:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    return got
+    got, deadline = [], time.time() + timeout
+    try:
+        while len(got) < world:
+            try:
+                got.append(q.get(timeout=2))
+            except queue_mod.Empty:
+                dead = [(r, p.exitcode) for r, p in enumerate(ps) if p.exitcode not in (None, 0)]
+                assert not dead, "rank(s) exited early (rank, exit code): %s" % dead
+                assert time.time() < deadline, "ranks did not finish within %d s" % timeout
+        for p in ps:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.terminate()
+        for p in ps:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    return sorted(got, key=lambda r: r["rank"])
 
 
 @pytest.mark.gpu
@@ -223,14 +246,28 @@ def test_whole_k19_proof_over_eight_ranks_equals_single_gpu():
     gathered coset row by coset row), takes its slice of the 1 500 evaluations and of the SHPLONK combinations.  Here the eight ranks
     share GPU 0 and the gathers go through gloo; on an 8-GPU node the same library path runs over RCCL.  All ranks must end with the
     same proof, it must be the single-GPU proof byte for byte, and the verifier must accept it."""
-    got = _run_ranks(_sharded_worker, 8, "k19", timeout=2400)
+    import torch  # noqa: F401
+    import zk_fhe_amd as zk
+    got = _run_ranks(_sharded_worker, 8, "k19", timeout=900)
     n = 1 << 19
     assert [g["range"] for g in got] == [(n * r // 8, n * (r + 1) // 8) for r in range(8)]
     for g in got[1:]:
         assert g["proof"] == got[0]["proof"] and g["inst"] == got[0]["inst"] and g["vk"] == got[0]["vk"]
-    assert got[0]["vk"] == got[0]["vk_1gpu"] and got[0]["proof"] == got[0]["proof_1gpu"]
-    assert got[0]["verified"][0], got[0]["verified"][1]
     assert len(got[0]["inst"]) == 5 * 16384 + 1
+    ok, why = zk.bfv_verify(got[0]["vk_bytes"], got[0]["inst"], got[0]["proof"])
+    assert ok, why
+    # the single-GPU proof of the same input and seed, made here after the ranks have exited (eight k = 19 keys and workspaces next to
+    # a ninth do not fit one device)
+    text_kg, text, params, cfg, k = _circuit("k19")
+    ctx = zk.Context(0)
+    srs = zk.Srs(ctx, k)
+    pk = zk.BfvProvingKey(ctx, srs, text_kg, params, cfg)
+    assert pk.info()["vk_digest"] == got[0]["vk"]
+    proof_1gpu = pk.prove(text, b"shard")[0]
+    pk.destroy()
+    srs.destroy()
+    ctx.close()
+    assert proof_1gpu == got[0]["proof"]
 
 
 def _msm_worker(rank, world, port, log_n, n_cols, out):

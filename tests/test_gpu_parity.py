@@ -116,10 +116,12 @@ def test_ntt_vs_oracle(ctx, log_n):
     assert np.array_equal(ctx.ntt(fwd, log_n, True), a)
 
 
-@pytest.mark.parametrize("log_n,n_cols", [(5, 3), (12, 4), (13, 1), (13, 37), (14, 2)])
+@pytest.mark.parametrize("log_n,n_cols", [(5, 3), (12, 4), (13, 1), (13, 37), (14, 2), (16, 5), (19, 3)])
 def test_ntt_out_of_place(ctx, log_n, n_cols):
     """zkfhe_ntt_batch_to: the input buffer is left untouched, the output equals the oracle.  At 2^13 this is the kernel's native
-    form (two workgroups per column, placed in groups of eight columns: 37 columns leave the last group ragged)."""
+    form (two workgroups per column, placed in groups of eight columns: 37 columns leave the last group ragged).  2^16 and 2^19:
+    the three / six stages above the tile as ONE four-step pass (ntt_dif8.hip: size-8 / size-64 transforms on constants, one
+    streaming table product per element), tiles numbered position-major over an odd number of columns."""
     rng = np.random.default_rng(900 + log_n + n_cols)
     n = 1 << log_n
     a = rand_fr(rng, n_cols * n).reshape(n_cols, n, 4)
@@ -174,7 +176,7 @@ def test_ntt_k13_batch_properties(ctx):
     assert np.array_equal(ctx.ntt(s[None], log_n, False)[0], orc.fe_binop("add", f[0], f[1]))
 
 
-@pytest.mark.parametrize("log_n,lef", [(4, 2), (7, 1), (10, 3), (13, 2), (14, 2), (15, 1)])
+@pytest.mark.parametrize("log_n,lef", [(4, 2), (7, 1), (10, 3), (13, 2), (14, 2), (15, 1), (16, 2), (16, 1)])
 def test_coset_ntt(ctx, log_n, lef):
     rng = np.random.default_rng(log_n * 10 + lef)
     n, E = 1 << log_n, 1 << lef

@@ -154,6 +154,7 @@ int zkfhe_ctx_destroy(zkfhe_ctx *ctx) {
   }
   for (auto &kv : ctx->tw13) hipFree(kv.second);
   for (auto &kv : ctx->pre13) hipFree(kv.second);
+  for (auto &kv : ctx->dif8) hipFree(kv.second);
   for (int i = 0; i < 4; ++i)
     if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
   if (ctx->tickets) hipFree(ctx->tickets);

@@ -36,6 +36,9 @@ struct zkfhe_ctx {
   // coset pre-multiplier tables (keyed by shift, extension and rows); device memory, freed with the context
   std::map<const void *, void *> tw13;
   std::map<std::array<uint64_t, 6>, void *> pre13;
+  // tables of the four-step passes of the longer rows (ntt_dif8.hip): butterfly constants and, per (size, direction, coset shift),
+  // [M constants | n entries]; device memory, bounded, freed with the context
+  std::map<std::array<uint64_t, 8>, void *> dif8;
   // grow-only scratch arenas (bytes)
   // profiling (zkfhe_prof_*): [0] = the summing kernel of a wide MSM call (k_msm_table / k_msm_accumulate), [1] = the NTT tile kernel (k_ntt13 / k_ntt_tile)
   bool prof_on = false;
@@ -113,6 +116,8 @@ inline hipError_t zk_wait(zkfhe_ctx *ctx) {
   return hipEventSynchronize(ctx->wait_ev);
 }
 
+// the top three / six DIF stages of long rows in four-step form (ntt_dif8.hip)
+int zk_dif8_pass(zkfhe_ctx *ctx, const zk::Fr *src, zk::Fr *dst, size_t n_cols, int log_n, int S, int inverse, const zk::Fr *shifts_host, unsigned rows);
 // zkfhe_msm_batch with a column stride (msm.hip)
 int zk_msm_batch_strided(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, zkfhe_g1_affine *out_dev);
 int zk_msm_batch_strided_form(zkfhe_ctx *ctx, const zkfhe_basis *basis, const zkfhe_fr *scalars_dev, size_t col_stride, size_t n_cols, void *out_dev, bool xyzz);

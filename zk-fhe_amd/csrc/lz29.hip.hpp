@@ -138,9 +138,11 @@ ZK_HD LzT lz_mul(const Lz<LO, HI, V> &a, const Lw &b) {
   return r;
 }
 
-// (a w + b v) / 2^261 mod r, one reduction: eighteen products below 2^29 2^29 per column
-template <int V, int V2>
-ZK_HD LzT lz_mul2(const Lz<0, 1, V> &a, const Lw &w, const Lz<0, 1, V2> &b, const Lw &v) {
+// (a w + b v) / 2^261 mod r, one reduction: eighteen products below 2^29 2^29 in magnitude per column (limbs of either sign below
+// 2^29: LO, HI <= 1) and nine m_j r_(k-j) below 2^58: 27 2^58 < 2^63
+template <int L1, int H1, int V, int L2, int H2, int V2>
+ZK_HD LzT lz_mul2(const Lz<L1, H1, V> &a, const Lw &w, const Lz<L2, H2, V2> &b, const Lw &v) {
+  static_assert(L1 <= 1 && H1 <= 1 && L2 <= 1 && H2 <= 1, "two-product form: limbs below 2^29 in magnitude");
   static_assert(V + V2 <= 160, "two-product form: |a w + b v| < 2^261 r");
   constexpr u32 P[9] = ZK_R29_P;
   int m[9];
@@ -167,6 +169,50 @@ ZK_HD LzT lz_mul2(const Lz<0, 1, V> &a, const Lw &w, const Lz<0, 1, V2> &b, cons
       acc += (long long)a.l[j] * (long long)(int)w.l[k - j];
       acc += (long long)b.l[j] * (long long)(int)v.l[k - j];
       acc += (long long)m[j] * (long long)(int)P[k - j];
+    }
+    r.l[k - 9] = (int)((u32)acc & q29::MASK);
+    acc >>= 29;
+  }
+  r.l[8] = (int)acc;
+  return r;
+}
+
+// (a0 w0 + a1 w1 + a2 w2 + a3 w3) / 2^261 mod r with ONE reduction, for canonical data (tight non-negative limbs, values below r)
+// against canonical constants: a column is 36 products below 2^58 and nine m_j r_(k-j) below 2^58 -- 45 2^58 < 2^64, an UNSIGNED
+// accumulator (v_mad_u64_u32).  The value is below 4 r r / 2^261 + r < 2 r.  (The radix-4 first stage of the quarter-column 2^13
+// tile with a coset pre-multiplier: four table products per output for the price of 2.5.)
+ZK_HD LzT lz_mul4u(const Lz<0, 1, 1> &a0, const Lw &w0, const Lz<0, 1, 1> &a1, const Lw &w1, const Lz<0, 1, 1> &a2, const Lw &w2, const Lz<0, 1, 1> &a3, const Lw &w3) {
+  constexpr u32 P[9] = ZK_R29_P;
+  u32 m[9];
+  LzT r;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      acc += (u64)(u32)a0.l[j] * (u64)w0.l[k - j];
+      acc += (u64)(u32)a1.l[j] * (u64)w1.l[k - j];
+      acc += (u64)(u32)a2.l[j] * (u64)w2.l[k - j];
+      acc += (u64)(u32)a3.l[j] * (u64)w3.l[k - j];
+      acc += (u64)m[j] * (u64)P[k - j];
+    }
+    acc += (u64)(u32)a0.l[k] * (u64)w0.l[0];
+    acc += (u64)(u32)a1.l[k] * (u64)w1.l[0];
+    acc += (u64)(u32)a2.l[k] * (u64)w2.l[0];
+    acc += (u64)(u32)a3.l[k] * (u64)w3.l[0];
+    m[k] = ((u32)acc * r29::INV) & q29::MASK;
+    acc += (u64)m[k] * (u64)P[0];
+    acc >>= 29;   // exact: the low 29 bits are zero
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int j = k - 8; j < 9; ++j) {
+      acc += (u64)(u32)a0.l[j] * (u64)w0.l[k - j];
+      acc += (u64)(u32)a1.l[j] * (u64)w1.l[k - j];
+      acc += (u64)(u32)a2.l[j] * (u64)w2.l[k - j];
+      acc += (u64)(u32)a3.l[j] * (u64)w3.l[k - j];
+      acc += (u64)m[j] * (u64)P[k - j];
     }
     r.l[k - 9] = (int)((u32)acc & q29::MASK);
     acc >>= 29;

@@ -336,7 +336,16 @@ int zk_domain(zkfhe_ctx *ctx, int log_n, const NttDomain **out) {
 
 #define MAX_TILE_LOG 13
 
-int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse, const Fr *pre = nullptr, unsigned rows = 1);
+int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse, const Fr *pre = nullptr, unsigned rows = 1,
+                const Fr *shifts_host = nullptr);
+
+// Rows of 2^16 and 2^19 (three / six stages above the 2^13 tile: BASELINE configs[3] and [4]) run those stages in four-step form
+// (ntt_dif8.hip): constants for the size-8 / size-64 part, one streaming table product per element.  ZKFHE_NTT_DIF8=0: the radix-2
+// passes with gathered twiddles (k_dif_fused / k_dif_lds) that every other length still takes.
+static bool dif8_rows(int log_n) {
+  static const bool on = !(getenv("ZKFHE_NTT_DIF8") && getenv("ZKFHE_NTT_DIF8")[0] == '0');
+  return on && (log_n - MAX_TILE_LOG == 3 || log_n - MAX_TILE_LOG == 6);
+}
 
 extern "C" {
 
@@ -357,9 +366,11 @@ int zkfhe_ntt_batch_to(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_dev
 
 // src == nullptr: in place on cols_dev.  pre (long rows, forward, out of place only): the n_cols transforms are `rows` coset rows
 // of the n_cols / rows vectors at src, each multiplied by its row of pre (2^261 form) while the first pass loads it.
-extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse, const Fr *pre, unsigned rows) {
+extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, size_t n_cols, int log_n, int inverse, const Fr *pre, unsigned rows,
+                             const Fr *shifts_host) {
   ZK_ENTER(ctx);
-  ZK_ARG(ctx, pre == nullptr || (src_dev != nullptr && !inverse && log_n > 13 && rows >= 1 && n_cols % rows == 0));
+  ZK_ARG(ctx, (pre == nullptr && shifts_host == nullptr) || (src_dev != nullptr && !inverse && log_n > 13 && rows >= 1 && n_cols % rows == 0));
+  ZK_ARG(ctx, !(pre && shifts_host));
   ZK_ARG(ctx, log_n >= 1 && log_n <= 26);
   if (!n_cols) return ZKFHE_OK;
   ZK_ARG(ctx, cols_dev != nullptr);
@@ -439,7 +450,17 @@ extern "C++" int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *
   const Fr *pass_in = src ? src : data;
   const int log_tiles = log_n - MAX_TILE_LOG;
   const Fr *tw = inverse ? dom->inv29 : dom->fwd29;
-  for (int s = log_n - 1; s >= MAX_TILE_LOG;) {
+  int s_top = log_n - 1;
+  if (dif8_rows(log_n) && !pre) {
+    // all stages above the tile in one four-step pass (the coset shifts, if any, are folded into its tables)
+    rc = zk_dif8_pass(ctx, pass_in, work, n_cols, log_n, log_n - MAX_TILE_LOG, inverse, shifts_host, shifts_host ? rows : 1u);
+    if (rc) return rc;
+    pass_in = work;
+    s_top = MAX_TILE_LOG - 1;
+  } else {
+    ZK_ARG(ctx, shifts_host == nullptr);   // the radix-2 passes take the coset powers as a device table (pre)
+  }
+  for (int s = s_top; s >= MAX_TILE_LOG;) {
     const int left = s - MAX_TILE_LOG + 1;
     static const bool lds_pass = !(getenv("ZKFHE_NTT_LDS_PASS") && getenv("ZKFHE_NTT_LDS_PASS")[0] == '0');
     if (left >= 4 && lds_pass) {   // four to six stages in one pass through LDS (seven: four, then three in registers)
@@ -510,6 +531,15 @@ extern "C++" int zk_coset_ntt_rows(zkfhe_ctx *ctx, const Fr *in_dev, Fr *out_dev
   if (log_n == 13) {   // the 2^13 tile keeps its own tables (coset powers times the first-stage twiddles), built once
     rc = zk_pre13(ctx, g, lef, rows, false, &pre13);
     if (rc) return rc;
+  } else if (dif8_rows(log_n) && rows <= 4) {
+    // the four-step pass folds the coset powers into its own (cached) tables: no table of powers per call
+    Fr shifts[4];
+    Fr shift = g;
+    for (int k1 = 0; k1 < rows; ++k1) {
+      shifts[k1] = shift;
+      shift = shift * edom->omega;
+    }
+    return zk_ntt_impl(ctx, (const zkfhe_fr *)in_dev, (zkfhe_fr *)out_dev, n_cols * (size_t)rows, log_n, 0, nullptr, (unsigned)rows, shifts);
   } else {
     Fr shift = g;
     const Fr c32 = zk_fr_to_29(Fr::one());
@@ -611,6 +641,14 @@ int zkfhe_coset_ntt_batch(zkfhe_ctx *ctx, const zkfhe_fr *in_dev, zkfhe_fr *out_
     if (log_n == 13) {
       rc = zk_pre13(ctx, g, lef, E, false, &pre13);
       if (rc) return rc;
+    } else if (dif8_rows(log_n) && E <= 4) {
+      Fr shifts[4];
+      Fr shift = g;
+      for (int k1 = 0; k1 < E; ++k1) {
+        shifts[k1] = shift;
+        shift = shift * edom->omega;
+      }
+      return zk_ntt_impl(ctx, in_dev, out_dev, n_cols * E, log_n, 0, nullptr, (unsigned)E, shifts);
     } else {
       Fr shift = g;
       const Fr c32 = zk_fr_to_29(Fr::one());

@@ -67,7 +67,14 @@ int alloc_workspace(zkfhe_ctx *ctx, const CircuitConfig &c, Workspace *ws, int e
   ZK_HIP(ctx, hipMemsetAsync(ws->inst_l.p, 0, col, ctx->stream));   // the prover only ever writes the public-input rows
   ws->inst_count = 0;
   CK(ws->tmp_c.alloc(ctx, std::max<size_t>(n_all, c.n_perm()) * col));
-  CK(ws->partials.alloc(ctx, 96 * 4 * col));
+  {
+    // quotient partials: one row set (ext_rows * n values) per expression group -- the groups prove.hip cuts (8 gates, all RLC
+    // gates, 32 chaining terms, 4 permutation chunks, 3 lookups per group; a rank of a sharded proof evaluates a contiguous share:
+    // at most one more group per kind), not a flat 96 x 4 columns (6 GB at k = 19).  The buffer doubles as the receive side of the
+    // sharded SHPLONK gather (ranks x rotation sets columns) and as scratch of the evaluation round: at least 96 columns.
+    const size_t groups = ((size_t)c.n_gate() + 7) / 8 + 1 + 2 + ((size_t)c.n_chunks() + 31) / 32 + ((size_t)c.n_chunks() + 3) / 4 + ((size_t)c.n_lookup + 2) / 3 + 8;
+    CK(ws->partials.alloc(ctx, std::max<size_t>(groups * (size_t)ext_rows, 96) * col));
+  }
   CK(ws->h_ext.alloc(ctx, 4 * col));
   CK(ws->h_c.alloc(ctx, 4 * col));
   CK(ws->misc.alloc(ctx, 32 * col));

@@ -580,6 +580,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     (void)pt_dev;   // the commitment is stored by the MSM's last kernel into pinned memory: no copy command
     if (int rc = zkfhe_msm_batch_xyzz(aux, srs->g, (const zkfhe_fr *)rand_dev, 1, (zkfhe_g1_xyzz *)ws->host_rand_pt))
       return zk_fail_msg(ctx, rc, std::string("random polynomial commitment (auxiliary stream): ") + zkfhe_last_error(aux));
+    // ... and its Lagrange form, which the evaluation round reads: one single-column transform less on the proof's critical path
+    if (int rc = zkfhe_ntt_batch_to(aux, (const zkfhe_fr *)rand_dev, (zkfhe_fr *)(ws->misc.fr() + 9 * n), 1, (int)k, 0))
+      return zk_fail_msg(ctx, rc, std::string("random polynomial, Lagrange form (auxiliary stream): ") + zkfhe_last_error(aux));
     ZK_HIP(ctx, hipEventRecord(ws->ev_rand, aux->stream));
   }
   Context ctx0(CTX_PHASE0, false, false), ctx_gate(CTX_GATE1, false, false), ctx_rlc(CTX_RLC1, true, false);
@@ -995,7 +998,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     run(zkp::QG_PERM_D, 0, nch, 4, 1, [&](size_t j) { return owns_chunk(j); });
     run(zkp::QG_LOOKUP, 0, cfg.n_lookup, 3, 5, [&](size_t i) { return owns_col(cfg.adv_lookup0() + i); });
     const size_t E = e, G = groups.size();
-    if (G > 96) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
+    if (G > 96 || G * n * (size_t)q_rows * 32 > ws->partials.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
     std::vector<Fr> ypow(G);
     for (size_t g = 0; g < G; ++g) ypow[g] = zk::zk_fr_to_29(fr_pow(y, E - 1 - last_e[g]));   // 2^261 form: constant operands of k_quotient_combine
     STAGE(groups_dev, zkp::QGroup, ws, groups.data(), G * sizeof(zkp::QGroup));
@@ -1148,7 +1151,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ptrs_dev, sc_dev, 3, n, H_c);
     ZK_LAUNCH_CHECK(ctx);
     CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)H_c, (zkfhe_fr *)H_l, 1, (int)k, 0));
-    CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)rand_c, (zkfhe_fr *)rand_l, 1, (int)k, 0));
+    if (!early_rand) CK(zkfhe_ntt_batch_to(ctx, (const zkfhe_fr *)rand_c, (zkfhe_fr *)rand_l, 1, (int)k, 0));   // early: transformed on the auxiliary stream at the start
   }
   Fr *bw = ws->misc.fr();  // [6][n] barycentric weights
   {
