@@ -500,8 +500,9 @@ def test_msm_sparse_terms(ctx):
 
 
 def test_both_2_13_kernels_against_the_oracle(tmp_path):
-    """The 2^13 tile exists twice: the quarter-column kernel (k_ntt13q: four workgroups of 256 threads per column, radix 4 fused into
-    the load -- the default) and the half-column kernel of round 3 (k_ntt13, ZKFHE_NTT13=half).  The choice is read once per process,
+    """The 2^13 tile exists twice: the half-column kernel of round 3 (k_ntt13, the default) and the quarter-column kernel of round 5
+    (k_ntt13q, ZKFHE_NTT13=quarter: four workgroups of 256 threads per column, radix 4 fused into the load; measured, not faster:
+    profiles/r5_probes.md).  The choice is read once per process,
     so each runs in its own interpreter: forward, inverse (with its n^-1), out of place, 37 columns (ragged groups of eight), the
     coset extension with 2 and 1 extension bits and the extension + inverse round trip, all against the C oracle."""
     import subprocess

@@ -665,3 +665,27 @@ def test_second_srs_on_a_full_device_gets_narrower_tables_same_bytes(ctx, monkey
         pk.destroy()
     b.destroy()
     a.destroy()
+
+
+def test_quotient_by_column_block_gives_the_same_proof(ctx):
+    """ZKFHE_QUOTIENT=blocks (k_quotient_blocks: every expression a block of eight columns takes part in from one load of each value,
+    one partial row per block -- built in round 5, measured slower than the grouping by kind, kept as an option): the choice is read
+    once per process, so a second interpreter proves the reference's bfv.in at k = 13 with it; the bytes must be the oracle's."""
+    import subprocess
+    import sys
+    o = oracle_k13()
+    script = r'''
+import json, os, sys
+import torch  # noqa: F401
+sys.path.insert(0, %r)
+import zk_fhe_amd as zk
+G = os.path.join(%r, "tests", "golden", "bfv")
+ctx = zk.Context(0)
+srs = zk.Srs(ctx, 13)
+cfg = zk.BfvConfig.from_pinning(json.load(open(os.path.join(G, "bfv_config.json"))))
+pk = zk.BfvProvingKey(ctx, srs, open(os.path.join(G, "bfv_empty.in")).read(), (1024, 536870909, 7, 19), cfg)
+sys.stdout.write(pk.prove(open(os.path.join(G, "bfv.in")).read(), b"seed-1")[0].hex())
+''' % (os.path.dirname(HERE), os.path.dirname(HERE))
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, ZKFHE_QUOTIENT="blocks"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert bytes.fromhex(r.stdout.strip().splitlines()[-1]) == o["proof_o"]

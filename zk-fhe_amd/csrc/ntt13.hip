@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(512, ZK_NTT13_WAVES) k_ntt13(Tile13Args A) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Quarter-column variant (round 5): FOUR workgroups of 256 threads per column instead of two of 512.  k_ntt13 needs 246 registers, so
+// Quarter-column variant (round 5; BUILT, MEASURED, NOT THE DEFAULT -- see ntt13_quarter below): FOUR workgroups of 256 threads per
+// column instead of two of 512.  k_ntt13 needs 246 registers, so
 // a CU holds one of its workgroups (eight waves, two per SIMD) and all of them move through the kernel's phases together: nothing
 // issues multiply-adds while the column is being loaded, while the eight waves meet at the exchange, while the results are stored
 // (the passes alone need 97 us per 256 columns, the kernel 150: profiles/r4_probes.md).  A 256-thread workgroup is one wave per SIMD,
@@ -353,7 +354,6 @@ __global__ void __launch_bounds__(256, 2) k_ntt13q(Tile13Args A) {
   const TileArgs &a = A.t;
   const Fr *__restrict__ src = a.in + c * a.col_stride_in + (size_t)b * a.in_tile_stride;
   const LwMem *__restrict__ tw = A.tw;
-
   // ---- load + radix 4 over the top two index bits (this workgroup keeps the outputs k = sub mod 4) -----------------------------
   LzT x[8];
   Fr raw[8][4];
@@ -507,9 +507,12 @@ __global__ void __launch_bounds__(256, 2) k_ntt13q(Tile13Args A) {
 
 }  // namespace
 
-// Which 2^13 kernel runs: the quarter-column one (k_ntt13q) unless ZKFHE_NTT13=half asks for the round-3 half-column kernel.
+// Which 2^13 kernel runs: the half-column kernel of round 3 (k_ntt13) unless ZKFHE_NTT13=quarter asks for k_ntt13q.  Measured on
+// one box (profiles/r5_probes.md): 256 columns 0.1542 ms against 0.1514 (plain), 0.1572 against 0.1440 per coset row (the four-product
+// first stage), the driver's wave 202-209 proofs/s against 207-220 -- two workgroups that start together on a CU run the same code
+// for the same time and stay in step, so the phases do not overlap after all (a start skew of the first resident set made it worse).
 static bool ntt13_quarter() {
-  static const bool q = !(getenv("ZKFHE_NTT13") && getenv("ZKFHE_NTT13")[0] == 'h');
+  static const bool q = getenv("ZKFHE_NTT13") && getenv("ZKFHE_NTT13")[0] == 'q';
   return q;
 }
 
@@ -542,12 +545,13 @@ int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const 
         if (p) (void)hipFree(p);
       }
     } own;
-    ZK_HIP(ctx, hipMalloc((void **)&own.p, (size_t)rows * 2 * 8192 * sizeof(LwMem)));   // either layout: 16 384 entries per row
+    const size_t per_row = quarter ? (size_t)4 * 4 * 2048 : (size_t)2 * 8192;   // entries of one coset row's tables
+    ZK_HIP(ctx, hipMalloc((void **)&own.p, (size_t)rows * per_row * sizeof(LwMem)));
     Fr shift = g;
     const Fr start = scaled ? dom->n_inv29 : zk_fr_to_29(Fr::one());
     for (int k1 = 0; k1 < rows; ++k1) {
-      if (quarter) k_pre13q_pack<<<128, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * 2 * 8192);
-      else k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * 2 * 8192);
+      if (quarter) k_pre13q_pack<<<128, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * per_row);
+      else k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * per_row);
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * edom->omega;
     }
