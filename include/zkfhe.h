@@ -321,6 +321,8 @@ int zkfhe_srs_create(zkfhe_ctx *ctx, uint32_t k, const uint8_t *seed, size_t see
  * save: an unsharded SRS made by zkfhe_srs_create, zkfhe_srs_load, or zkfhe_srs_from_points + zkfhe_srs_set_g2.
  * load: checks the frame, that every coordinate is reduced and every point on its curve (as halo2's RawBytes read does). */
 int zkfhe_srs_save(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path);
+/* Releases the host copies of the points an unsharded SRS keeps for zkfhe_srs_save (128 B x 2^k); a later save is refused. */
+int zkfhe_srs_drop_host_copy(zkfhe_srs *srs);
 int zkfhe_srs_load(zkfhe_ctx *ctx, const char *path, zkfhe_srs **out);
 /* The verifier's half, as zkfhe_bfv_verify_g2 takes it: canonical little-endian x.c0 | x.c1 | y.c0 | y.c1 of G2 and s G2.
  * zkfhe_srs_g2: of an SRS in memory (ZKFHE_EINVAL when it has none: from_points without set_g2); zkfhe_srs_file_g2: read from

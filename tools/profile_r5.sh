@@ -82,7 +82,6 @@ ZKFHE_HASH_MODE=shared python bench.py --steps 20 --warmup 5 --no-cpu-baseline >
 ZKFHE_HASH_MODE=shared python bench.py --no-cpu-baseline > $OUT/bench_default_shared.json 2>/dev/null
 ZKFHE_GATE=4 python bench.py --no-cpu-baseline > $OUT/bench_default_gate4.json 2>/dev/null
 ZKFHE_PREFIX_CACHE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_nocache.json 2>/dev/null
-ZKFHE_QUOTIENT=groups python bench.py --steps 8 --streams 1 --transcript blake2b --no-cpu-baseline --steady-seconds 0 > $OUT/bench_single_blake2b_groups.json 2>/dev/null
 /opt/rocm/lib/llvm/bin/clang++ -O3 -std=c++17 -I zk-fhe_amd/host tools/exp/poseidon_x8_check.cpp zk-fhe_amd/host/poseidon_x8.cpp zk-fhe_amd/host/poseidon_ifma.cpp -o /tmp/px8 -lpthread 2>/dev/null && /tmp/px8 > $OUT/poseidon_x8.txt 2>&1
 nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>&1; lscpu | grep -E "Model name" >> $OUT/host.txt
 ls -la $OUT

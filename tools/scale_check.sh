@@ -21,10 +21,10 @@ NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "GPUs visible: $NGPU; usable CPUs: $(python -c 'import zk_fhe_amd.batch as b; print(b.usable_cpus())')" | tee "$OUT/host.txt"
 : > "$OUT/scale.jsonl"
 port=29500
-run() {  # ranks mode hash_mode extra bench arguments...
-  local n=$1 mode=$2 hm=$3; shift 3
+run() {  # ranks mode hash_mode tag extra bench arguments...
+  local n=$1 mode=$2 hm=$3 tag=$4; shift 4
   port=$((port + 1))
-  local log="$OUT/${mode}_${hm}_n${n}"
+  local log="$OUT/${mode}_${tag}_${hm}_n${n}"
   if [ "$n" -eq 1 ]; then
     ZKFHE_HASH_MODE=$hm python bench.py --gpus 1 --no-cpu-baseline "$@" > "$log.json" 2> "$log.err"
   else
@@ -46,10 +46,10 @@ PY
 for n in 1 2 4 8; do
   [ "$n" -le "$NGPU" ] || continue
   for hm in latency shared; do
-    run $n batch $hm --steps 96 --warmup 4                                           # 96 proofs per rank, 16 in flight per GPU
+    run $n batch $hm k13 --steps 96 --warmup 4                                           # 96 proofs per rank, 16 in flight per GPU
   done
-  run $n one-proof-sharded latency --config k19 --steps 4 --warmup 1 --transcript blake2b --steady-seconds 0
-  run $n one-proof-sharded latency --config k16 --steps 6 --warmup 1 --transcript blake2b --steady-seconds 0
+  run $n one-proof-sharded latency k19 --config k19 --steps 4 --warmup 1 --transcript blake2b --steady-seconds 0
+  run $n one-proof-sharded latency k16 --config k16 --steps 6 --warmup 1 --transcript blake2b --steady-seconds 0
 done
 python - "$OUT/scale.jsonl" <<'PY'
 import json, sys

@@ -31,7 +31,7 @@ EXPORTS = [
     "zkfhe_bfv_build_tables", "zkfhe_bfv_auto_config", "zkfhe_bfv_tables_free", "zkfhe_bfv_tables_count", "zkfhe_bfv_tables_copy_advice",
     "zkfhe_bfv_tables_copy_fixed", "zkfhe_bfv_tables_copy_instance", "zkfhe_bfv_tables_copy_copies",
     "zkfhe_bfv_tables_copy_break_points", "zkfhe_bfv_mock_check", "zkfhe_bfv_tables_poke_advice",
-    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_srs_save", "zkfhe_srs_load", "zkfhe_srs_g2", "zkfhe_srs_set_g2", "zkfhe_srs_file_g2",
+    "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_srs_save", "zkfhe_srs_drop_host_copy", "zkfhe_srs_load", "zkfhe_srs_g2", "zkfhe_srs_set_g2", "zkfhe_srs_file_g2",
     "zkfhe_chacha20_block", "zkfhe_snark_encode", "zkfhe_snark_decode", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info", "zkfhe_bfv_pk_prefix_cache",
     "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
@@ -819,6 +819,11 @@ class Srs:
         lib = self.ctx.lib
         lib.zkfhe_srs_save.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
         self.ctx._check(lib.zkfhe_srs_save(self.ctx.h, self.h, os.fsencode(path)))
+
+    def drop_host_copy(self):
+        """zkfhe_srs_drop_host_copy: give back the host copies kept for save() (a later save() raises)."""
+        self.ctx.lib.zkfhe_srs_drop_host_copy.argtypes = [ctypes.c_void_p]
+        self.ctx._check(self.ctx.lib.zkfhe_srs_drop_host_copy(self.h))
 
     def g2(self):
         """(G2, s G2) as ((x.c0, x.c1), (y.c0, y.c1)) ints: what bfv_verify(g2=, s_g2=) takes"""

@@ -248,6 +248,7 @@ int main(int argc, char **argv) {
       mkdir(params_dir.c_str(), 0755);
       CHECK(zkfhe_srs_save(ctx, srs, srs_path.c_str()));
       printf("wrote %s (unsafe test setup: ChaCha20Rng::from_seed([0; 32]))\n", srs_path.c_str());
+      zkfhe_srs_drop_host_copy(srs);   // written: the host copies of the points are not needed again
     }
   }
   zkfhe_bfv_pk *pk = nullptr;

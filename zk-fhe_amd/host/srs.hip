@@ -134,7 +134,7 @@ int zkfhe_srs_save(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path) {
   const size_t n = (size_t)1 << srs->k;
   if (srs->sharded()) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: a sharded SRS holds only a slice of the points");
   if (srs->g_host.size() != n || srs->gl_host.size() != n)
-    return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: this SRS keeps no host copy of its points (made over a communicator); save the one made without");
+    return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: this SRS keeps no host copy of its points (made over a communicator, or zkfhe_srs_drop_host_copy was called)");
   if (!srs->have_g2) return zk_fail_msg(ctx, ZKFHE_EINVAL, "zkfhe_srs_save: the SRS has no G2 half (zkfhe_srs_set_g2)");
   // written aside under a name of this process' own and renamed into place: two ranks (or two CLI runs) that both find the file
   // missing and derive it at once never write into each other's temporary, and a reader sees the old file, none, or a whole one
@@ -150,6 +150,15 @@ int zkfhe_srs_save(zkfhe_ctx *ctx, const zkfhe_srs *srs, const char *path) {
     remove(tmp.c_str());
     return zk_fail_msg(ctx, ZKFHE_EINVAL, std::string("writing ") + path + " failed");
   }
+  return ZKFHE_OK;
+}
+
+// An unsharded SRS keeps host copies of both point vectors (64 B x 2^k each: 128 MB at k = 20) only so that zkfhe_srs_save can write
+// them; a prover that has saved (or never will) gives them back with this.  Saving afterwards is refused with a message that says so.
+int zkfhe_srs_drop_host_copy(zkfhe_srs *srs) {
+  if (!srs) return ZKFHE_EINVAL;
+  std::vector<G1Affine>().swap(srs->g_host);
+  std::vector<G1Affine>().swap(srs->gl_host);
   return ZKFHE_OK;
 }
 
