@@ -501,35 +501,13 @@ def native_cpu_proof(pk, hcfg, prm, text, seed, tmp_dir):
 
 
 def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
-    """Large configurations: the Python oracle prover would take many minutes, so the checks are: the GPU proof is accepted by
-    the oracle VERIFIER (pairing check) against the commitments of the GPU keygen, a tampered proof is not, and (tmp_dir given)
+    """Large configurations: the Python oracle prover takes minutes to hours here, so it ran ONCE on the CPU and its proof is a
+    committed digest (tests/golden/large_proofs.json, round 5): the GPU proof must have the oracle's bytes.  Besides: the oracle
+    VERIFIER (pairing check) accepts it against the commitments of the GPU keygen, a tampered proof is refused, and (tmp_dir given)
     the proof equals the native CPU prover's byte for byte."""
-    import numpy as np
     import zk_fhe_amd as zk
-    Q, T, B = (1 << 60) - 93, 7, 19
-    rng = np.random.default_rng(4)
-    pk0 = rng.integers(0, Q, N, dtype=np.int64)
-    pk1 = rng.integers(0, Q, N, dtype=np.int64)
-    u = rng.choice(np.array([0, 1, -1], dtype=np.int64), N)
-    m = rng.choice(np.array([0, 1, 2, 3, -1, -2, -3], dtype=np.int64), N)
-    e = np.clip(np.rint(rng.normal(0, 3.2, (2, N))), -B, B).astype(np.int64)
-
-    def negacyclic_pm1(a, s):  # a * s in Z_Q[x]/(x^N+1), s in {0,+1,-1}; big-endian in and out
-        a, s = a[::-1], s[::-1]
-        out = np.zeros(N, dtype=np.int64)
-        for i in np.nonzero(s)[0]:
-            sh = np.empty(N, dtype=np.int64)
-            sh[i:] = a[: N - i]
-            sh[:i] = (Q - a[N - i:]) % Q
-            out = (out + (sh if s[i] == 1 else (Q - sh) % Q)) % Q
-        return out[::-1]
-    delta = Q // T
-    md = np.array([(int(x) % Q) * delta % Q for x in m], dtype=np.int64)
-    c0 = (negacyclic_pm1(pk0, u) + md) % Q
-    c0 = (c0 + e[0] % Q) % Q
-    c1 = (negacyclic_pm1(pk1, u) + e[1] % Q) % Q
-    s = lambda v: [str(int(x) % Q) for x in v]  # noqa: E731
-    inp = dict(pk0=s(pk0), pk1=s(pk1), m=s(m), u=s(u), e0=s(e[0]), e1=s(e[1]), c0=s(c0), c1=s(c1), cyclo=s([1] + [0] * (N - 1) + [1]))
+    from tests.large_inputs import B, Q60 as Q, T, large_input
+    inp = large_input(N)
     text = json.dumps(inp)
     # column counts: place the circuit with generous limits and count the break points (halo2-base auto-configuration)
     probe = zk.bfv_build_tables(text, (N, Q, T, B), zk.BfvConfig(k, 8, 400, 120, 16, 109), 1, keygen_mode=False)
@@ -543,6 +521,16 @@ def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
     proof, inst, tm = pk.prove(text, tag.encode())
     print(tag, "prove timings ms [witness, commit, quotient, open, total]:", tm, "proof bytes", len(proof))
     assert len(inst) == 4 * N + N + 1
+    # the ORACLE prover's proof of the same input and seed (Python, minutes to hours at this size: made once on the CPU by
+    # tests/golden/gen_large_proof_digests.py, committed as digests): column counts, verifying-key digest, public inputs and proof bytes
+    gold = json.load(open(os.path.join(HERE, "golden", "large_proofs.json"))).get("k%d" % k)
+    if gold is not None:
+        import hashlib
+        assert (gold["N"], gold["seed"], gold["columns"]) == (N, tag, [n0, n1, nl, nr])
+        assert "%064x" % info["vk_digest"] == gold["vk_digest"], "verifying key differs from the oracle keygen's"
+        assert hashlib.sha256(b"".join(int(v).to_bytes(32, "little") for v in inst)).hexdigest() == gold["instances_sha256"]
+        assert len(proof) == gold["proof_len"] and proof[:64].hex() == gold["proof_head_hex"] and proof[-64:].hex() == gold["proof_tail_hex"]
+        assert hashlib.sha256(proof).hexdigest() == gold["proof_sha256"], "proof bytes differ from the oracle prover's"
     hcfg = H.Config(k, n0, n1, nl, nr, 109)
     vk = H.RawVerifyingKey(hcfg, info["fixed_commit"], info["sigma_commit"], info["vk_digest"])
     srs_v = H.srs_verifier_half(k)
