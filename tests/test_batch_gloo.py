@@ -341,6 +341,18 @@ def test_rccl_transport_one_rank_smoke():
     comm.all_gather(send, recv, payload.nbytes)
     ctx.sync()
     assert np.array_equal(recv.download(dtype=np.uint8), payload)
+    # the asynchronous form (the prover's quotient shares, one coset row at a time): three gathers in a row on the communicator's own
+    # stream, each behind the kernel that produced its input on the context's stream, then one join
+    rows = orc.ints_to_mont([int.from_bytes(rng.bytes(31), "little") for _ in range(3 * 4096)]).reshape(3, 4096, 4)
+    src, tmp, dst = ctx.to_device(rows), ctx.alloc(rows.nbytes), ctx.alloc(rows.nbytes)
+    row_bytes = rows.nbytes // 3
+    for k1 in range(3):
+        ctx.fr_binop_dev("add", src.at(k1 * row_bytes), src.at(k1 * row_bytes), tmp.at(k1 * row_bytes), 4096)   # produce row k1 ...
+        comm.all_gather_async(tmp, dst, row_bytes, k1 * row_bytes, k1 * row_bytes)                                                 # ... and send it
+    comm.join()
+    ctx.sync()
+    assert np.array_equal(dst.download(shape=(3, 4096, 4)), orc.fe_binop("add", rows.reshape(-1, 4), rows.reshape(-1, 4)).reshape(3, 4096, 4))
+    src.free(), tmp.free(), dst.free()
     n, n_cols = 1024, 3
     bases = orc.g1_powers(orc.ints_to_mont([77])[0], orc.ints_to_mont([99])[0], n)
     S = orc.ints_to_mont([int.from_bytes(rng.bytes(31), "little") for _ in range(n_cols * n)]).reshape(n_cols, n, 4)

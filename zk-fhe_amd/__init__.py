@@ -700,6 +700,19 @@ class Comm:
         lib.zkfhe_comm_all_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         self.ctx._check(lib.zkfhe_comm_all_gather(self.ctx.h, self.h, send.ptr, recv.ptr, nbytes))
 
+    def all_gather_async(self, send, recv, nbytes, byte_offset_send=0, byte_offset_recv=0):
+        """zkfhe_comm_all_gather_async: the same collective on the communicator's own stream (behind what is queued on the context's
+        stream); join() orders the context's stream or the caller behind it."""
+        lib = self.ctx.lib
+        lib.zkfhe_comm_all_gather_async.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.ctx._check(lib.zkfhe_comm_all_gather_async(self.ctx.h, self.h, send.at(byte_offset_send), recv.at(byte_offset_recv), nbytes))
+
+    def join(self, block_host=False):
+        """zkfhe_comm_join: the context's stream (or, with block_host, the calling thread) waits for the collectives queued so far"""
+        lib = self.ctx.lib
+        lib.zkfhe_comm_join.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        self.ctx._check(lib.zkfhe_comm_join(self.ctx.h, self.h, 1 if block_host else 0))
+
     def point_range(self, n):
         lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
         self.ctx.lib.zkfhe_comm_point_range.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]

@@ -1344,7 +1344,11 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     // One proof over several GPUs, long rows: every rank sums its share of a set's members (a k_lincomb_ptrs over zero members
     // writes zeros), the W partial combinations of all sets are all-gathered (ns n values per rank) and added up.
     const bool shard_sets = W_sh > 1 && k >= 14;
-    if (shard_sets && (size_t)W_sh * ns * n * 32 > ws->partials.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many ranks for the SHPLONK gather buffer");
+    if (shard_sets && ws->qgather.bytes < (size_t)W_sh * ns * n * 32) {   // [set][rank][n]: the buffer of the quotient shares, grown if there are more sets than coset rows
+      CK(zkfhe_sync(ctx));
+      ws->qgather.release();
+      CK(ws->qgather.alloc(ctx, (size_t)W_sh * ns * n * 32));
+    }
     for (size_t j = 0; j < ns; ++j) {
       const size_t all = sets[j].members.size();
       const size_t m_lo = shard_sets ? all * r_sh / W_sh : 0, m_hi = shard_sets ? all * (r_sh + 1) / W_sh : all;
@@ -1361,11 +1365,16 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         zkp::k_lincomb_ptrs<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(pp, pw, msz, n, F + j * n);
       }
       ZK_LAUNCH_CHECK(ctx);
+      // set j's share goes onto the communicator's stream as soon as it is formed (16 MB per rank at k = 19) and travels while the
+      // next set is combined; the sums wait for the join below
+      if (shard_sets) CK(zkfhe_comm_all_gather_async(ctx, srs->comm, F + j * n, ws->qgather.fr() + j * (size_t)W_sh * n, n * 32));
     }
     if (shard_sets) {
-      CK(zkfhe_comm_all_gather(ctx, srs->comm, F, ws->partials.p, ns * n * 32));
-      zkp::k_sum_rows<<<grid_for(ctx, ns * n), 256, 0, ctx->stream>>>(ws->partials.fr(), W_sh, ns * n, F);
-      ZK_LAUNCH_CHECK(ctx);
+      CK(zkfhe_comm_join(ctx, srs->comm, 0));
+      for (size_t j = 0; j < ns; ++j) {
+        zkp::k_sum_rows<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ws->qgather.fr() + j * (size_t)W_sh * n, W_sh, n, F + j * n);
+        ZK_LAUNCH_CHECK(ctx);
+      }
     }
   }
   const Fr v = mont(tr.squeeze());
