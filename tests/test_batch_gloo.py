@@ -465,4 +465,11 @@ def test_batch_of_64_eight_ranks_equals_one_rank_and_cpu_prover():
     for i in (0, 13, 38, 63):                                                               # ranks 0, 5, 6, 7 of the 8-rank run
         assert cp.prove(inputs[i].decode(), b"batch64-%d" % i) == all8[i], "proof %d differs from the CPU prover's" % i
     cp.close()
+    # ... and to the Python oracle's own proofs of the same inputs and seeds (an independent prover; made once on the CPU by
+    # tests/golden/gen_batch64_digests.py, committed as digests)
+    gold = json.load(open(os.path.join(HERE, "golden", "batch64_proofs.json")))
+    assert gold["count"] == 64 and set(gold["proofs"]) == {"0", "13", "38", "63"}
+    for i, g in gold["proofs"].items():
+        assert hashlib.sha256(inputs[int(i)]).hexdigest() == g["input_sha256"]
+        assert hashlib.sha256(all8[int(i)]).hexdigest() == g["proof_sha256"], "proof %s differs from the oracle prover's" % i
 
