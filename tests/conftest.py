@@ -7,7 +7,7 @@ if ROOT not in sys.path:
 
 
 # Every Srs / default Basis a test creates holds a digit-multiple table sized by this budget (GB per SRS half; the library's
-# default is 160 for the Lagrange half and half of it for the monomial half: 189 GB per k = 13 SRS).  The suite keeps several SRS alive at once, so it runs on a smaller budget -- the
+# default is 48 and a quarter of the free memory -- 56 GB per k = 13 SRS -- and bench.py's service profile 160: 189 GB).  The suite keeps several SRS alive at once, so it runs on a smaller budget -- the
 # same kernels with narrower digits (k = 13: 9 bits instead of 15); test_gpu_parity.py::test_msm_table_path forces the
 # wide ones.
 os.environ.setdefault("ZKFHE_TABLE_GB", "4")
