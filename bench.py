@@ -47,6 +47,26 @@ def synth_bfv_input(seed):
     return gen.config3_vector(seed, N, Q, T, B)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _relaunch_as_ranks(n):
+    """`python bench.py --gpus N` without a launcher: the same command line under torch.distributed.run, N ranks on this node,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve).  Returns the job's exit status."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,16 +84,39 @@ def main():
     ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
                     help="Fiat-Shamir hash: poseidon = snark-verifier PoseidonTranscript (the reference's, examples/bfv.rs:311); blake2b = halo2's own")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1 (got %d)" % args.gpus)
+
+    # --gpus N MEANS N ranks.  Launched plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) with N > 1, the
+    # script starts itself again under torch.distributed.run with N local ranks -- the launch the task's contract describes --
+    # and exits with that job's status; launched by torch.distributed.run already, the job's size must be the N asked for.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(_relaunch_as_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     backend = os.environ.get("ZKFHE_BENCH_BACKEND", "nccl")   # "gloo": control-flow test of the N > 1 path on one GPU
+    # ZKFHE_BENCH_FORCE_DIST=1: a ONE-rank job still makes its process group and runs every collective of the N > 1 path through it
+    # (RCCL with the default backend) -- how the multi-rank branch is exercised on a box with one GPU
+    force_dist = os.environ.get("ZKFHE_BENCH_FORCE_DIST", "0") not in ("", "0")
     n_dev = torch.cuda.device_count()
-    if world > 1:
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launch has WORLD_SIZE=%d ranks: refusing to print a line whose n_gpus is not the N asked for "
+                         "(launch with --nproc-per-node %d, or run plain `python bench.py --gpus %d`)" % (args.gpus, world, args.gpus, args.gpus))
+    if backend == "nccl" and n_dev < local_world:
+        raise SystemExit("bench: %d local ranks but %d visible GPU(s): one process per GPU is the contract "
+                         "(ZKFHE_BENCH_BACKEND=gloo shares devices for control-flow tests only)" % (local_world, n_dev))
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -87,7 +130,7 @@ def main():
     # transcript hashing mode from the host CPUs each rank can count on (the ranks of this launch share one node)
     host = batch.configure_host(zk, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     ctx = zk.Context(local_rank)
-    sharded = args.mode == "one-proof-sharded" and world > 1
+    sharded = args.mode == "one-proof-sharded" and use_dist
     comm = None
     if sharded:
         # one communicator for the job: RCCL (the unique id of rank 0 goes round as a byte tensor) or, in the gloo control-flow
@@ -129,21 +172,22 @@ def main():
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     import threading
     n_streams = max(1, min(args.streams, args.steps))
     ctxs = [ctx] + [zk.Context(local_rank) for _ in range(n_streams - 1)]
-    acc = np.zeros(5)
+    acc = np.zeros(8)
     proof_len = [0]
     last = {}
     lock = threading.Lock()
 
     def one_proof(c, j):
         proof, inst, tm = pk.prove(inputs[j % len(inputs)], seeds[j % len(seeds)], ctx=c)
+        marks = c.last_proof_marks()   # a context runs one proof at a time: these are this proof's
         with lock:
-            acc[:] += np.array(tm)
+            acc[:] += np.array(list(tm) + marks)
             proof_len[0] = len(proof)
             last[j] = (proof, inst)
             last.pop(j - 64, None)
@@ -181,7 +225,28 @@ def main():
     if not verified:
         raise SystemExit("bench: a proof of the timed region does not verify: %s" % why)
     si += args.steps
-    dev = "cuda" if (world > 1 and backend == "nccl") else None
+    # a batch's only collective besides the clock (batch.gather_proofs: all_gather_object of <= 62 KB per proof): every rank's last
+    # timed proof goes to all ranks and rank 0 verifies each -- outside the clock, like the check above
+    gathered = None
+    if use_dist and not sharded:
+        everyone = batch.gather_proofs({rank: (v_proof, v_inst)}, world, rank, world)
+        if rank == 0:
+            for r_, (p_, i_) in enumerate(everyone):
+                ok_, why_ = zk.bfv_verify(pk.export_vk(), i_, p_)
+                if not ok_:
+                    raise SystemExit("bench: rank %d's last timed proof does not verify: %s" % (r_, why_))
+        gathered = len(everyone)
+    # one-proof-sharded: every rank made every proof together and must hold the same bytes
+    import hashlib
+    last_sha = hashlib.sha256(v_proof).hexdigest()
+    same_on_all_ranks = None
+    if sharded:
+        digests = batch.gather_proofs({rank: last_sha}, world, rank, world)
+        same_on_all_ranks = len(set(digests)) == 1
+        if not same_on_all_ranks:
+            raise SystemExit("bench: the ranks of a sharded proof hold different bytes: %s" % digests)
+    j_last = si - 1
+    dev = "cuda" if (use_dist and backend == "nccl") else None
     dt = batch.max_over_ranks(dt, device=dev)
     jobs = 1 if sharded else world   # proofs per step over the whole job: every rank its own, or all ranks the same one
     host_cpu_by_rank = batch.gather_floats(host_cpu_ms, device=dev)
@@ -199,6 +264,21 @@ def main():
             c.sync()
         steady = n_more / (time.perf_counter() - ts)
         si += n_more
+
+    # the timed region cycles four public keys, all in the per-key transcript cache after the warm-up -- `value` is the
+    # WARM-key rate (many encryptions under a few keys: a client encrypting to a server's key).  The same K proofs again with the cache
+    # off = every proof under a key never seen before (BASELINE configs[2]: 64 vectors, 64 keys): reported beside it, never the headline.
+    cold = None
+    if args.transcript == "poseidon" and not sharded:
+        zk.prover_gate(gate_timed)
+        pk.prefix_cache(0)
+        tc = time.perf_counter()
+        batch.run_concurrent(list(range(si, si + args.steps)), ctxs, one_proof)
+        for c in ctxs:
+            c.sync()
+        cold = jobs * args.steps / batch.max_over_ranks(time.perf_counter() - tc, device=dev)
+        si += args.steps
+        pk.prefix_cache(8)
 
     # dominant kernel timed live with HIP events on the library's stream, in a separate untimed pass: k_msm_table (the sum of
     # table points of a commitment batch) when the SRS holds a digit-multiple table wide enough for such calls, else the
@@ -272,7 +352,7 @@ def main():
             except Exception as e:  # noqa: BLE001  -- the CPU leg is a label: never lose the GPU measurement over it
                 cpu = {"value": None, "unit": "proofs/s", "cores": None, "kind": "port", "sample": "native CPU prover failed: %r" % (e,)}
         out = {
-            "metric": "BFV proofs/sec (k=%d)" % conf["k"], "value": jobs * args.steps / dt, "unit": "proofs/s", "n_gpus": world,
+            "metric": "BFV proofs/sec (k=%d)" % conf["k"], "value": jobs * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "gpus_requested": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak", "vs_baseline": (world * args.steps / dt) / (1.0 / 10.2) if (world == 1 and not big) else None,
             "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)", "data": "synthetic",
@@ -281,10 +361,15 @@ def main():
                                    "one proof per step, k=%d, N=%d, Q=2^60-93 (BASELINE configs[%d]); columns by halo2-base auto-configuration"
                                    % (conf["k"], conf["N"], 3 if args.config == "k16" else 4),
                        "columns": {"gate0": zcfg.n_gate0, "gate1": zcfg.n_gate1, "lookup": zcfg.n_lookup, "rlc": zcfg.n_rlc},
-                       "mode": args.mode if world > 1 else "batch", "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
-                       "host_cpu_ms_per_proof_by_rank": host_cpu_by_rank, "host": host, "verified": bool(verified),
-                       "steady_state_proofs_per_s": steady, "admission_gate": gate_timed,
-                       "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4]},
+                       "mode": args.mode if use_dist else "batch", "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
+                       "host_cpu_ms_per_proof_by_rank": host_cpu_by_rank, "host": host, "verified": bool(verified), "proofs_gathered_and_verified": gathered, "sharded_proof_identical_on_all_ranks": same_on_all_ranks,
+                       # rank 0's last timed proof, reproducible: input = index into this configuration's input list (bench.py main), seed as given to zkfhe_bfv_prove
+                       "last_timed_proof": {"sha256": last_sha, "vk_digest": "%064x" % pk.info()["vk_digest"], "input_index": j_last % len(inputs), "seed": seeds[j_last % len(seeds)].decode()}, "process_group": (backend if use_dist else None),
+                       "steady_state_proofs_per_s": steady, "cold_key_proofs_per_s": cold, "headline_keys": "warm: %d public keys cycled, all in the per-key transcript cache (cold_key_proofs_per_s: the same K proofs with the cache off)" % len(inputs), "admission_gate": gate_timed,
+                       "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4],
+                                                                                  # the sequential sponge over the 5 N + 1 public inputs (examples/bfv.rs:118-122) stands between the
+                                                                                  # phase-0 commitment and the first challenge: what a proof waits for the HOST there
+                                                                                  "phase0_commitment_back": stage[5], "first_challenge": stage[6], "host_wait_for_first_challenge": stage[6] - stage[5]},
                        "vs_baseline_note": "reference README.md:58: 10.2 s per proof on an 8-core M2 -- DIFFERENT HARDWARE and a LARGER constraint system "
                                            "(axiom-eth always configures a Keccak sub-circuit whose columns this prover does not have, DESIGN.md 6.1); "
                                            "a batch rate against a single-proof latency: not a like-for-like speed-up"},
@@ -307,7 +392,7 @@ def main():
     srs.destroy()
     if comm is not None:
         comm.destroy()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

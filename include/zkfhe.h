@@ -83,6 +83,12 @@ int zkfhe_prof_read(zkfhe_ctx *ctx, int which, double *total_ms, uint64_t *launc
 /* arithmetic units of the profiled launches: which = 0 -> mixed point additions (k_msm_accumulate), 1 -> butterflies (NTT tile kernel) */
 int zkfhe_prof_read_ops(zkfhe_ctx *ctx, int which, double *ops);
 
+/* Host-side marks of the LAST zkfhe_bfv_prove on this context, in ms from its start: [0] the phase-0 commitment is back from the
+ * GPU (what the transcript absorbs next), [1] the first challenge is squeezed -- it stands behind the sponge over the public
+ * inputs (examples/bfv.rs:118-122: 5 N + 1 values, one sequential Poseidon chain with the reference's transcript), so [1] - [0]
+ * is the time a lone proof waits for the HOST --, [2] the proof is complete. */
+int zkfhe_ctx_last_proof_marks(zkfhe_ctx *ctx, float marks_ms[3]);
+
 /* ---- coefficient-wise Fr arithmetic (device buffers, out may alias a or b) ----------------- */
 int zkfhe_fr_add(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);
 int zkfhe_fr_sub(zkfhe_ctx *ctx, const zkfhe_fr *a_dev, const zkfhe_fr *b_dev, zkfhe_fr *out_dev, size_t n);

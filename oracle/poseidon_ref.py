@@ -133,6 +133,15 @@ class Sponge:
         self.state = permute(s)
         self.permutations += 1
 
+    def absorb_full_chunks(self):
+        """Runs the permutations of the FULL chunks buffered so far and keeps the remainder (< RATE values) buffered: what squeeze()
+        would do with them first, whatever is absorbed later -- a full chunk is absorbed without padding and the "exact multiple"
+        rule only looks at the tail.  Lets a caller remember the state behind a long common prefix (halo2_ref._absorb_public_inputs)."""
+        full = len(self.buf) - len(self.buf) % RATE
+        for i in range(0, full, RATE):
+            self._absorb(self.buf[i:i + RATE])
+        self.buf = self.buf[full:]
+
     def squeeze(self):
         buf, self.buf = self.buf, []
         exact = len(buf) % RATE == 0

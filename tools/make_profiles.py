@@ -1,10 +1,26 @@
 #!/usr/bin/env python3
-"""Turn the outputs of tools/profile_r4.sh (gpurun_out/r4/) into the tracked summaries profiles/r4_*.  Run from the repo root."""
+"""Turn the outputs of `bash tools/profile.sh <round>` (gpurun_out/r<round>/) into the tracked summaries profiles/r<round>_*.
+One generator for every round (rounds 2-5 each had a copy of this file that differed by file names):
+
+    python tools/make_profiles.py --round 6        # from the repo root
+"""
+import argparse
 import json
 import os
 
-R = 'gpurun_out/r4/'
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--round", required=True, help="round tag: 6 -> gpurun_out/r6/ -> profiles/r6_*")
+_ap.add_argument("--calibration", default="r5_pmc_calibration.md", help="the PMC calibration file the read factors come from")
+_args = _ap.parse_args()
+RT = 'r%s' % _args.round          # the tag of this round's files
+CAL = _args.calibration
+R = 'gpurun_out/%s/' % RT
 P = 'profiles/'
+
+
+def W(name, text):
+    """profiles/<round tag><name>; @RT@ / @CAL@ in the text = this round's tag / the calibration file"""
+    open(P + RT + name, 'w').write(text.replace('@RT@', RT).replace('@CAL@', CAL))
 
 
 def rd(f):
@@ -38,16 +54,16 @@ single_avg = None
 for l in lp.splitlines():
     if l.startswith('k_msm_table<false>'):
         single_avg = float(l.split()[3]) / int(l.split()[2])
-open(P + 'r4_a_driver_kernel_stats.md', 'w').write("""# r4 (a) -- kernel stats of the driver's command (k = 13, Poseidon transcript, one wave of 20 concurrent proofs)
+W('_a_driver_kernel_stats.md', """# @RT@ (a) -- kernel stats of the driver's command (k = 13, Poseidon transcript, one wave of 20 concurrent proofs)
 
 Command (MI355X box): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_a_driver -o r -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline`,
-summarised with `tools/rocpd_stats.py` (`tools/profile_r4.sh` runs all of these profiles, `tools/make_profiles_r4.py` writes
+summarised with `tools/rocpd_stats.py` (`tools/profile.sh` runs all of these profiles, `tools/make_profiles.py` writes
 these files).  The run printed %.1f proofs/s under the profiler; un-profiled `python bench.py --steps 20 --warmup 5` right after:
 %.1f proofs/s, steady-state pass %.1f.  With 20 proofs sharing the GPU a launch's duration includes the time its workgroups
-wait for CUs, so the averages below are NOT per-kernel costs: those are in `r4_b_single_proof.md`.
+wait for CUs, so the averages below are NOT per-kernel costs: those are in `@RT@_b_single_proof.md`.
 
 Agreement check required by the bench contract: `bench.py` times the `k_msm_table` launches of two extra proofs with HIP
-events (nothing else in flight): `avg_launch_ms` = %.3f; the same launches in `r4_b_single_proof.md` (rocprof, one proof in
+events (nothing else in flight): `avg_launch_ms` = %.3f; the same launches in `@RT@_b_single_proof.md` (rocprof, one proof in
 flight, the two calls of 266 and 136 columns) average %.3f ms.
 
 ## All kernels of the run
@@ -57,11 +73,10 @@ flight, the two calls of 266 and 136 columns) average %.3f ms.
        au['roofline']['avg_launch_ms'] if au else 0, single_avg or 0, head(rd('a_driver_kernel_stats.md'), 40)))
 
 b, bs, bp = jl('b_single_bench.json'), jl('bench_single_blake2b.json'), jl('bench_single_poseidon.json')
-open(P + 'r4_b_single_proof.md', 'w').write("""# r4 (b) -- one proof in flight (k = 13, Blake2b transcript so that the host hash does not pace the GPU)
+W('_b_single_proof.md', """# @RT@ (b) -- one proof in flight (k = 13, Blake2b transcript so that the host hash does not pace the GPU)
 
 `rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 1 --streams 1 --no-cpu-baseline --transcript blake2b --steady-seconds 0`
-(%.2f ms per proof under the profiler; %.2f ms un-profiled, %.1f ms with the Poseidon transcript: `r4_bench_lines.md`).
-Round 3 (`r3_b_single_proof.md`): 8.15 ms of kernels in a 10.2 ms span, host phase 0 on BigInt (1.2 ms before the first launch).
+(%.2f ms per proof under the profiler; %.2f ms un-profiled, %.1f ms with the Poseidon transcript: `@RT@_bench_lines.md`).
 
 ## Kernels of the last proof (`tools/last_proof_stats.py`)
 
@@ -79,10 +94,10 @@ for tag, name, cfgn in (('c_k16', 'k16', 'BASELINE configs[3]: N = 4096, Q = 2^6
     note = ("Calls of many columns take the bucket pipeline here (a 48 GB table allows 9-bit digits at n = 2^16: 29 windows against the "
             "pipeline's 19); calls of <= 8 columns take `k_msm_table`.") if name == 'k16' else \
            "No digit-multiple table at n = 2^19 (8-bit digits would need 137 GB per SRS half): every call takes the bucket pipeline."
-    open(P + 'r4_%s_kernel_stats.md' % name, 'w').write("""# r4 -- %s (%s), one proof in flight, Blake2b transcript
+    W('_%s_kernel_stats.md' % name, """# @RT@ -- %s (%s), one proof in flight, Blake2b transcript
 
 `rocprofv3 --kernel-trace --stats -- python bench.py --config %s --steps %d --warmup 1 --streams 1 --transcript blake2b --steady-seconds 0`
-%.1f ms per proof under the profiler.  Un-profiled: `r4_bench_lines.md`.  %s
+%.1f ms per proof under the profiler.  Un-profiled: `@RT@_bench_lines.md`.  %s
 
 ## Kernels of the last proof
 
@@ -101,24 +116,30 @@ nf, nnl = val(fs, 'k_ntt13')
 nw, _ = val(ws, 'k_ntt13')
 traffic = {}
 if f and w:
-    bpl = int(2 * f * 1024 + w * 1024)
+    # calibrated factors (profiles/@CAL@): scattered 64-byte gathers are counted at their size, coalesced 16 / 32-byte
+    # reads at half of it, writes at their size.  A launch reads its scalars coalesced (32 B x 8192 x columns: counted at half, the
+    # other half is added back) and gathers table points (x 1).
+    scalars = (266 + 136) / 2 * 8192 * 32
+    bpl = int(f * 1024 + scalars / 2 + w * 1024)
     alg = int((266 + 136) / 2 * 8192 * 96)
     traffic = {"kernel": "k_msm_table", "fetch_size_kb_avg": f, "write_size_kb_avg": w, "bytes_per_launch": bpl, "launches": nl,
                "algorithmic_bytes_per_launch": alg,
-               "note": "2 x FETCH_SIZE (gfx950: wide loads are tallied at half their bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (uncalibrated); KB units; "
-                       "separate --pmc passes; k_msm_table<false> = the two calls of 266 and 136 columns of a k = 13 proof"}
+               "note": "FETCH_SIZE x 1 (64-byte table gathers are counted at their size: profiles/@CAL@) + half the streamed scalar bytes "
+                       "(coalesced 32-byte reads are counted at half) + WRITE_SIZE x 1; KB units; separate --pmc passes; k_msm_table<false> = the two calls of 266 and 136 "
+                       "columns of a k = 13 proof"}
 if nf and nw:
     traffic["ntt13"] = {"fetch_size_kb_avg": nf, "write_size_kb_avg": nw, "bytes_per_launch": int(2 * nf * 1024 + nw * 1024), "launches": nnl,
-                        "note": "k_ntt13 launches of a k = 13 proof (inverse transform of 408 columns, three coset rows of each, five single-column calls): average"}
-json.dump(traffic, open(P + 'r4_pmc_traffic.json', 'w'), indent=1)
-open(P + 'r4_pmc.md', 'w').write("""# r4 -- PMC counters (rocprofv3, one or two counters per pass, kernel trace only)
+                        "note": "k_ntt13 launches of a k = 13 proof (inverse transform of 408 columns, three coset rows of each, single-column calls): average; "
+                                "2 x FETCH_SIZE (coalesced 32-byte reads) + WRITE_SIZE"}
+open(P + RT + '_pmc_traffic.json', 'w').write(json.dumps(traffic, indent=1).replace('@CAL@', CAL))
+W('_pmc.md', """# @RT@ -- PMC counters (rocprofv3, one or two counters per pass, kernel trace only)
 
 ## HBM traffic, k = 13, one proof in flight, Poseidon transcript
 
 `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --steady-seconds 0`,
 the same with `--pmc WRITE_SIZE`; `tools/pmc_stats.py`.  Units: KB per launch, averaged over the launches of the run.  gfx950
-correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies wide (16 B / lane) loads at half their bytes, so the
-bytes of a launch are 2 x FETCH_SIZE + WRITE_SIZE (WRITE_SIZE uncalibrated).
+factors measured on this library's own access patterns (`@CAL@`): coalesced 16 / 32-byte reads are tallied at half
+their bytes (x 2), scattered 64-byte gathers at their size (x 1), writes at their size (x 1).
 
 ```
 %s
@@ -144,7 +165,7 @@ writes 256 MB.  Each column is read by both of its workgroups: FETCH_SIZE shows 
 %s
 """ % (fs, ws, rd('ntt13_bench.txt'), rd('ntt13_pmc.txt'), rd('ntt13_resources.txt'), rd('pmc_valu_per_proof.md')))
 
-open(P + 'r4_msm_table.md', 'w').write("""# r4 -- one MSM call: bucket pipeline (bits 0: explicit 13-bit windows, no table) against the digit-multiple table (13-bit digits)
+W('_msm_table.md', """# @RT@ -- one MSM call: bucket pipeline (bits 0: explicit 13-bit windows, no table) against the digit-multiple table (13-bit digits)
 
 `BITS=0,13 python tools/exp/msm_table_bench.py 13 <columns> <kind>`: n = 2^13 points; `full` = random 248-bit scalars,
 `small` = 8-bit, `mixed` = a quarter each of 248-bit / 8-bit / 29-bit / 0-1 columns.  `call` = the whole `zkfhe_msm_batch`
@@ -155,7 +176,7 @@ New in round 3: the fold (`call` - `summing kernel` on the table path) runs 512 
 %s```
 """ % rd('msm_calls.txt'))
 
-lines = ["# r4 -- bench lines (un-profiled, MI355X box, `tools/profile_r4.sh` section (f))", "",
+lines = ["# @RT@ -- bench lines (un-profiled, MI355X box, `tools/profile.sh` section (f))", "",
          "| command | proofs/s | ms per proof | proofs in flight | steady-state pass | host CPU ms / proof | dominant kernel: avg launch ms, int_alu frac |",
          "|---|---|---|---|---|---|---|"]
 for fn, cmd in (('bench_driver', "`python bench.py --steps 20 --warmup 5` (the driver's command)"), ('bench_default', '`python bench.py --no-cpu-baseline`'),
@@ -167,8 +188,7 @@ for fn, cmd in (('bench_driver', "`python bench.py --steps 20 --warmup 5` (the d
                 ('bench_k19_poseidon', '`--config k19 --steps 4 --streams 1`'),
                 ('bench_driver_shared', "`ZKFHE_HASH_MODE=shared` + the driver's command (eight-lane Poseidon service)"),
                 ('bench_default_shared', '`ZKFHE_HASH_MODE=shared python bench.py --no-cpu-baseline`'),
-                ('bench_default_gate0', '`ZKFHE_GATE=0 python bench.py --no-cpu-baseline` (without the admission gate bench.py sets for runs with more steps than streams)'),
-                ('bench_single_blake2b_generic_phase0', '`ZKFHE_PHASE0=generic` + `--steps 8 --streams 1 --transcript blake2b` (BigInt phase 0)')):
+                ('bench_driver_nocache', "`ZKFHE_PREFIX_CACHE=0` + the driver's command (no per-public-key transcript cache)")):
     d = jl(fn + '.json')
     if not d:
         lines.append("| %s | (missing) | | | | | |" % cmd)
@@ -185,13 +205,13 @@ if dd and dd.get('cpu_baseline'):
               "phases of the last proof (ms): %s." % (cb['value'], cb['unit'], cb['cores'], cb['kind'], cb['sample'], cb.get('seconds_per_proof_by_threads'),
                                                       cb.get('phase_ms_last_proof'))]
 lines += ["", "The full JSON line of the driver's command:", "", "```", rd('bench_driver.json').strip().splitlines()[-1] if os.path.exists(R + 'bench_driver.json') else '', "```", ""]
-open(P + 'r4_bench_lines.md', 'w').write('\n'.join(lines))
-open(P + 'r4_microbench.md', 'w').write("# r4 -- micro-benchmarks (`python tools/microbench.py`, MI355X box; the NTT sweep runs out of place: `zkfhe_ntt_batch_to`)\n\n```\n" + rd('microbench.json') + "```\n")
+W('_bench_lines.md', '\n'.join(lines))
+W('_microbench.md', "# @RT@ -- micro-benchmarks (`python tools/microbench.py`, MI355X box; the NTT sweep runs out of place: `zkfhe_ntt_batch_to`)\n\n```\n" + rd('microbench.json') + "```\n")
 
 # ---- wave occupancy --------------------------------------------------------------------------------------------------------
-open(P + 'r4_wave_occupancy.md', 'w').write("""# r4 -- GPU occupancy over the driver's wave of 20 concurrent proofs (2 ms bins)
+W('_wave_occupancy.md', """# @RT@ -- GPU occupancy over the driver's wave of 20 concurrent proofs (2 ms bins)
 
-`rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-seconds 0` (`tools/profile_r4b.sh`), `tools/busy_bins.py <db> 260 2`:
+`rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-seconds 0` (`tools/profile.sh`), `tools/busy_bins.py <db> 260 2`:
 per bin the fraction of time with at least one kernel running, the average number of kernels in flight and the kernel with the largest
 share.  The last ~60 ms of the trace are the two profiled proofs that follow the timed region (one in flight); the wave is the ~100 ms
 block before them: a head of 14-18 ms in which the proofs' early work (phase-0 commitment, gadgets, early phase-1 commitment) shares the
@@ -205,6 +225,9 @@ one-column commitments).
 """ % rd('a_driver_bins.txt'))
 
 # ---- roofline table: one recomputable line per kernel >= 5 % of a configuration ----------------------------------------------
+GATHER = ('k_msm_table<false>', 'k_msm_table<true>', 'k_msm_accumulate')   # reads dominated by scattered 64-byte table points
+
+
 def last_proof(f):
     out = {}
     for l in rd(f).splitlines():
@@ -232,13 +255,14 @@ def cols_of(d):
     return dict(c, advice=adv, perm=perm, chunks=chunks, all=adv + 3 * c['lookup'] + chunks + 1)
 
 
-rows = ["# r4 -- roofline table: every kernel that takes >= 5 % of a lone proof's kernel time in some configuration", "",
-        "Columns: calls and total duration in ONE proof (rocprofv3 kernel trace, `tools/last_proof_stats.py`: the files `r4_b_single_proof.md`, `r4_k16_kernel_stats.md`,",
-        "`r4_k19_kernel_stats.md`), algorithmic bytes of those calls (formula in the last column, SURVEY.md 8(d)), algorithmic GB/s = bytes / duration, fraction of the 8 TB/s",
-        "HBM peak, and the HBM bytes the counters saw per proof: (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB summed over the kernel's launches (separate `--pmc` passes,",
-        "`tools/pmc_stats.py`; gfx950 tallies wide loads at half their bytes, WRITE_SIZE uncalibrated -- MI355X_MICROARCH.md, HBM section), and their ratio to the algorithmic bytes.",
+rows = ["# @RT@ -- roofline table: every kernel that takes >= 5 % of a lone proof's kernel time in some configuration", "",
+        "Columns: calls and total duration in ONE proof (rocprofv3 kernel trace, `tools/last_proof_stats.py`: the files `@RT@_b_single_proof.md`, `@RT@_k16_kernel_stats.md`,",
+        "`@RT@_k19_kernel_stats.md`), algorithmic bytes of those calls (formula in the last column, SURVEY.md 8(d)), algorithmic GB/s = bytes / duration, fraction of the 8 TB/s",
+        "HBM peak, and the bytes the memory-side counters saw per proof: (factor x FETCH_SIZE + WRITE_SIZE) x 1 KiB summed over the kernel's launches (separate `--pmc` passes,",
+        "`tools/pmc_stats.py`), factor = 2 for the streaming kernels and 1 for the MSM kernels whose reads are scattered 64-byte table points -- measured, `@CAL@` --",
+        "and their ratio to the algorithmic bytes (for k_msm_accumulate the counter includes Infinity-Cache hits on its window table: L2-miss traffic, not HBM traffic).",
         "All of these kernels do 256-bit modular integer arithmetic; none is bound by HBM (DESIGN.md section 3): the integer rate against the bare-product-loop rate measured by",
-        "`tools/exp/mad_rate.hip` / `tools/microbench.py` (168-182 G products/s, NOT a hardware bound) is in `r4_bench_lines.md` (`int_alu`).", "",
+        "`tools/exp/mad_rate.hip` / `tools/microbench.py` (168-182 G products/s, NOT a hardware bound) is in `@RT@_bench_lines.md` (`int_alu`).", "",
         "| config | kernel | calls | ms | % of kernel time | algorithmic MB | GB/s | frac of 8 TB/s | counter MB | counter / algorithmic | algorithmic bytes |",
         "|---|---|---|---|---|---|---|---|---|---|---|"]
 for cfg, stats_f, bench_f, pre, n in (('k13', 'b_single_last_proof.txt', 'bench_single_blake2b.json', 'pmc_', 8192), ('k16', 'c_k16_last_proof.txt', 'bench_k16_blake2b.json', 'pmc_k16_', 65536),
@@ -264,6 +288,9 @@ for cfg, stats_f, bench_f, pre, n in (('k13', 'b_single_last_proof.txt', 'bench_
         'k_msm_cscatter': ((32.0 + 4.0 * 16) * n * (wide + small), "(32 B scalar + 4 B x ~16 staged entries) per scalar"),
         'k_msm_fine': ((3 * 4.0 * 16) * n * (wide + small), "4 B x ~16 entries per scalar: two reads of the staged segment, one write of the sorted entries"),
         'k_dif_lds<3>': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform, six stages in one pass (+ 32 n of coset factors on the forward rows)"),
+        'k_dif8_two': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform: the six stages above the tile as one four-step pass (the 32 n table of a pass is shared by all columns: not counted)"),
+        'k_dif8_one': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform: the three stages above the tile as one four-step pass"),
+        'zkp::k_quotient_blocks': (32.0 * 3 * n * (cc['advice'] + (cc['gate0'] + cc['gate1'] + cc['rlc'] + 2) + cc['perm'] + cc['chunks'] + 3 * cc['lookup'] + 4 + 1), "as k_quotient_partials"),
         'k_dif_lds<2>': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform, five stages in one pass"),
         'k_dif_lds<1>': (64.0 * n * (ext_cols * 4 + 5), "64 n per transform, four stages in one pass"),
         'k_msm_table_fold': (None, "latency-bound: sums the partial lists (128 B per partial), one workgroup per column"),
@@ -277,26 +304,11 @@ for cfg, stats_f, bench_f, pre, n in (('k13', 'b_single_last_proof.txt', 'bench_
         cnt = None
         if key in fe and key in wr:
             # counters are per-launch averages over the run (warm-up + timed proofs): launches per proof = this table's calls
-            cnt = (2 * fe[key][0] + wr[key][0]) * 1024 * calls
+            rf = 1.0 if name in GATHER else 2.0     # read factor of the kernel's dominant pattern (@CAL@)
+            cnt = (rf * fe[key][0] + wr[key][0]) * 1024 * calls
         rows.append("| %s | %s | %d | %.3f | %.1f | %s | %s | %s | %s | %s | %s |" % (
             cfg, name, calls, ms, pct, ('%.1f' % (a_bytes / 1e6)) if a_bytes else '-', ('%.0f' % (a_bytes / ms / 1e6)) if a_bytes else '-',
             ('%.3f' % (a_bytes / ms / 1e6 / 8000)) if a_bytes else '-', ('%.1f' % (cnt / 1e6)) if cnt else '-', ('%.1f' % (cnt / a_bytes)) if (cnt and a_bytes) else '-', formula))
-rows += ["", "Micro-benchmarks at the sizes SURVEY.md 8(d) lists (NTT 256 columns at 2^13 ... 2^19, 64 at 2^21; MSM at 2^16 / 2^19, uniform and witness-like scalars): `r4_microbench.md`.", ""]
-open(P + 'r4_roofline.md', 'w').write('\n'.join(rows))
-open(P + 'r4_probes.md', 'w').write("""# r4 -- probes behind the "measured, not adopted" notes of DESIGN.md section 3
-
-## NTT: radix 4 with four coefficients per thread (108 VGPRs, four waves per SIMD) against radix 8 with eight (k_ntt13's passes, two waves per SIMD)
-
-`tools/exp/ntt_radix_probe.hip`: the real butterflies, twiddle products and weak reductions of `csrc/lz29.hip.hpp` in a loop, 512 workgroups, no LDS exchanges.
-
-```
-%s```
-
-## Eight-lane Poseidon engine on the box's CPU (`tools/exp/poseidon_x8_check.cpp`)
-
-```
-%s```
-
-host: %s
-""" % (rd('ntt_radix_probe.txt'), rd('poseidon_x8.txt'), ' / '.join(rd('host.txt').split('\n'))))
-print(open(P + 'r4_bench_lines.md').read()[:3000])
+rows += ["", "Micro-benchmarks at the sizes SURVEY.md 8(d) lists (NTT 256 columns at 2^13 ... 2^19, 64 at 2^21; MSM at 2^16 / 2^19, uniform and witness-like scalars): `@RT@_microbench.md`.", ""]
+W('_roofline.md', '\n'.join(rows))
+print(open(P + RT + '_bench_lines.md').read()[:3000])

@@ -1,12 +1,15 @@
 #!/bin/bash
-# Round-5 profiles (per-public-key transcript cache, commitments normalised on the host, four-step passes above the 2^13 tile, quotient by column
-# block, conservative table default with bench.py opting into the 160 GB service profile).
-# Run on the MI355X box through gpurun; results land in gpurun_out/r5/ and are summarised into profiles/r5_*.md by
-# tools/make_profiles_r5.py.      bash tools/profile_r5.sh
+# The round's profiles: kernel traces, PMC passes, micro-benchmarks and un-profiled bench lines of every configuration.
+# Run on the MI355X box through gpurun; results land in gpurun_out/r<round>/ and are summarised into profiles/r<round>_*.md by
+# tools/make_profiles.py --round <round>.      bash tools/profile.sh <round> [sections, default "a b c d e f g"]
+# (One script for every round: rounds 2-5 each kept a copy of this file that differed by the directory name.)
 set -u
 ulimit -c 0   # a faulting kernel must not fill the box's disk with a core file
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/r5
+RT=r${1:?usage: profile.sh <round> [sections]}
+SECTIONS=${2:-a b c d e f g}
+has() { [[ " $SECTIONS " == *" $1 "* ]]; }
+OUT=$REPO/gpurun_out/$RT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, then the bench arguments

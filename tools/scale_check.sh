@@ -3,7 +3,7 @@
 #
 #   bash tools/scale_check.sh [out_dir]          # default out_dir: gpurun_out/scale
 #
-# Runs bench.py the way the driver launches it (python -m torch.distributed.run, one rank per GPU, RCCL over xGMI) at 1 / 2 / 4 / 8
+# Runs plain `python bench.py --gpus N` (the script launches its N ranks itself: one per GPU, RCCL over xGMI) at 1 / 2 / 4 / 8
 # ranks -- as many as the node has -- in both multi-GPU modes and both host hashing modes, one JSON line each:
 #   batch                independent k = 13 proofs, proof i -> rank i mod W (BASELINE configs[2]; weak scaling, no data-path collective)
 #   one-proof-sharded    every proof made by all ranks (BASELINE configs[4]: --config k19; commitments by point range + ncclAllGather
@@ -20,17 +20,13 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "GPUs visible: $NGPU; usable CPUs: $(python -c 'import zk_fhe_amd.batch as b; print(b.usable_cpus())')" | tee "$OUT/host.txt"
 : > "$OUT/scale.jsonl"
-port=29500
 run() {  # ranks mode hash_mode tag extra bench arguments...
   local n=$1 mode=$2 hm=$3 tag=$4; shift 4
-  port=$((port + 1))
   local log="$OUT/${mode}_${tag}_${hm}_n${n}"
-  if [ "$n" -eq 1 ]; then
-    ZKFHE_HASH_MODE=$hm python bench.py --gpus 1 --no-cpu-baseline "$@" > "$log.json" 2> "$log.err"
-  else
-    ZKFHE_HASH_MODE=$hm python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port $port \
-      bench.py --gpus "$n" --no-cpu-baseline --mode "$mode" "$@" > "$log.json" 2> "$log.err"
-  fi
+  # the PLAIN form: `python bench.py --gpus N` starts its own N ranks under torch.distributed.run (one per GPU, RCCL) and refuses to
+  # print a line whose n_gpus is not N; at N = 1 the process group is forced as well, so that the 1-GPU row of the table has paid
+  # for the same collectives as the others
+  ZKFHE_BENCH_FORCE_DIST=1 ZKFHE_HASH_MODE=$hm python bench.py --gpus "$n" --no-cpu-baseline --mode "$mode" "$@" > "$log.json" 2> "$log.err"
   python - "$log.json" "$n" "$mode" "$hm" >> "$OUT/scale.jsonl" <<'PY'
 import json, sys
 path, n, mode, hm = sys.argv[1:5]

@@ -19,7 +19,7 @@ _lib = None
 EXPORTS = [
     "zkfhe_ctx_create", "zkfhe_ctx_destroy", "zkfhe_last_error", "zkfhe_sync", "zkfhe_stream", "zkfhe_device_info",
     "zkfhe_dev_alloc", "zkfhe_dev_free", "zkfhe_upload", "zkfhe_download", "zkfhe_copy_dev", "zkfhe_memset_dev",
-    "zkfhe_timer_start", "zkfhe_timer_stop_ms", "zkfhe_prof_enable", "zkfhe_prof_reset", "zkfhe_prof_read", "zkfhe_prof_read_ops",
+    "zkfhe_timer_start", "zkfhe_timer_stop_ms", "zkfhe_prof_enable", "zkfhe_prof_reset", "zkfhe_prof_read", "zkfhe_prof_read_ops", "zkfhe_ctx_last_proof_marks",
     "zkfhe_fr_add", "zkfhe_fr_sub", "zkfhe_fr_mul", "zkfhe_fr_scale", "zkfhe_fr_to_mont", "zkfhe_fr_from_mont",
     "zkfhe_fr_batch_invert", "zkfhe_fr_sqr_chain", "zkfhe_fq29_sqr_chain",
     "zkfhe_ntt_batch", "zkfhe_ntt_batch_to", "zkfhe_coset_ntt_batch",
@@ -199,6 +199,14 @@ class Context:
         self.lib.zkfhe_prof_reset.argtypes = [ctypes.c_void_p]
         self._check(self.lib.zkfhe_prof_reset(self.h))
         self._check(self.lib.zkfhe_prof_enable(self.h, int(bool(on))))
+
+    def last_proof_marks(self):
+        """zkfhe_ctx_last_proof_marks: ms from the start of the last proof on this context to (phase-0 commitment back from the GPU,
+        first challenge squeezed, proof complete)"""
+        m = (ctypes.c_float * 3)()
+        self.lib.zkfhe_ctx_last_proof_marks.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        self._check(self.lib.zkfhe_ctx_last_proof_marks(self.h, m))
+        return list(m)
 
     def prof_read(self, which):
         self.lib.zkfhe_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),

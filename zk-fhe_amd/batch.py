@@ -95,9 +95,9 @@ def prove_batch(pk, inputs, seeds, contexts, with_instances=False):
 
 def gather_proofs(local, n_items, rank, world):
     """local: {global index: proof bytes} of this rank -> list of all n_items proofs (on every rank)."""
-    if world == 1:
-        return [local[i] for i in range(n_items)]
     import torch.distributed as dist
+    if world == 1 and not dist.is_initialized():
+        return [local[i] for i in range(n_items)]
     parts = [None] * world
     dist.all_gather_object(parts, local)
     merged = {}
@@ -113,7 +113,7 @@ def max_over_ranks(seconds, device=None):
     """Wall time of the slowest rank (what bench.py reports)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():      # a one-rank process GROUP still runs the collective (bench.py ZKFHE_BENCH_FORCE_DIST)
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -124,7 +124,7 @@ def gather_floats(value, device=None):
     """one float per rank -> list over ranks (on every rank); what bench.py reports per rank (host CPU per proof)"""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [float(value)]
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]

@@ -703,16 +703,20 @@ ZK_HD G1Affine g1x_to_affine(const G1X& p) {
 // Host: n accumulator-form sums -> affine points with ONE field inversion (Montgomery's trick over the non-zero ZZZ: three
 // products per point), x = X (ZZ / ZZZ)^2, y = Y / ZZZ as in g1x_to_affine; identity (ZZ = 0) -> (0, 0).  The prover normalises
 // the commitments of a Fiat-Shamir round this way (the MSM's last kernel stores the XYZZ sum and skips its own inversion).
+// A slot with ZZ != 0 and ZZZ == 0 is not a point any kernel writes (ZZ^3 = ZZZ^2); were one ever there (a stale or damaged
+// slot) it must stay ITS fault: it is left out of the shared product -- a zero factor would turn every point of the round into
+// garbage -- and comes out as the identity, which the Poseidon transcript refuses loudly.
 inline void g1x_normalize_batch(const G1X *in, size_t n, G1Affine *out) {
   std::vector<Fq> pre(n);
   Fq acc = Fq::one();
+  auto skip = [](const G1X &p) { return p.is_identity() || p.zzz.is_zero(); };
   for (size_t i = 0; i < n; ++i) {
     pre[i] = acc;
-    if (!in[i].is_identity()) acc = acc * in[i].zzz;
+    if (!skip(in[i])) acc = acc * in[i].zzz;
   }
   Fq inv = fp_inv<FqP>(acc);   // 1 / (product of all ZZZ)
   for (size_t i = n; i-- > 0;) {
-    if (in[i].is_identity()) {
+    if (skip(in[i])) {
       out[i].x = Fq::zero();
       out[i].y = Fq::zero();
       continue;

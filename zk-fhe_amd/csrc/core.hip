@@ -272,6 +272,13 @@ int zkfhe_prof_read_ops(zkfhe_ctx *ctx, int which, double *ops) {
   return ZKFHE_OK;
 }
 
+int zkfhe_ctx_last_proof_marks(zkfhe_ctx *ctx, float marks_ms[3]) {
+  ZK_ENTER(ctx);
+  ZK_ARG(ctx, marks_ms != nullptr);
+  for (int i = 0; i < 3; ++i) marks_ms[i] = ctx->proof_marks[i];
+  return ZKFHE_OK;
+}
+
 int zkfhe_timer_start(zkfhe_ctx *ctx) {
   ZK_ENTER(ctx);
   ZK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

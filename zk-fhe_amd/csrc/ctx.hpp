@@ -51,6 +51,9 @@ struct zkfhe_ctx {
   static constexpr size_t BOUNCE_BYTES = (size_t)1 << 20;
   void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[4] = {0, 0, 0, 0};
+  // host-side marks of the last proof made on this context, ms from its start (zkfhe_ctx_last_proof_marks): [0] the phase-0
+  // commitment is back from the GPU, [1] the first challenge is squeezed (behind the public inputs' sponge), [2] the proof is done
+  float proof_marks[3] = {0, 0, 0};
   unsigned *tickets = nullptr;   // zeroed counters: "last workgroup done" tickets of the table-path MSM, one per column (self-resetting)
 };
 

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256, 2) k_dif8_one(Dif8Args A) {
     const size_t c = wi % A.n_cols, pb = wi / A.n_cols;   // position-major: neighbours in the grid share their slice of T
     const size_t j0 = (pb << 8) + threadIdx.x;
     const size_t cs = c / A.rows, k1r = c - cs * A.rows;
-    const Fr *__restrict__ ps = A.src + cs * n + j0;
+    const Fr *ps = A.src + cs * n + j0;
     const Fr *__restrict__ tb = A.tab[k1r];
     Fr raw[8];
 #pragma unroll
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256, 2) k_dif8_one(Dif8Args A) {
     for (int s = 0; s < 8; ++s) t[s] = T[(size_t)brev3(s) << log_q];   // requested before the butterfly: the latency hides behind its products
     ZK_F
     ZK_DFT8_CORE(x, K)
-    Fr *__restrict__ pd = A.dst + c * n + j0;
+    Fr *pd = A.dst + c * n + j0;
     pd[(size_t)brev3(0) << log_q] = lz_store(mulw(y0, lw_unpack(t[0]))); ZK_F
     pd[(size_t)brev3(1) << log_q] = lz_store(mulw(y1, lw_unpack(t[1]))); ZK_F
     pd[(size_t)brev3(2) << log_q] = lz_store(mulw(y2, lw_unpack(t[2]))); ZK_F
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(128, 2) k_dif8_two(Dif8Args A) {
     const size_t c = wi % A.n_cols, pos = wi / A.n_cols;
     const size_t j0 = (pos << 4) + jj;
     const size_t cs = c / A.rows, k1r = c - cs * A.rows;
-    const Fr *__restrict__ ps = A.src + cs * n + j0;
+    const Fr *ps = A.src + cs * n + j0;
     const Fr *__restrict__ tb = A.tab[k1r];
     LzT x[8];
     {
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(128, 2) k_dif8_two(Dif8Args A) {
     for (int s = 0; s < 8; ++s) t[s] = T[(size_t)brev3(s) << log_q];
     ZK_F
     ZK_DFT8_CORE(x, K)
-    Fr *__restrict__ pd = A.dst + c * n + row0 + j0;
+    Fr *pd = A.dst + c * n + row0 + j0;
     pd[(size_t)brev3(0) << log_q] = lz_store(mulw(y0, lw_unpack(t[0]))); ZK_F
     pd[(size_t)brev3(1) << log_q] = lz_store(mulw(y1, lw_unpack(t[1]))); ZK_F
     pd[(size_t)brev3(2) << log_q] = lz_store(mulw(y2, lw_unpack(t[2]))); ZK_F
@@ -239,7 +239,9 @@ int zk_dif8_pass(zkfhe_ctx *ctx, const Fr *src, Fr *dst, size_t n_cols, int log_
         for (unsigned s = 1; s < 8; ++s) h[3 + 7 * g + (s - 1)] = lw_from_packed(zk_fr_to_29(fr_pow_u64(w64, (uint64_t)g * s)));
       void *d = nullptr;
       ZK_HIP(ctx, hipMalloc(&d, h.size() * sizeof(LwMem)));
-      if (hipMemcpy(d, h.data(), h.size() * sizeof(LwMem), hipMemcpyHostToDevice) != hipSuccess) {
+      // blocking copy + a wait on the null stream it ran on: the kernels that read the table run on ctx->stream, which is
+      // hipStreamNonBlocking and would not order itself behind the copy (once per table: they are cached with the context)
+      if (hipMemcpy(d, h.data(), h.size() * sizeof(LwMem), hipMemcpyHostToDevice) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
         (void)hipFree(d);
         return zk_fail_msg(ctx, ZKFHE_EHIP, "zk_dif8_pass: constant upload failed");
       }
@@ -271,7 +273,7 @@ int zk_dif8_pass(zkfhe_ctx *ctx, const Fr *src, Fr *dst, size_t n_cols, int log_
         cp[m] = cur;
         cur = cur * hq;
       }
-      if (hipMemcpy(d, cp.data(), M * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) {
+      if (hipMemcpy(d, cp.data(), M * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
         (void)hipFree(d);
         return zk_fail_msg(ctx, ZKFHE_EHIP, "zk_dif8_pass: constant upload failed");
       }

@@ -26,7 +26,12 @@ namespace zkhost {
 class PrefixCache {
  public:
   PrefixCache() {
-    if (const char *e = getenv("ZKFHE_PREFIX_CACHE")) capacity_ = (size_t)atoi(e) > 64 ? 64 : (size_t)atoi(e);
+    if (const char *e = getenv("ZKFHE_PREFIX_CACHE")) {
+      // a number in [0, 64]; anything else (negative, garbage, empty) leaves the default -- never "-1 = the maximum"
+      char *end = nullptr;
+      const long v = strtol(e, &end, 10);
+      if (end != e && *end == 0 && v >= 0) capacity_ = v > 64 ? 64 : (size_t)v;
+    }
   }
   static uint64_t fingerprint(const U256 *v, size_t n) {
     uint64_t h = 0x9e3779b97f4a7c15ULL ^ (uint64_t)n;

@@ -684,8 +684,10 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     points_canon(srs, ws->host_pts, cfg.n_gate0, pts.data());
   }
   trace.mark("commit phase 0 (GPU)");
+  ctx->proof_marks[0] = (float)(now_ms() - t_start);
   for (unsigned c = 0; c < cfg.n_gate0; ++c) tr.write_point(adv_commit[c] = pts[c]);
   const U256 gamma_rlc = tr.squeeze();
+  ctx->proof_marks[1] = (float)(now_ms() - t_start);
   // ------------------------------------------------------------ phase 1 witness
   const size_t nbl = n - u;
   int *lookup_err = nullptr;
@@ -1435,6 +1437,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   proof = tr.out;
   const double t_end = now_ms();
   trace.mark("evaluations + shplonk");
+  ctx->proof_marks[2] = (float)(t_end - t_start);
   if (timings) {
     timings[0] = (float)(t_wit - t_start);
     timings[1] = (float)(t_commit - t_wit);

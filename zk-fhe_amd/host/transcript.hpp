@@ -228,15 +228,25 @@ class Transcript {
     sp = s.sp;
   }
   // common_scalars_async, with a callback on the helper thread after the first `mark` values: the state at that point (the
-  // prover caches it per public key -- prefix_cache.hpp).  The first `mark` values always take the single-sponge path; the rest
-  // goes to the hash service when common_scalars_async would have sent the run there.
+  // prover caches it per public key -- prefix_cache.hpp).  Both halves, [0, mark) and [mark, end), go to the hash service when
+  // common_scalars_async would have sent the run there (shared mode: a batch of cold keys keeps the eight-lane saving), with the
+  // state taken between the two jobs; otherwise through the single sponge.  A callback that throws (it allocates) loses the
+  // cache entry, not the process.
   void common_scalars_async_marked(std::vector<U256> v, size_t mark, std::function<void(const State &)> on_mark) {
     join();
     pending = std::move(v);
     if (mark > pending.size()) mark = pending.size();
     worker = std::thread([this, mark, on_mark] {
-      for (size_t i = 0; i < mark; ++i) absorb_scalar(pending[i]);
-      on_mark(State{h, sp});
+      if (bulk_ok(mark)) {
+        sp.begin_bulk(pending.data(), mark, job);
+        sp.end_bulk(job);
+      } else {
+        for (size_t i = 0; i < mark; ++i) absorb_scalar(pending[i]);
+      }
+      try {
+        on_mark(State{h, sp});
+      } catch (...) {
+      }
       const size_t rest = pending.size() - mark;
       if (bulk_ok(rest)) {
         sp.begin_bulk(pending.data() + mark, rest, job);
