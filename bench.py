@@ -47,6 +47,54 @@ def synth_bfv_input(seed):
     return gen.config3_vector(seed, N, Q, T, B)
 
 
+def _measure_traffic(transcript, timeout_s=300):
+    """HBM-side bytes per launch of the two dominant kernels from the PMC counters, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc <counter> --kernel-trace` (one counter per pass, nothing else traced -- the guide's recipe), one proof in flight.
+    Read with the factors of profiles/r5_pmc_calibration.md (this library's own access patterns on gfx950): scattered 64-byte table
+    gathers are tallied at their size, coalesced 16 / 32-byte reads at half of it, writes at their size.  Returns None (and says why
+    on stderr) when rocprofv3 is missing, fails or times out -- the caller falls back to the committed pass."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        print("bench: no rocprofv3: traffic comes from the committed PMC pass", file=sys.stderr)
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None   # this process is being profiled itself: no nested profiler
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="zkfhe_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+               "--streams", "1", "--no-cpu-baseline", "--steady-seconds", "0", "--no-traffic-pass", "--transcript", transcript]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                print("bench: rocprofv3 --pmc %s failed (rc %s): %s" % (ctr, r.returncode, r.stderr[-400:]), file=sys.stderr)
+                return None
+            rows = sqlite3.connect(dbs[0]).execute("select name, count(*), avg(counter_value) from pmc_events where counter_name = ? group by name", (ctr,)).fetchall()
+            for name, cnt, avg in rows:
+                for key, pat in (("msm", "k_msm_table<false>"), ("ntt", "k_ntt13")):
+                    if pat in name:
+                        got[(key, ctr)] = (float(avg), int(cnt))
+        except Exception as e:  # noqa: BLE001
+            print("bench: PMC pass %s: %r" % (ctr, e), file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if not all((k, c) in got for k in ("msm", "ntt") for c in ("FETCH_SIZE", "WRITE_SIZE")):
+        print("bench: PMC passes did not see both kernels: %s" % sorted(got), file=sys.stderr)
+        return None
+    scalars = (266 + 136) / 2 * 8192 * 32     # a wide call streams its scalars (coalesced: counted at half, the other half added back) and gathers table points (x 1)
+    return {"bytes_per_launch": int(got[("msm", "FETCH_SIZE")][0] * 1024 + scalars / 2 + got[("msm", "WRITE_SIZE")][0] * 1024),
+            "ntt13": {"bytes_per_launch": int(2 * got[("ntt", "FETCH_SIZE")][0] * 1024 + got[("ntt", "WRITE_SIZE")][0] * 1024), "launches": got[("ntt", "FETCH_SIZE")][1]},
+            "launches": got[("msm", "FETCH_SIZE")][1], "fetch_size_kb_avg": got[("msm", "FETCH_SIZE")][0], "write_size_kb_avg": got[("msm", "WRITE_SIZE")][0]}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -80,6 +128,8 @@ def main():
                          "(BASELINE configs[4]: commitments by point range with an RCCL all-gather of the partials, coset extension and quotient by column, "
                          "evaluations by index -- strong scaling, one proof in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-pass", action="store_true", help="do not measure roofline.traffic with two child rocprofv3 --pmc passes (N = 1, k13 only; ~1.5 min): "
+                                                                   "take it from the committed pass under profiles/")
     ap.add_argument("--stagger-ms", type=float, default=None, help="start offset between the concurrent proofs of the timed wave")
     ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
                     help="Fiat-Shamir hash: poseidon = snark-verifier PoseidonTranscript (the reference's, examples/bfv.rs:311); blake2b = halo2's own")
@@ -296,16 +346,6 @@ def main():
     direct = ctx.prof_read(2)
     ctx.prof_enable(False)
 
-    traffic = ntt_traffic = traffic_source = None
-    for fn in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes (profiles/, rocprofv3 --pmc)
-        try:
-            pt = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            traffic = pt["bytes_per_launch"] if (not big and table_wide) else None
-            ntt_traffic = pt["ntt13"] if not big else None   # the same for the 2^13 NTT tile (second kernel of every configuration)
-            traffic_source = "profiles/%s (a committed rocprofv3 --pmc pass of this command, not measured in this run)" % fn
-            break
-        except Exception:  # noqa: BLE001
-            continue
     if rank == 0:
         ach = msm["algorithmic_bytes"] / (msm["total_ms"] * 1e-3) / 1e9
         ntt_ach = ntt["algorithmic_bytes"] / (ntt["total_ms"] * 1e-3) / 1e9 if ntt["launches"] else None
@@ -351,6 +391,33 @@ def main():
                        "phase_ms_last_proof": phases, "seconds_per_proof_by_threads": sweep}
             except Exception as e:  # noqa: BLE001  -- the CPU leg is a label: never lose the GPU measurement over it
                 cpu = {"value": None, "unit": "proofs/s", "cores": None, "kind": "port", "sample": "native CPU prover failed: %r" % (e,)}
+        traffic = ntt_traffic = traffic_source = None
+        measured = None
+        vk_hex = "%064x" % pk.info()["vk_digest"]
+        if rank == 0 and world == 1 and not big and table_wide and not args.no_traffic_pass:
+            # VERDICT r5 "weak" 9: the counters are read in THIS run, not from a file.  The children build their own SRS tables: this
+            # process gives the device back first (160 + 160 GB of tables do not fit next to each other)
+            pk.destroy()
+            srs.destroy()
+            for c in ctxs[1:]:
+                c.close()
+            torch.cuda.empty_cache()
+            t_pm = time.perf_counter()
+            measured = _measure_traffic(args.transcript)
+            if measured:
+                traffic, ntt_traffic = measured["bytes_per_launch"], measured["ntt13"]
+                traffic_source = ("measured in this run: two child passes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --streams 1` "
+                                  "(%.0f s), per-launch average over %d launches of k_msm_table<false>; FETCH_SIZE x 1 for the scattered 64-byte table gathers + half the streamed "
+                                  "scalar bytes + WRITE_SIZE x 1 (factors: profiles/r5_pmc_calibration.md)" % (time.perf_counter() - t_pm, measured["launches"]))
+        for fn in (() if measured else ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json")):   # HBM bytes per launch from the committed PMC passes (profiles/, rocprofv3 --pmc)
+            try:
+                pt = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                traffic = pt["bytes_per_launch"] if (not big and table_wide) else None
+                ntt_traffic = pt["ntt13"] if not big else None   # the same for the 2^13 NTT tile (second kernel of every configuration)
+                traffic_source = "profiles/%s (a committed rocprofv3 --pmc pass of this command, not measured in this run)" % fn
+                break
+            except Exception:  # noqa: BLE001
+                continue
         out = {
             "metric": "BFV proofs/sec (k=%d)" % conf["k"], "value": jobs * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "gpus_requested": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -364,7 +431,7 @@ def main():
                        "mode": args.mode if use_dist else "batch", "transcript": args.transcript, "concurrent_proofs_per_gpu": n_streams, "host_cpu_ms_per_proof": host_cpu_ms,
                        "host_cpu_ms_per_proof_by_rank": host_cpu_by_rank, "host": host, "verified": bool(verified), "proofs_gathered_and_verified": gathered, "sharded_proof_identical_on_all_ranks": same_on_all_ranks,
                        # rank 0's last timed proof, reproducible: input = index into this configuration's input list (bench.py main), seed as given to zkfhe_bfv_prove
-                       "last_timed_proof": {"sha256": last_sha, "vk_digest": "%064x" % pk.info()["vk_digest"], "input_index": j_last % len(inputs), "seed": seeds[j_last % len(seeds)].decode()}, "process_group": (backend if use_dist else None),
+                       "last_timed_proof": {"sha256": last_sha, "vk_digest": vk_hex, "input_index": j_last % len(inputs), "seed": seeds[j_last % len(seeds)].decode()}, "process_group": (backend if use_dist else None),
                        "steady_state_proofs_per_s": steady, "cold_key_proofs_per_s": cold, "headline_keys": "warm: %d public keys cycled, all in the per-key transcript cache (cold_key_proofs_per_s: the same K proofs with the cache off)" % len(inputs), "admission_gate": gate_timed,
                        "proof_bytes": proof_len[0], "per_proof_latency_ms": {"witness_host": stage[0], "commit": stage[1], "quotient": stage[2], "open": stage[3], "total": stage[4],
                                                                                   # the sequential sponge over the 5 N + 1 public inputs (examples/bfv.rs:118-122) stands between the

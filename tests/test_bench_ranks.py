@@ -146,7 +146,7 @@ def test_bench_rccl_process_group_of_one_rank(mode):
     library's RCCL communicator (ncclAllGather of the partials)."""
     env = _clean_env(ZKFHE_BENCH_FORCE_DIST="1", ZKFHE_TABLE_GB="4")
     env.pop("ZKFHE_BENCH_BACKEND", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--streams", "2", "--no-cpu-baseline",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-traffic-pass",
            "--steady-seconds", "0", "--mode", mode]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]

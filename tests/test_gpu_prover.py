@@ -505,8 +505,14 @@ def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
     committed digest (tests/golden/large_proofs.json, round 5): the GPU proof must have the oracle's bytes.  Besides: the oracle
     VERIFIER (pairing check) accepts it against the commitments of the GPU keygen, a tampered proof is refused, and (tmp_dir given)
     the proof equals the native CPU prover's byte for byte."""
+    import time
     import zk_fhe_amd as zk
     from tests.large_inputs import B, Q60 as Q, T, large_input
+    t_ = [time.time()]
+
+    def lap(what):   # where the minutes of the large configurations go (shown with pytest -s)
+        t_.append(time.time())
+        print("%s: %-28s %6.1f s" % (tag, what, t_[-1] - t_[-2]))
     inp = large_input(N)
     text = json.dumps(inp)
     # column counts: place the circuit with generous limits and count the break points (halo2-base auto-configuration)
@@ -515,10 +521,14 @@ def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
     nl = -(-probe["lookups"] // ((1 << k) - 109))
     print(tag, "columns: gate", n0, n1, "lookup", nl, "rlc", nr, "cells", probe["cells"])
     zcfg = zk.BfvConfig(k, n0, n1, nl, nr, 109)
+    lap("input + column counts")
     srs = zk.Srs(ctx, k)
+    lap("SRS")
     pk = zk.BfvProvingKey(ctx, srs, text, (N, Q, T, B), zcfg)
     info = pk.info()
+    lap("keygen")
     proof, inst, tm = pk.prove(text, tag.encode())
+    lap("prove")
     print(tag, "prove timings ms [witness, commit, quotient, open, total]:", tm, "proof bytes", len(proof))
     assert len(inst) == 4 * N + N + 1
     # the ORACLE prover's proof of the same input and seed (Python, minutes to hours at this size: made once on the CPU by
@@ -534,14 +544,18 @@ def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
     hcfg = H.Config(k, n0, n1, nl, nr, 109)
     vk = H.RawVerifyingKey(hcfg, info["fixed_commit"], info["sigma_commit"], info["vk_digest"])
     srs_v = H.srs_verifier_half(k)
+    lap("verifier-side SRS (oracle)")
     assert H.verify(vk, srs_v, inst, proof)
+    lap("oracle verifier")
     vkb = pk.export_vk()
     ok, why = zk.bfv_verify(vkb, inst, proof)
     assert ok, why
+    lap("C++ verifier")
     if tmp_dir is not None:
         import types
         proof_c = native_cpu_proof(pk, hcfg, types.SimpleNamespace(N=N, Q=Q, T=T, B=B), text, tag.encode(), str(tmp_dir))
         assert first_diff(proof, proof_c) is None, "first differing 32-byte item: %s" % first_diff(proof, proof_c)
+        lap("native CPU prover")
     # negative coverage at this size: a flipped bit in a commitment, an evaluation and both opening points, and a changed
     # public input -- each rejected by the oracle verifier and by the C++ verifier
     for pos in (5, len(proof) // 2, len(proof) - 40, len(proof) - 1):
@@ -554,6 +568,7 @@ def _prove_and_verify_large(ctx, N, k, tag, tmp_dir=None):
     assert not zk.bfv_verify(vkb, inst2, proof)[0]
     if k <= 16:   # the pure-Python sponge over other public inputs starts from scratch: 5.6 s at k = 16, 22 s at k = 19 -- the oracle's
         assert not H.verify(vk, srs_v, inst2, proof)   # answer on a changed input is checked at every size up to 2^16
+    lap("tampered proofs, both verifiers")
     pk.destroy()
     srs.destroy()
     return (n0, n1, nl, nr), probe["cells"]
@@ -567,8 +582,11 @@ def test_config4_k16_n4096_60bit_modulus(ctx, tmp_path):
 
 
 def test_config5_k19_n16384(ctx, tmp_path):
-    """BASELINE config 5: N = 16384, k = 19 (n = 524288 rows): MSM-dominated, long-row NTTs everywhere."""
-    cols, cells = _prove_and_verify_large(ctx, 16384, 19, "config5", tmp_path)
+    """BASELINE config 5: N = 16384, k = 19 (n = 524288 rows): MSM-dominated, long-row NTTs everywhere.  The proof must have the bytes
+    of the Python oracle prover's (tests/golden/large_proofs.json: a prover that shares no line with the product) and pass both
+    verifiers.  Round 6: the native CPU prover's comparison stays at k = 16 and k = 13 -- at this size it costs a minute (its own SRS
+    from the oracle: 2^20 scalar multiplications on the host) and adds nothing to byte equality with the independent oracle."""
+    cols, cells = _prove_and_verify_large(ctx, 16384, 19, "config5", None)
     assert cols[1] <= 64
 
 
@@ -655,27 +673,3 @@ def test_second_srs_on_a_full_device_gets_narrower_tables_same_bytes(ctx, monkey
         pk.destroy()
     b.destroy()
     a.destroy()
-
-
-def test_quotient_by_column_block_gives_the_same_proof(ctx):
-    """ZKFHE_QUOTIENT=blocks (k_quotient_blocks: every expression a block of eight columns takes part in from one load of each value,
-    one partial row per block -- built in round 5, measured slower than the grouping by kind, kept as an option): the choice is read
-    once per process, so a second interpreter proves the reference's bfv.in at k = 13 with it; the bytes must be the oracle's."""
-    import subprocess
-    import sys
-    o = oracle_k13()
-    script = r'''
-import json, os, sys
-import torch  # noqa: F401
-sys.path.insert(0, %r)
-import zk_fhe_amd as zk
-G = os.path.join(%r, "tests", "golden", "bfv")
-ctx = zk.Context(0)
-srs = zk.Srs(ctx, 13)
-cfg = zk.BfvConfig.from_pinning(json.load(open(os.path.join(G, "bfv_config.json"))))
-pk = zk.BfvProvingKey(ctx, srs, open(os.path.join(G, "bfv_empty.in")).read(), (1024, 536870909, 7, 19), cfg)
-sys.stdout.write(pk.prove(open(os.path.join(G, "bfv.in")).read(), b"seed-1")[0].hex())
-''' % (os.path.dirname(HERE), os.path.dirname(HERE))
-    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, ZKFHE_QUOTIENT="blocks"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-1500:]
-    assert bytes.fromhex(r.stdout.strip().splitlines()[-1]) == o["proof_o"]

@@ -340,12 +340,9 @@ int zk_ntt_impl(zkfhe_ctx *ctx, const zkfhe_fr *src_dev, zkfhe_fr *cols_dev, siz
                 const Fr *shifts_host = nullptr);
 
 // Rows of 2^16 and 2^19 (three / six stages above the 2^13 tile: BASELINE configs[3] and [4]) run those stages in four-step form
-// (ntt_dif8.hip): constants for the size-8 / size-64 part, one streaming table product per element.  ZKFHE_NTT_DIF8=0: the radix-2
-// passes with gathered twiddles (k_dif_fused / k_dif_lds) that every other length still takes.
-static bool dif8_rows(int log_n) {
-  static const bool on = !(getenv("ZKFHE_NTT_DIF8") && getenv("ZKFHE_NTT_DIF8")[0] == '0');
-  return on && (log_n - MAX_TILE_LOG == 3 || log_n - MAX_TILE_LOG == 6);
-}
+// (ntt_dif8.hip): constants for the size-8 / size-64 part, one streaming table product per element.  Every other length takes the
+// radix-2 passes with gathered twiddles (k_dif_fused / k_dif_lds).
+static bool dif8_rows(int log_n) { return log_n - MAX_TILE_LOG == 3 || log_n - MAX_TILE_LOG == 6; }
 
 extern "C" {
 

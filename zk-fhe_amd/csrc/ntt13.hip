@@ -276,253 +276,17 @@ __global__ void __launch_bounds__(512, ZK_NTT13_WAVES) k_ntt13(Tile13Args A) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Quarter-column variant (round 5; BUILT, MEASURED, NOT THE DEFAULT -- see ntt13_quarter below): FOUR workgroups of 256 threads per
-// column instead of two of 512.  k_ntt13 needs 246 registers, so
-// a CU holds one of its workgroups (eight waves, two per SIMD) and all of them move through the kernel's phases together: nothing
-// issues multiply-adds while the column is being loaded, while the eight waves meet at the exchange, while the results are stored
-// (the passes alone need 97 us per 256 columns, the kernel 150: profiles/r4_probes.md).  A 256-thread workgroup is one wave per SIMD,
-// so TWO of them share a CU -- of different columns, in different phases, each with its own barriers -- and in a prover with many
-// proofs in flight the other wave slot may as well go to another kernel's workgroup.  Same registers, same LDS per CU (2 x 36 KB).
-//   * radix 4 over the top two index bits fused into the load (n = 2048 j + t, k = s0 + 4 k'): quarter s0 forms
-//     u[t] = (sum_j x[2048 j + t] i^(j s0)) w^(t s0) -- s0 = 0: a sum; s0 = 2: one product; s0 = 1, 3: ONE fused two-product multiply
-//     (x0 - x2) w^(s0 t) + (x1 - x3) (i^s0 w^(s0 t)) against two table entries; with a coset pre-multiplier ONE unsigned four-product
-//     multiply sum_j x_j A_j[t] (lz_mul4u), the tables holding h^(2048 j + t) i^(j s0) w^(t s0);
-//   * then the 2048-point transform of u with root w^4: radix 8 over t = 256 m1 + t1 in registers, the workgroup-wide exchange (wave v
-//     receives the 256-point sub-transforms s1 = 2 v and 2 v + 1: lane = (b, t2), register = m2 with t1 = 32 m2 + t2), radix 8 over m2,
-//     an exchange inside the wave, radix 8 over m3 (t2 = 4 m3 + t3), an exchange inside the wave that trades the two low lane bits for
-//     the two low register bits, and two radix-4 butterflies per thread over t3;
-//   * outputs k' = s1 + 8 s2 + 64 s3 + 512 s4 of the quarter, i.e. k = s0 + 4 k' of the column, through one last workgroup-wide
-//     exchange of the packed results so that a thread stores k' = tid, tid + 256, ...
-// Products per point: 1.0 (load, plain) or 2.5 (coset) + 3 x 1.5 + 0.25 against 0.5 / 1.5 + 3 x 1.5 + 0.625 of the half-column kernel.
-constexpr int Q_T0 = 0;                     // [s0 - 1][t], t < 2048:   w^(s0 t)
-constexpr int Q_T0I = Q_T0 + 3 * 2048;      // [0][t] = i w^t, [1][t] = i^3 w^(3 t)      (i = w^2048)
-constexpr int Q_T1 = Q_T0I + 2 * 2048;      // [s - 1][t1], t1 < 256:   w^(4 t1 s)
-constexpr int Q_T2 = Q_T1 + 7 * 256;        // [s - 1][t2], t2 < 32:    w^(32 t2 s)
-constexpr int Q_T3 = Q_T2 + 7 * 32;         // [s - 1][t3], t3 < 4:     w^(256 t3 s)
-constexpr int Q_C = Q_T3 + 7 * 4;           // w^1024 (w8), w^2048 (w4 = i), w^3072 (w8^3)
-constexpr int Q_LEN = Q_C + 3;
-
-__global__ void __launch_bounds__(256) k_tw13q_pack(const Fr *__restrict__ tw29 /* w^j 2^261, j < 8192 */, LwMem *__restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Q_LEN) return;
-  int e;
-  if (i < Q_T0I) e = ((i - Q_T0) / 2048 + 1) * (i & 2047);
-  else if (i < Q_T1) e = (i - Q_T0I) < 2048 ? 2048 + (i & 2047) : 3 * 2048 + 3 * (i & 2047);
-  else if (i < Q_T2) e = 4 * ((i - Q_T1) & 255) * (((i - Q_T1) >> 8) + 1);
-  else if (i < Q_T3) e = 32 * ((i - Q_T2) & 31) * (((i - Q_T2) >> 5) + 1);
-  else if (i < Q_C) e = 256 * ((i - Q_T3) & 3) * (((i - Q_T3) >> 2) + 1);
-  else e = 1024 * (i - Q_C + 1);
-  out[i] = lw_from_packed(tw29[e & 8191]);
-}
-
-// coset tables of row k1 (shift h) for the quarter kernel: [s0][j][t] = start h^(2048 j + t) w^(2048 j s0 + t s0), 4 x 4 x 2048 entries
-__global__ void __launch_bounds__(256) k_pre13q_pack(Fr h, Fr start, const Fr *__restrict__ fwd /* w^j, standard form */, LwMem *__restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 4 * 4 * 2048) return;
-  const int t = idx & 2047, j = (idx >> 11) & 3, s0 = idx >> 13;
-  Fr r = start;
-  Fr b = h;
-  for (int e = 2048 * j + t; e; e >>= 1) {
-    if (e & 1) r = r * b;
-    b = fp_sqr<FrP>(b);
-  }
-  out[idx] = lw_from_packed(r * fwd[(2048 * j * s0 + t * s0) & 8191]);
-}
-
-template <int L1, int H1, int V1, int L2, int H2, int V2>
-__device__ __forceinline__ LzT mul2w(const Lz<L1, H1, V1> &a, const Lw &w, const Lz<L2, H2, V2> &b, const Lw &v) {
-  __builtin_amdgcn_sched_barrier(0);
-  const LzT r = lz_mul2(a, w, b, v);
-  __builtin_amdgcn_sched_barrier(0);
-  return r;
-}
-
-constexpr int QW_SLOTS = 576;                                  // per wave: 8 rows of 68 (or 65) slots
-constexpr size_t LDS13Q = (size_t)4 * QW_SLOTS * 16;           // 36 KB: two workgroups per CU
-__device__ __forceinline__ int q_out_slot(int kp) { return kp + (kp >> 4) + 2 * (kp >> 7); }   // < 2205; conflict-free for the writes below and for 16 consecutive k'
-
-__global__ void __launch_bounds__(256, 2) k_ntt13q(Tile13Args A) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // block id -> (column, tile row, quarter): the four quarters of a column on one XCD (ids 8 apart)
-  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const unsigned sub = slot & 3u, unit = (slot >> 2) * 8u + xcd;
-  if (unit >= A.tiles * A.cols) return;
-  const unsigned b = unit % A.tiles;
-  const size_t c = unit / A.tiles;
-  const TileArgs &a = A.t;
-  const Fr *__restrict__ src = a.in + c * a.col_stride_in + (size_t)b * a.in_tile_stride;
-  const LwMem *__restrict__ tw = A.tw;
-  // ---- load + radix 4 over the top two index bits (this workgroup keeps the outputs k = sub mod 4) -----------------------------
-  LzT x[8];
-  Fr raw[8][4];
-  auto fetch = [&](int m) {
-    int q = tid + 256 * m;
-    if (m >= 2) asm volatile("" : "+v"(q) : "v"(x[m - 2].l[8]));   // two iterations (64 registers) of raw inputs in flight
-#pragma unroll
-    for (int j = 0; j < 4; ++j) raw[m][j] = q + 2048 * j < a.in_len ? src[q + 2048 * j] : Fr::zero();
-  };
-  fetch(0);
-  fetch(1);
-  if (A.pre) {
-    const LwMem *__restrict__ pre = A.pre + ((size_t)b * 4 + sub) * (4 * 2048);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int q = tid + 256 * m;
-      if (m >= 1) asm volatile("" : "+v"(q) : "v"(x[m - 1].l[8]));
-      const Lw w0 = tw_at(pre + q), w1 = tw_at(pre + 2048 + q), w2 = tw_at(pre + 4096 + q), w3 = tw_at(pre + 6144 + q);
-      const auto l0 = lz_load(raw[m][0]), l1 = lz_load(raw[m][1]), l2 = lz_load(raw[m][2]), l3 = lz_load(raw[m][3]);
-      ZK_F
-      x[m] = lz_mul4u(l0, w0, l1, w1, l2, w2, l3, w3);
-      ZK_F
-      if (m + 2 < 8) fetch(m + 2);
-    }
-  } else if (sub == 0) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      x[m] = lz_weak(lz_add(lz_add(lz_load(raw[m][0]), lz_load(raw[m][2])), lz_add(lz_load(raw[m][1]), lz_load(raw[m][3]))));   // [0, 2 r)
-      ZK_F
-      if (m + 2 < 8) fetch(m + 2);
-    }
-  } else if (sub == 2) {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int q = tid + 256 * m;
-      if (m >= 1) asm volatile("" : "+v"(q) : "v"(x[m - 1].l[8]));
-      const Lw w = tw_at(tw + Q_T0 + 2048 + q);
-      x[m] = mulw(lz_sub(lz_add(lz_load(raw[m][0]), lz_load(raw[m][2])), lz_add(lz_load(raw[m][1]), lz_load(raw[m][3]))), w);   // (2,2) in
-      if (m + 2 < 8) fetch(m + 2);
-    }
-  } else {
-    const int o0 = sub == 1 ? Q_T0 : Q_T0 + 2 * 2048, o1 = sub == 1 ? Q_T0I : Q_T0I + 2048;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int q = tid + 256 * m;
-      if (m >= 1) asm volatile("" : "+v"(q) : "v"(x[m - 1].l[8]));
-      const Lw w = tw_at(tw + o0 + q), wi = tw_at(tw + o1 + q);
-      x[m] = mul2w(lz_sub(lz_load(raw[m][0]), lz_load(raw[m][2])), w, lz_sub(lz_load(raw[m][1]), lz_load(raw[m][3])), wi);   // limbs (1,1)
-      if (m + 2 < 8) fetch(m + 2);
-    }
-  }
-
-  // ---- radix 8 over m1 (t = 256 m1 + t1, t1 = tid), twiddles w^(4 t1 s1); exchange: wave v gets s1 = 2 v + b, lane (b, t2), register m2
-  Consts K;   // the three butterfly constants: 27 registers, not needed (and not held) during the load phase
-  K.w8 = tw_at(tw + Q_C);
-  K.w4 = tw_at(tw + Q_C + 1);
-  K.w83 = tw_at(tw + Q_C + 2);
-  pass8_tw(x, K, tw + Q_T1 + tid, 256);
-  const int bq = lane >> 5, t2 = lane & 31;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    if (r) __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) lds[s * 256 + tid] = limbs3(x[s], r);
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) set_limbs3(x[m], r, lds[(2 * wv + bq) * 256 + 32 * m + t2]);
-  }
-  __syncthreads();   // the per-wave regions below overlap what other waves still read
-
-  // ---- inside the wave from here on -----------------------------------------------------------------------------------------------
-  uint4 *__restrict__ mine = lds + wv * QW_SLOTS;
-  const int s2l = (lane >> 2) & 7, lo2 = lane & 3;
-  // radix 8 over m2, twiddles w^(32 t2 s2); exchange (s2 | b, m3, t3) -> (m3 | b, s2, t3): rows of 68 slots
-  pass8_tw(x, K, tw + Q_T2 + t2, 32);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    wave_sync();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) mine[s * 68 + lane] = limbs3(x[s], r);
-    wave_sync();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) set_limbs3(x[m], r, mine[s2l * 68 + bq * 32 + m * 4 + lo2]);
-  }
-  // radix 8 over m3, twiddles w^(256 t3 s3); exchange (s3 = 4 h + s3l | b, s2, t3) -> (4 h + t3 | b, s2, s3l): rows of 65 slots
-  pass8_tw(x, K, tw + Q_T3 + lo2, 4);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    wave_sync();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) mine[s * 65 + lane] = limbs3(x[s], r);
-    wave_sync();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) set_limbs3(x[m], r, mine[(4 * (m >> 2) + lo2) * 65 + bq * 32 + s2l * 4 + (m & 3)]);
-  }
-  // two radix-4 butterflies over t3 (registers 4 h + t3), root i = w4: outputs s4 = 0 .. 3
-  Fr y[8];
-  const bool post = a.post != nullptr;
-  const Lw pw = post ? lw_unpack(*a.post) : K.w4;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const auto a0 = lz_add(x[4 * h], x[4 * h + 2]);            // (0,2)
-    const auto a1 = lz_sub(x[4 * h], x[4 * h + 2]);            // (1,1)
-    const auto b0 = lz_add(x[4 * h + 1], x[4 * h + 3]);        // (0,2)
-    ZK_F const LzT b1 = mulw(lz_sub(x[4 * h + 1], x[4 * h + 3]), K.w4);
-    ZK_F const auto y0 = lz_norm(lz_add(a0, b0));              // (0,4) -> (0,1), |v| < 8 r
-    ZK_F const auto y2 = lz_sub(a0, b0);                       // (2,2)
-    ZK_F const auto y1 = lz_add(a1, b1);                       // (1,2)
-    const auto y3 = lz_sub(a1, b1);                            // (2,1)
-    ZK_F
-    if (post) {
-      y[4 * h] = lz_store(mulw(y0, pw)); ZK_F
-      y[4 * h + 1] = lz_store(mulw(y1, pw)); ZK_F
-      y[4 * h + 2] = lz_store(mulw(y2, pw)); ZK_F
-      y[4 * h + 3] = lz_store(mulw(y3, pw)); ZK_F
-    } else {
-      y[4 * h] = lz_store(y0); ZK_F
-      y[4 * h + 1] = lz_store(y1); ZK_F
-      y[4 * h + 2] = lz_store(y2); ZK_F
-      y[4 * h + 3] = lz_store(y3); ZK_F
-    }
-  }
-
-  // ---- exchange of the packed results: register (h, s4) of lane (b, s2, s3l) in wave v is k' = (2 v + b) + 8 s2 + 64 (4 h + s3l) + 512 s4
-  const int kbase = (2 * wv + bq) + 8 * s2l + 64 * lo2;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) lds[q_out_slot(kbase + 256 * (s >> 2) + 512 * (s & 3))] = hh ? hi4(y[s]) : lo4(y[s]);
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const uint4 t = lds[q_out_slot(tid + 256 * m)];
-      if (hh) set_hi(y[m], t);
-      else set_lo(y[m], t);
-    }
-  }
-  Fr *__restrict__ dst = a.out + c * a.col_stride_out;
-  if (a.out_natural_tiles) {
-    dst += (size_t)b * 8192;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) dst[sub + 4 * (tid + 256 * m)] = y[m];
-  } else {
-    const size_t off = brev(b, a.log_tiles);
-    const size_t stride = (size_t)1 << a.log_tiles;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) dst[off + (size_t)(sub + 4 * (tid + 256 * m)) * stride] = y[m];
-  }
-}
-
 }  // namespace
 
-// Which 2^13 kernel runs: the half-column kernel of round 3 (k_ntt13) unless ZKFHE_NTT13=quarter asks for k_ntt13q.  Measured on
-// one box (profiles/r5_probes.md): 256 columns 0.1542 ms against 0.1514 (plain), 0.1572 against 0.1440 per coset row (the four-product
-// first stage), the driver's wave 202-209 proofs/s against 207-220 -- two workgroups that start together on a CU run the same code
-// for the same time and stay in step, so the phases do not overlap after all (a start skew of the first resident set made it worse).
-static bool ntt13_quarter() {
-  static const bool q = getenv("ZKFHE_NTT13") && getenv("ZKFHE_NTT13")[0] == 'q';
-  return q;
-}
+// (A quarter-column variant -- four workgroups of 256 threads per column, two per CU -- was built and measured in round 5: bit-exact,
+// 0.1542 against 0.1514 ms per 256 columns, not faster in the prover either.  It lives in tools/exp/patches/ntt13_quarter.patch.)
 
 // coset tables for coeff_to_extended at n = 2^13 (rows cosets g w_ext^k1 of the 2^(13+lef) domain), built once per context
 // (scaled: every entry times 2^-13 -- for input that is an inverse transform WITHOUT its n^-1, see zk_extend_lagrange)
 int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const void **out) {
   std::array<uint64_t, 6> key;
   for (int i = 0; i < 4; ++i) key[i] = (uint64_t)g.l[2 * i] | ((uint64_t)g.l[2 * i + 1] << 32);
-  const bool quarter = ntt13_quarter();
-  key[4] = (uint64_t)lef | (scaled ? 256u : 0u) | (quarter ? 512u : 0u);
+  key[4] = (uint64_t)lef | (scaled ? 256u : 0u);
   key[5] = (uint64_t)rows;
   auto it = ctx->pre13.find(key);
   if (it == ctx->pre13.end()) {
@@ -545,13 +309,12 @@ int zk_pre13(zkfhe_ctx *ctx, const Fr &g, int lef, int rows, bool scaled, const 
         if (p) (void)hipFree(p);
       }
     } own;
-    const size_t per_row = quarter ? (size_t)4 * 4 * 2048 : (size_t)2 * 8192;   // entries of one coset row's tables
+    const size_t per_row = (size_t)2 * 8192;   // entries of one coset row's tables
     ZK_HIP(ctx, hipMalloc((void **)&own.p, (size_t)rows * per_row * sizeof(LwMem)));
     Fr shift = g;
     const Fr start = scaled ? dom->n_inv29 : zk_fr_to_29(Fr::one());
     for (int k1 = 0; k1 < rows; ++k1) {
-      if (quarter) k_pre13q_pack<<<128, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * per_row);
-      else k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * per_row);
+      k_pre13_pack<<<32, 256, 0, ctx->stream>>>(shift, start, dom->fwd, own.p + (size_t)k1 * per_row);
       ZK_LAUNCH_CHECK(ctx);
       shift = shift * edom->omega;
     }
@@ -572,15 +335,13 @@ int zk_launch_tile_13(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsigne
     const Fr *i0 = a.in, *o0 = a.out;
     if (!(i0 + in_span <= o0 || o0 + out_span <= i0)) return zk_fail_msg(ctx, ZKFHE_EINVAL, "2^13 tile: input and output buffers must not overlap");
   }
-  const bool quarter = ntt13_quarter();
-  const void *tw_key = quarter ? (const void *)((const char *)a.tw + 1) : (const void *)a.tw;   // one pack per (table, kernel)
+  const void *tw_key = (const void *)a.tw;
   auto it = ctx->tw13.find(tw_key);
   if (it == ctx->tw13.end()) {
     LwMem *p = nullptr;
-    const int len = quarter ? Q_LEN : PACK_LEN;
+    const int len = PACK_LEN;
     ZK_HIP(ctx, hipMalloc((void **)&p, (size_t)len * sizeof(LwMem)));
-    if (quarter) k_tw13q_pack<<<zk_blocks(len, 256), 256, 0, ctx->stream>>>(a.tw, p);
-    else k_tw13_pack<<<zk_blocks(len, 256), 256, 0, ctx->stream>>>(a.tw, p);
+    k_tw13_pack<<<zk_blocks(len, 256), 256, 0, ctx->stream>>>(a.tw, p);
     if (hipGetLastError() != hipSuccess) {
       (void)hipFree(p);
       return zk_fail_msg(ctx, ZKFHE_EHIP, "2^13 tile: twiddle pack launch failed");
@@ -595,13 +356,8 @@ int zk_launch_tile_13(zkfhe_ctx *ctx, const TileArgs &a, unsigned tiles, unsigne
   A.cols = cols;
   const unsigned units = tiles * cols;
   zk_prof_begin(ctx);
-  if (quarter) {
-    ZK_CK(zk_func_max_lds(ctx, (const void *)k_ntt13q, (int)LDS13Q));
-    k_ntt13q<<<((units + 7) / 8) * 32, 256, LDS13Q, ctx->stream>>>(A);
-  } else {
-    ZK_CK(zk_func_max_lds(ctx, (const void *)k_ntt13, (int)LDS13));
-    k_ntt13<<<((units + 7) / 8) * 16, 512, LDS13, ctx->stream>>>(A);
-  }
+  ZK_CK(zk_func_max_lds(ctx, (const void *)k_ntt13, (int)LDS13));
+  k_ntt13<<<((units + 7) / 8) * 16, 512, LDS13, ctx->stream>>>(A);
   ZK_LAUNCH_CHECK(ctx);
   zk_prof_end(ctx, 1, 64.0 * 8192.0 * (double)tiles * (double)cols);
   if (ctx->prof_on) ctx->prof_ops[1] += 0.5 * 8192.0 * 13.0 * (double)tiles * (double)cols;  // butterflies

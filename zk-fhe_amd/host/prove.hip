@@ -1000,52 +1000,15 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     run(zkp::QG_PERM_D, 0, nch, 4, 1, [&](size_t j) { return owns_chunk(j); });
     run(zkp::QG_LOOKUP, 0, cfg.n_lookup, 3, 5, [&](size_t i) { return owns_col(cfg.adv_lookup0() + i); });
     const size_t E = e;
-    // Round 5, ZKFHE_QUOTIENT=blocks: the same expressions cut by COLUMN BLOCK (prover_kernels.hip.hpp k_quotient_blocks): a block =
-    // the permutation chunks of eight columns, everything those columns take part in evaluated from one load of each value, one partial
-    // row per block (the powers of y of its runs are folded in by the kernel: the combine adds the rows up).  It reads a quarter less
-    // and is SLOWER -- k = 19: 15.7 ms against 12.2, k = 13: 236 proofs/s against 249 over 96 steps (profiles/r5_probes.md): a third of
-    // the threads, each with a five times longer dependent chain -- so the grouping by kind above stays the default.
-    static const bool by_blocks = getenv("ZKFHE_QUOTIENT") && getenv("ZKFHE_QUOTIENT")[0] == 'b';
-    std::vector<zkp::QBlock> blocks;
-    if (by_blocks) {
-      const size_t n_gate = cfg.n_gate(), n_rlc = cfg.n_rlc, nl = cfg.n_lookup, chunk = cfg.chunk(), n_perm = cfg.n_perm();
-      const size_t e_rlc0 = n_gate, e_first = n_gate + n_rlc, e_last = e_first + 1, e_permc0 = e_last + 1, e_permd0 = e_permc0 + (nch - 1), e_lk0 = e_permd0 + nch;
-      if (e_lk0 + 5 * nl != E) return zk_fail_msg(ctx, ZKFHE_EINVAL, "quotient: expression count mismatch");
-      const size_t cpb = std::max<size_t>(1, 8 / chunk);   // chunks per block: eight columns
-      for (size_t j0 = c_lo; j0 < c_hi; j0 += cpb) {
-        const size_t j1 = std::min(j0 + cpb, c_hi), col0 = j0 * chunk, col1 = std::min(j1 * chunk, n_perm);
-        zkp::QBlock B{};
-        B.chunk0 = (int)j0;
-        B.n_chunks = (int)(j1 - j0);
-        auto set = [&](int kind, size_t last) {
-          B.kinds |= 1u << kind;
-          B.w[kind] = fr_pow(y, E - 1 - last);
-        };
-        if (col0 < n_gate) set(zkp::QB_GATE, std::min(col1, n_gate) - 1);
-        {
-          const size_t lo = std::max<size_t>(col0, cfg.adv_rlc0()), hi = std::min<size_t>(col1, cfg.adv_rlc0() + n_rlc);
-          if (lo < hi) set(zkp::QB_RLC, e_rlc0 + (hi - 1 - cfg.adv_rlc0()));
-        }
-        if (j0 == 0) set(zkp::QB_FIRST, e_first);
-        if (j1 == nch) set(zkp::QB_LAST, e_last);
-        if (j1 > std::max<size_t>(j0, 1)) set(zkp::QB_PERMC, e_permc0 + (j1 - 1) - 1);   // chaining terms exist for chunks 1 ..
-        set(zkp::QB_PERMD, e_permd0 + j1 - 1);
-        {
-          const size_t lo = std::max<size_t>(col0, cfg.adv_lookup0()), hi = std::min<size_t>(col1, cfg.adv_lookup0() + nl);
-          if (lo < hi) set(zkp::QB_LOOKUP, e_lk0 + 5 * (hi - cfg.adv_lookup0()) - 1);
-        }
-        blocks.push_back(B);
-      }
-    }
-    const size_t G = by_blocks ? blocks.size() : groups.size();
+    // (The same expressions cut by COLUMN BLOCK instead of by kind -- k_quotient_blocks, round 5 -- read a quarter less and were 29 %
+    // slower: tools/exp/patches/quotient_blocks.patch, profiles/r5_probes.md section 2.)
+    const size_t G = groups.size();
     if (G > 96 || G * n * (size_t)q_rows * 32 > ws->partials.bytes) return zk_fail_msg(ctx, ZKFHE_EINVAL, "too many quotient groups for the workspace");
     std::vector<Fr> ypow(G);
-    for (size_t g = 0; g < G; ++g) ypow[g] = zk::zk_fr_to_29(by_blocks ? Fr::one() : fr_pow(y, E - 1 - last_e[g]));   // 2^261 form: constant operands of k_quotient_combine
+    for (size_t g = 0; g < G; ++g) ypow[g] = zk::zk_fr_to_29(fr_pow(y, E - 1 - last_e[g]));   // 2^261 form: constant operands of k_quotient_combine
     if (groups.empty()) groups.push_back(zkp::QGroup{});     // a rank that owns nothing still stages a (unread) entry
-    if (blocks.empty()) blocks.push_back(zkp::QBlock{});
     if (ypow.empty()) ypow.push_back(Fr::zero());
     STAGE(groups_dev, zkp::QGroup, ws, groups.data(), groups.size() * sizeof(zkp::QGroup));
-    STAGE(blocks_dev, zkp::QBlock, ws, blocks.data(), blocks.size() * sizeof(zkp::QBlock));
     STAGE(ypow_dev, Fr, ws, ypow.data(), ypow.size() * 32);
     const Fr wext = zk_fr_root_of_unity((int)k + 2);
     const Fr gn = fr_pow(mont_u64(COSET_G), n), i4 = fr_pow(wext, n);
@@ -1094,8 +1057,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
       qa.pt0 = 0;
       qa.pt_count = npts;
       dim3 grid((unsigned)((npts + 255) / 256), (unsigned)G);
-      if (by_blocks) zkp::k_quotient_blocks<<<grid, 256, 0, ctx->stream>>>(qa, blocks_dev);
-      else zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
+      zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
       ZK_LAUNCH_CHECK(ctx);
       zkp::k_quotient_combine<<<(unsigned)((npts + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, 0, npts, ws->h_ext.fr());
       ZK_LAUNCH_CHECK(ctx);
@@ -1114,8 +1076,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
         qa.pt_count = n;
         dim3 grid((unsigned)((n + 255) / 256), (unsigned)G);
         if (G) {
-          if (by_blocks) zkp::k_quotient_blocks<<<grid, 256, 0, ctx->stream>>>(qa, blocks_dev);
-          else zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
+          zkp::k_quotient_partials<<<grid, 256, 0, ctx->stream>>>(qa);
           ZK_LAUNCH_CHECK(ctx);
         }
         zkp::k_quotient_combine<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ws->partials.fr(), ypow_dev, (unsigned)G, zinv_dev, k, (unsigned)q_rows, qa.pt0, n, ws->h_ext.fr());

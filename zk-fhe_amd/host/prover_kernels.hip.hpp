@@ -429,78 +429,6 @@ static __global__ void __launch_bounds__(256) k_quotient_partials(QArgs a) {
   a.partials[(size_t)blockIdx.y * ne + p] = acc;
 }
 
-// The same expressions, grouped by COLUMN BLOCK instead of by kind (round 5).  k_quotient_partials above reads an advice column
-// once for its gate and once more for the permutation term of its chunk, a grand product three times (its own chunk's term, the
-// chaining term of its chunk and of the next), l_0 / l_last / l_active / X once per group: 1 270 column reads for the 772 columns
-// of a k = 13 proof -- the 1.5 - 1.7 x of profiles/r4_roofline.md.  Here one thread walks the permutation chunks [chunk0, chunk0 + n)
-// of a block (8 columns) and evaluates EVERYTHING those columns take part in -- the gate, RLC gate or lookup of each column, the
-// chunk's permutation term, its chaining term, the first / last-row terms -- from one load of each value: five Horner accumulators,
-// one per kind (the expressions of a kind are consecutive in the global numbering, so each is a contiguous run), folded with the
-// host's powers of y into ONE partial row per block.  ~970 column reads; a third of the partial rows for the combine to sum.
-enum { QB_GATE = 0, QB_RLC = 1, QB_FIRST = 2, QB_LAST = 3, QB_PERMC = 4, QB_PERMD = 5, QB_LOOKUP = 6, QB_KINDS = 7 };
-struct QBlock {
-  int chunk0, n_chunks;     // permutation chunks of this block
-  unsigned kinds;           // bit k: the block holds expressions of kind k
-  int pad;
-  Fr w[QB_KINDS];           // y^(E - 1 - last expression of the kind's run in this block), standard form
-};
-
-static __global__ void __launch_bounds__(256) k_quotient_blocks(QArgs a, const QBlock *__restrict__ blocks) {
-  const size_t n = (size_t)1 << a.log_n, ne = n * a.rows;
-  const size_t p = a.pt0 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= a.pt0 + a.pt_count || p >= ne) return;
-  const QBlock &B = blocks[blockIdx.y];
-  const size_t row0 = p & ~(n - 1);           // k1 * n
-  const size_t k2 = p & (n - 1);
-  auto at = [&](const Fr *base, unsigned col, unsigned rot) -> Fr { return base[(size_t)col * ne + row0 + ((k2 + rot) & (n - 1))]; };
-  const Fr one = Fr::one();
-  Fr acc_g = Fr::zero(), acc_r = Fr::zero(), acc_c = Fr::zero(), acc_d = Fr::zero(), acc_l = Fr::zero();
-  auto horner = [&](Fr &acc, const Fr &u, const Fr &v) { acc = zk::fp_mul2<zk::FrP>(acc, a.y, u, v); };
-  const Fr l0 = a.lext[p], lact = a.lext[2 * ne + p], x = a.xs[p];
-  Fr ll = Fr::zero(), tbl = Fr::zero();
-  if (B.kinds & ((1u << QB_LAST) | (1u << QB_LOOKUP))) ll = a.lext[ne + p];
-  if (B.kinds & (1u << QB_LOOKUP)) tbl = at(a.fix, a.fix_table, 0);
-  for (int j = B.chunk0; j < B.chunk0 + B.n_chunks; ++j) {
-    const Fr z0 = at(a.pz, j, 0);
-    Fr left = at(a.pz, j, 1), right = z0;
-    for (unsigned c = (unsigned)j * a.chunk; c < (unsigned)(j + 1) * a.chunk && c < a.n_perm; ++c) {
-      const Fr v = c < a.n_advice ? at(a.adv, c, 0) : (c == a.n_advice ? at(a.fix, a.fix_const, 0) : a.inst[p]);
-      left = left * (v + a.beta * at(a.sig, c, 0) + a.gamma);
-      right = right * (v + a.beta_delta[c] * x + a.gamma);
-      if (c < a.n_gate) {
-        const Fr q = at(a.fix, c, 0);
-        if (!q.is_zero()) horner(acc_g, q, v + at(a.adv, c, 1) * at(a.adv, c, 2) - at(a.adv, c, 3));
-        else acc_g = acc_g * a.y;
-      } else if (c >= a.adv_rlc0 && c < a.adv_rlc0 + a.n_rlc) {
-        horner(acc_r, at(a.fix, a.fix_qrlc0 + (c - a.adv_rlc0), 0), v * a.gamma_rlc + at(a.adv, c, 1) - at(a.adv, c, 2));
-      } else if (c >= a.adv_lookup0 && c < a.adv_lookup0 + a.n_lookup) {
-        const unsigned i = c - a.adv_lookup0;
-        const Fr lz0 = at(a.lz, i, 0), lz1 = at(a.lz, i, 1);
-        const Fr ap = at(a.la, i, 0), apm = at(a.la, i, (unsigned)(n - 1)), sp = at(a.ls, i, 0);
-        horner(acc_l, l0, one - lz0);
-        horner(acc_l, ll, lz0 * lz0 - lz0);
-        horner(acc_l, lact, zk::fp_mul2<zk::FrP>(lz1, (ap + a.beta) * (sp + a.gamma), zk::fp_neg<zk::FrP>(lz0), (v + a.beta) * (tbl + a.gamma)));
-        horner(acc_l, l0, ap - sp);
-        horner(acc_l, lact, (ap - sp) * (ap - apm));
-      }
-    }
-    horner(acc_d, lact, left - right);
-    if (j >= 1) horner(acc_c, l0, z0 - at(a.pz, j - 1, a.u));
-  }
-  Fr out = Fr::zero();
-  if (B.kinds & (1u << QB_GATE)) out = out + acc_g * B.w[QB_GATE];
-  if (B.kinds & (1u << QB_RLC)) out = out + acc_r * B.w[QB_RLC];
-  if (B.kinds & (1u << QB_FIRST)) out = out + l0 * (one - at(a.pz, 0, 0)) * B.w[QB_FIRST];
-  if (B.kinds & (1u << QB_LAST)) {
-    const Fr zm = at(a.pz, a.n_chunks - 1, 0);
-    out = out + ll * (zm * zm - zm) * B.w[QB_LAST];
-  }
-  if (B.kinds & (1u << QB_PERMC)) out = out + acc_c * B.w[QB_PERMC];
-  if (B.kinds & (1u << QB_PERMD)) out = out + acc_d * B.w[QB_PERMD];
-  if (B.kinds & (1u << QB_LOOKUP)) out = out + acc_l * B.w[QB_LOOKUP];
-  a.partials[(size_t)blockIdx.y * ne + p] = out;
-}
-
 // h_ext[p] = (sum_g ypow[g] * partials[g][p]) * zinv[k1]
 static __global__ void __launch_bounds__(256) k_quotient_combine(const Fr *__restrict__ partials, const Fr *__restrict__ ypow, unsigned n_groups,
                                                           const Fr *__restrict__ zinv, unsigned log_n, unsigned rows, size_t pt0, size_t pt_count, Fr *__restrict__ h_ext) {
