@@ -372,6 +372,15 @@ int zkfhe_bfv_pk_commitments(const zkfhe_bfv_pk *pk, uint8_t *fixed_out, uint8_t
  * public key is cached.  capacity >= 0 sets how many keys are remembered (default 8, ZKFHE_PREFIX_CACHE; 0 = off; at most 64),
  * negative only queries; hits / misses / entries are optional outputs. */
 int zkfhe_bfv_pk_prefix_cache(const zkfhe_bfv_pk *pk, int capacity, uint64_t *hits, uint64_t *misses, uint64_t *entries);
+/* Announce a proof ahead of time.  The first challenge of a proof stands behind one SEQUENTIAL sponge over the 5 N + 1 public inputs
+ * (reference examples/bfv.rs:118-122; with the reference's Poseidon transcript 10 241 permutations at N = 4096, 40 961 at N = 16384:
+ * 30 / 120 ms on a core, as long as the proof's GPU work) that depends on the input alone.  A caller that knows the input of a LATER
+ * proof calls this while the current proof is on the GPU: the public inputs are parsed and absorbed on a helper thread, and the
+ * zkfhe_bfv_prove of the same input_json (the same bytes) starts from the parked state (it waits for it if it is not complete yet).
+ * The call returns after copying the text.  One-shot: an announcement serves one proof, the oldest announcement of a text first; at
+ * most 16 may be pending (ZKFHE_EINVAL beyond).  An input that does not parse serves nobody (zkfhe_bfv_prove words the error).  Same
+ * state, same proof bytes.  Host only.  started / taken / pending: optional counters; input_json == NULL only reads them. */
+int zkfhe_bfv_pk_prehash(const zkfhe_bfv_pk *pk, const char *input_json, uint64_t *started, uint64_t *taken, uint64_t *pending);
 int zkfhe_bfv_pk_break_points(const zkfhe_bfv_pk *pk, int which, uint32_t *out, uint32_t *count);
 
 /* Serialised verifying key: magic "ZKFHEVK2", 8 x u32 configuration (k, n_gate0, n_gate1, n_lookup, n_rlc, unusable_rows,

@@ -4,7 +4,10 @@
 // carries a half-filled chunk across the cut) -- and the cache must hit on equal keys only, evict the least recently used entry and
 // keep entries of two interleaved keys apart.  usage: transcript_prefix_check
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
+#include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "prefix_cache.hpp"
@@ -115,6 +118,53 @@ int main() {
     CHECK(!pc.lookup(k1.data(), 2048, got));
     pc.stats(&h, &m, &e);
     CHECK(e == 0 && h == 5 && m == 4);            // switched off: neither a hit nor a miss
+  }
+  // announced proofs (PreHash): the parked state continues like a transcript that absorbed digest | inputs itself; an entry serves one
+  // proof, the oldest announcement of a text first; another text misses; public inputs that differ from the helper's are refused; a
+  // failing helper is a miss and its entry is dropped; the queue is bounded
+  for (uint32_t kind : {(uint32_t)TR_POSEIDON, (uint32_t)TR_BLAKE2B}) {
+    std::vector<U256> in1(5121), in2(5121);   // before `ph`: its helper threads read them until its destructor has joined them
+    for (size_t i = 0; i < 5121; ++i) in1[i] = val(11 + kind, i), in2[i] = val(12 + kind, i);
+    PreHash ph;
+    const U256 digest = val(77, 1);
+    // "parsing": text "1..." -> in1, "2..." -> in2, anything else does not parse
+    const PreHash::Work work = [&, kind, digest](const std::string &text, std::vector<U256> &inst, Transcript::State &out) {
+      if (text[0] == '1') inst = in1;
+      else if (text[0] == '2') inst = in2;
+      else throw std::runtime_error("does not parse");
+      Transcript t(kind);
+      t.common_scalar(digest);
+      t.common_scalars_async(inst);
+      out = t.snapshot();
+    };
+    Transcript ref(kind);
+    ref.common_scalar(digest);
+    ref.common_scalars_async(in1);
+    ref.common_scalar(val(5, 9));
+    const U256 want = ref.squeeze();
+    Transcript::State st;
+    CHECK(!ph.take("1a", 2, in1.data(), in1.size(), st));
+    CHECK(ph.start("1a", 2, work) && ph.start("1a", 2, work) && ph.start("2a", 2, work));
+    CHECK(!ph.take("1b", 2, in1.data(), in1.size(), st) && !ph.take("1", 1, in1.data(), in1.size(), st));   // other texts
+    for (int rep = 0; rep < 2; ++rep) {
+      CHECK(ph.take("1a", 2, in1.data(), in1.size(), st));
+      Transcript t(kind);
+      t.common_scalar(val(3, 3));   // replaced by the restore
+      t.restore(st);
+      t.common_scalar(val(5, 9));
+      CHECK(same(t.squeeze(), want));
+    }
+    CHECK(!ph.take("1a", 2, in1.data(), in1.size(), st));   // both announcements are used up
+    CHECK(!ph.take("2a", 2, in1.data(), in1.size(), st));   // the helper derived other public inputs than the proof: refused (and consumed)
+    uint64_t s0, t0, p0;
+    ph.stats(&s0, &t0, &p0);
+    CHECK(s0 == 3 && t0 == 2 && p0 == 0);
+    CHECK(ph.start("xx", 2, work));
+    CHECK(!ph.take("xx", 2, in1.data(), in1.size(), st));   // a failed helper: the proof hashes for itself
+    CHECK(ph.start("yy", 2, work));                         // fails in the background ...
+    std::this_thread::sleep_for(std::chrono::milliseconds(200));
+    for (size_t i = 0; i < PreHash::MAX_PENDING; ++i) CHECK(ph.start("2a", 2, work));   // ... and is dropped by the next announcement
+    CHECK(!ph.start("2a", 2, work));                         // MAX_PENDING entries are waiting
   }
   printf("transcript prefix check: %s\n", fails ? "FAILED" : "ok");
   return fails ? 1 : 0;

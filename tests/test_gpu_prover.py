@@ -673,3 +673,77 @@ def test_second_srs_on_a_full_device_gets_narrower_tables_same_bytes(ctx, monkey
         pk.destroy()
     b.destroy()
     a.destroy()
+
+
+@pytest.mark.parametrize("transcript", ["poseidon", "blake2b"])
+def test_announced_proofs_have_the_same_bytes(ctx, transcript):
+    """zkfhe_bfv_pk_prehash (host/prefix_cache.hpp PreHash): the public inputs of a LATER proof absorbed ahead of time on a helper
+    thread.  A proof that starts from the parked state has the bytes of one that hashes for itself; an announcement serves exactly
+    one proof; announcing input X does not touch a proof of input Y; two announcements of one input serve two proofs; with the
+    per-key cache on or off; four proofs in flight, each announced; an input that does not parse serves nobody; the queue is bounded.
+    Toy circuit, both transcripts."""
+    import zk_fhe_amd as zk
+    import zk_fhe_amd.batch as batch
+    from zk_fhe_amd import inputs as gen
+    prm = C.BfvParams(N=8)
+    par = (8, prm.Q, prm.T, prm.B)
+    texts = [json.dumps(gen.generate(8, prm.Q, prm.T, prm.B, seed=s, key_seed=100 + s % 2)) for s in range(6)]
+    cfg = zk.bfv_auto_config(texts[0], par, 9, unusable_rows=9, transcript=transcript)
+    srs = zk.Srs(ctx, 9)
+    pk = zk.BfvProvingKey(ctx, srs, texts[0], par, cfg)
+    plain = [pk.prove(t, b"ann-%d" % i)[0] for i, t in enumerate(texts)]
+    assert pk.prehash() == {"started": 0, "taken": 0, "pending": 0}
+    for cache in (8, 0):
+        pk.prefix_cache(cache)
+        base = pk.prehash()["started"]
+        assert pk.prehash(texts[1])["pending"] == 1
+        assert pk.prove(texts[0], b"ann-0")[0] == plain[0] and pk.prehash()["pending"] == 1      # another input: not taken
+        assert pk.prove(texts[1], b"ann-1")[0] == plain[1] and pk.prehash()["pending"] == 0      # taken
+        assert pk.prove(texts[1], b"ann-1")[0] == plain[1]                                       # one-shot: this one hashed for itself
+        pk.prehash(texts[2]), pk.prehash(texts[2])
+        assert pk.prove(texts[2], b"ann-2")[0] == plain[2] and pk.prove(texts[2], b"ann-2")[0] == plain[2]
+        st = pk.prehash()
+        assert st["started"] == base + 3 and st["pending"] == 0 and st["taken"] == st["started"]
+    pk.prefix_cache(8)
+    ctxs = [zk.Context(0) for _ in range(4)]
+    for t in texts:
+        pk.prehash(t)
+
+    def job(c, i):
+        return pk.prove(texts[i], b"ann-%d" % i, ctx=c)[0]
+    assert batch.run_concurrent(list(range(len(texts))), ctxs, job) == plain
+    st = pk.prehash()
+    assert st["pending"] == 0 and st["taken"] == st["started"]
+    # an input that does not parse is announced like any other (the call only copies the text) and serves nobody; its entry goes when the
+    # next announcement finds it failed; seventeen pending announcements are one too many
+    import time
+    pk.prehash('{"pk0": ["1"]}')
+    time.sleep(0.5)
+    for _ in range(16):
+        pk.prehash(texts[0])
+    assert pk.prehash()["pending"] == 16
+    with pytest.raises(zk.ZkfheError):
+        pk.prehash(texts[0])
+    assert pk.prove(texts[0], b"ann-0")[0] == plain[0] and pk.prehash()["pending"] == 15
+    for c in ctxs:
+        c.close()
+    pk.destroy()
+    srs.destroy()
+
+
+def test_announced_proof_matches_the_oracle_proof_k13(ctx):
+    """bfv.in at k = 13 announced ahead of time: the proof that picks the parked state up (5 121 public inputs absorbed on the helper
+    thread, through the per-key prefix) is the ORACLE prover's bytes, and so is the next one, which hashes for itself."""
+    import zk_fhe_amd as zk
+    o = oracle_k13()
+    srs = zk.Srs(ctx, 13)
+    pk = zk.BfvProvingKey(ctx, srs, o["text_empty"], (1024, o["prm"].Q, o["prm"].T, o["prm"].B), zk.BfvConfig.from_pinning(o["cfgj"]))
+    pk.prehash(o["text"])
+    proof, inst, _ = pk.prove(o["text"], b"seed-1")
+    assert proof == o["proof_o"] and inst == o["inst_o"]
+    assert pk.prehash() == {"started": 1, "taken": 1, "pending": 0}
+    marks = ctx.last_proof_marks()
+    assert 0 < marks[0] <= marks[1] <= marks[2]
+    assert pk.prove(o["text"], b"seed-1")[0] == o["proof_o"]
+    pk.destroy()
+    srs.destroy()

@@ -84,19 +84,22 @@ if has f; then
   python bench.py --no-traffic-pass --transcript blake2b --no-cpu-baseline > $OUT/bench_blake2b.json 2>/dev/null
   python bench.py --no-traffic-pass --transcript blake2b --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_blake2b_20.json 2>/dev/null
   python bench.py --no-traffic-pass --steps 8 --streams 1 --transcript blake2b --no-cpu-baseline --steady-seconds 0 > $OUT/bench_single_blake2b.json 2>/dev/null
-  python bench.py --no-traffic-pass --steps 8 --streams 1 --no-cpu-baseline --steady-seconds 0 > $OUT/bench_single_poseidon.json 2>/dev/null
+  python bench.py --no-traffic-pass --steps 8 --streams 1 --announce off --no-cpu-baseline --steady-seconds 0 > $OUT/bench_single_poseidon.json 2>/dev/null
+  # configs[3] / [4]: Blake2b (no host hashing to speak of), then the reference's Poseidon transcript -- one proof alone WITHOUT announcing
+  # its input (the first challenge waits for the sequential sponge over 5 N + 1 public inputs: host-bound latency), the same with every
+  # input announced one proof ahead (zkfhe_bfv_pk_prehash: the sponge of proof i + 1 runs on a host thread while proof i is on the GPU),
+  # and 2 / 3 proofs in flight
   for k in k16 k19; do
     python bench.py --no-traffic-pass --config $k --steps 4 --streams 1 --transcript blake2b --steady-seconds 0 > $OUT/bench_${k}_blake2b.json 2>/dev/null
-    python bench.py --no-traffic-pass --config $k --steps 4 --streams 1 --steady-seconds 0 > $OUT/bench_${k}_poseidon.json 2>/dev/null
+    python bench.py --no-traffic-pass --config $k --steps 6 --streams 1 --announce off --steady-seconds 0 > $OUT/bench_${k}_poseidon.json 2>/dev/null
+    python bench.py --no-traffic-pass --config $k --steps 9 --warmup 2 --streams 1 --steady-seconds 0 > $OUT/bench_${k}_poseidon_announced.json 2>/dev/null
+    for st in 2 3; do
+      python bench.py --no-traffic-pass --config $k --steps 9 --warmup 2 --streams $st --steady-seconds 0 > $OUT/bench_${k}_poseidon_s$st.json 2>/dev/null
+    done
+    python bench.py --no-traffic-pass --config $k --steps 9 --warmup 2 --streams 3 --announce off --steady-seconds 0 > $OUT/bench_${k}_poseidon_s3_plain.json 2>/dev/null
   done
   python bench.py --no-traffic-pass --config k16 --steps 8 --warmup 2 --transcript blake2b --steady-seconds 0 > $OUT/bench_k16_2streams.json 2>/dev/null
-  # configs[3] / [4] under the reference's transcript with 2 and 3 proofs in flight: the sponge over 5 N + 1 public inputs is one
-  # sequential chain per proof, so a lone proof waits for the host; several in flight hash on a core each while the GPU serves the others
-  for k in k16 k19; do
-    for st in 2 3; do
-      python bench.py --no-traffic-pass --config $k --steps 9 --warmup 1 --streams $st --steady-seconds 0 > $OUT/bench_${k}_poseidon_s$st.json 2>/dev/null
-    done
-  done
+  python bench.py --no-traffic-pass --steps 16 --warmup 2 --streams 1 --no-cpu-baseline --steady-seconds 0 > $OUT/bench_single_poseidon_announced.json 2>/dev/null
   ls -la $OUT
 fi
 # (g) host hashing modes, admission gate, the transcript cache off, the quotient by kind

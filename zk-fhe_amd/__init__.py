@@ -33,7 +33,7 @@ EXPORTS = [
     "zkfhe_bfv_tables_copy_break_points", "zkfhe_bfv_mock_check", "zkfhe_bfv_tables_poke_advice",
     "zkfhe_srs_create", "zkfhe_srs_from_points", "zkfhe_srs_destroy", "zkfhe_srs_save", "zkfhe_srs_drop_host_copy", "zkfhe_srs_load", "zkfhe_srs_g2", "zkfhe_srs_set_g2", "zkfhe_srs_file_g2",
     "zkfhe_chacha20_block", "zkfhe_snark_encode", "zkfhe_snark_decode", "zkfhe_bfv_keygen", "zkfhe_bfv_pk_destroy", "zkfhe_bfv_pk_release_ctx", "zkfhe_bfv_pk_info", "zkfhe_bfv_pk_prefix_cache",
-    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
+    "zkfhe_bfv_pk_commitments", "zkfhe_bfv_pk_break_points", "zkfhe_bfv_pk_prehash", "zkfhe_bfv_prove", "zkfhe_bfv_pk_export_vk", "zkfhe_bfv_pk_save", "zkfhe_bfv_pk_load", "zkfhe_bfv_witness_stream", "zkfhe_lookup_permute", "zkfhe_bfv_verify", "zkfhe_bfv_verify_g2",
     "zkfhe_transcript_create", "zkfhe_transcript_destroy", "zkfhe_transcript_common_scalar", "zkfhe_transcript_write_scalar",
     "zkfhe_transcript_common_point", "zkfhe_transcript_write_point", "zkfhe_transcript_squeeze", "zkfhe_transcript_bytes",
     "zkfhe_poseidon_permute", "zkfhe_poseidon_constants", "zkfhe_poseidon_hash_many", "zkfhe_host_hash_mode", "zkfhe_prover_gate",
@@ -1045,6 +1045,20 @@ class BfvProvingKey:
         h, m, e = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         self.ctx._check(lib.zkfhe_bfv_pk_prefix_cache(self.h, int(capacity), ctypes.byref(h), ctypes.byref(m), ctypes.byref(e)))
         return {"hits": h.value, "misses": m.value, "entries": e.value}
+
+    def prehash(self, input_json_text=None):
+        """zkfhe_bfv_pk_prehash: announce the input of a LATER proof -- its public inputs are absorbed into a transcript state on a
+        helper thread now (host only) and the prove() of the same text starts from it.  One-shot.  Returns {"started", "taken",
+        "pending"}; None as text only reads the counters."""
+        lib = self.ctx.lib
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        lib.zkfhe_bfv_pk_prehash.argtypes = [ctypes.c_void_p, ctypes.c_char_p, u64p, u64p, u64p]
+        s, t, p = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        text = None if input_json_text is None else (input_json_text if isinstance(input_json_text, bytes) else input_json_text.encode())
+        rc = lib.zkfhe_bfv_pk_prehash(self.h, text, ctypes.byref(s), ctypes.byref(t), ctypes.byref(p))
+        if rc != 0:
+            raise ZkfheError("zkfhe_bfv_pk_prehash: too many announced proofs are pending (%d)" % rc)
+        return {"started": s.value, "taken": t.value, "pending": p.value}
 
     def export_vk(self):
         lib = self.ctx.lib

@@ -19,6 +19,7 @@ LIB = os.path.join(HERE, "libzkfhe_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=default", "-Wno-unused-value",
          "-mllvm", "-pragma-unroll-threshold=1000000", "-I", os.path.join(HERE, "..", "include")]
+FLAGS += os.environ.get("ZKFHE_EXTRA_FLAGS", "").split()   # A/B builds of experiments (e.g. -DZK_MAD_C): build a copy of this directory with it
 TILE_SIZES = list(range(3, 13))   # the 2^13 tile is csrc/ntt13.hip
 
 

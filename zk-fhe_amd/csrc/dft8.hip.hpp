@@ -19,6 +19,14 @@ __device__ __forceinline__ LzT mulw(const Lz<LO, HI, V> &x, const Lw &w) {
   __builtin_amdgcn_sched_barrier(0);
   return r;
 }
+// the same against a constant that is uniform across the wave (the butterfly constants K, n^-1): its limbs stay in SGPRs
+template <int LO, int HI, int V>
+__device__ __forceinline__ LzT mulw_u(const Lz<LO, HI, V> &x, const Lw &w) {
+  __builtin_amdgcn_sched_barrier(0);
+  const LzT r = lz_mul<true>(x, w);
+  __builtin_amdgcn_sched_barrier(0);
+  return r;
+}
 __device__ __forceinline__ Lw tw_at(const LwMem *__restrict__ p) { return lw_load(*p); }
 
 // The eight outputs of a size-8 DFT of x (natural order in and out), as typed values:
@@ -33,7 +41,7 @@ __device__ __forceinline__ Lw tw_at(const LwMem *__restrict__ p) { return lw_loa
   const auto a0 = lz_add(x[0], x[4]);                        /* (0,2) */                                             \
   const auto a1 = lz_sub(x[0], x[4]);                        /* (1,1) */                                             \
   const auto b0 = lz_add(x[2], x[6]);                        /* (0,2) */                                             \
-  ZK_F const LzT b1 = mulw(lz_sub(x[2], x[6]), K.w4);        /* (0,1) */                                             \
+  ZK_F const LzT b1 = mulw_u(lz_sub(x[2], x[6]), K.w4);        /* (0,1) */                                             \
   ZK_F const auto E0 = lz_norm(lz_add(a0, b0));              /* (0,4) -> (0,1), |v| < 8 r */                         \
   ZK_F const auto E2 = lz_norm(lz_sub(a0, b0));              /* (2,2) -> (0,1) */                                    \
   ZK_F const auto E1 = lz_norm(lz_add(a1, b1));              /* (1,2) -> (0,1) */                                    \
@@ -41,11 +49,11 @@ __device__ __forceinline__ Lw tw_at(const LwMem *__restrict__ p) { return lw_loa
   ZK_F const auto c0 = lz_add(x[1], x[5]);                                                                           \
   const auto c1 = lz_sub(x[1], x[5]);                                                                                \
   const auto d0 = lz_add(x[3], x[7]);                                                                                \
-  ZK_F const LzT d1 = mulw(lz_sub(x[3], x[7]), K.w4);                                                                \
+  ZK_F const LzT d1 = mulw_u(lz_sub(x[3], x[7]), K.w4);                                                                \
   ZK_F const auto O0 = lz_norm(lz_add(c0, d0));              /* (0,1), |v| < 8 r */                                  \
-  ZK_F const LzT O2 = mulw(lz_sub(c0, d0), K.w4);            /* (2,2) in */                                          \
-  ZK_F const LzT O1 = mulw(lz_add(c1, d1), K.w8);            /* (1,2) in */                                          \
-  ZK_F const LzT O3 = mulw(lz_sub(c1, d1), K.w83);           /* (2,1) in */                                          \
+  ZK_F const LzT O2 = mulw_u(lz_sub(c0, d0), K.w4);            /* (2,2) in */                                          \
+  ZK_F const LzT O1 = mulw_u(lz_add(c1, d1), K.w8);            /* (1,2) in */                                          \
+  ZK_F const LzT O3 = mulw_u(lz_sub(c1, d1), K.w83);           /* (2,1) in */                                          \
   ZK_F const auto y0 = lz_add(E0, O0);                       /* (0,2), |v| < 16 r */                                 \
   const auto y4 = lz_sub(E0, O0);                            /* (1,1) */                                             \
   ZK_F const auto y1 = lz_add(E1, O1);                                                                               \

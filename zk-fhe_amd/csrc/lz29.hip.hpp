@@ -104,7 +104,9 @@ ZK_HD LzW lz_weak(const Lz<LO, HI, V> &a) {
 
 // Montgomery product a * w / 2^261 mod r for |a w| < 2^261 r: value in (-r, 2 r).  Column k: nine |a_j| w_(k-j) < 2^30 2^29,
 // nine m_j r_(k-j) < 2^58 and the carry: magnitude below 9 2^59 + 9 2^58 + 2^35 < 2^63.
-template <int LO, int HI, int V>
+// UNIFORM: the constant is the same for every lane of the wave (a butterfly constant, n^-1 -- loaded through a uniform address): its
+// limbs are taken from SGPRs, as the compiler did on its own before the multiply-adds became inline assembly (fq29.hip.hpp zk_madi).
+template <bool UNIFORM = false, int LO, int HI, int V>
 ZK_HD LzT lz_mul(const Lz<LO, HI, V> &a, const Lw &b) {
   static_assert(LO <= 2 && HI <= 2, "product: limbs below 2^30 in magnitude");
   static_assert(V <= 160, "product: |a w| < 2^261 r");
@@ -116,20 +118,20 @@ ZK_HD LzT lz_mul(const Lz<LO, HI, V> &a, const Lw &b) {
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
     for (int j = 0; j < k; ++j) {
-      acc += (long long)a.l[j] * (long long)(int)b.l[k - j];
-      acc += (long long)m[j] * (long long)(int)P[k - j];
+      if (UNIFORM) zk_madi_s(acc, a.l[j], (int)b.l[k - j]); else zk_madi(acc, a.l[j], (int)b.l[k - j]);
+      zk_madi_s(acc, m[j], (int)P[k - j]);
     }
-    acc += (long long)a.l[k] * (long long)(int)b.l[0];
+    if (UNIFORM) zk_madi_s(acc, a.l[k], (int)b.l[0]); else zk_madi(acc, a.l[k], (int)b.l[0]);
     m[k] = (int)(((u32)acc * r29::INV) & q29::MASK);
-    acc += (long long)m[k] * (long long)(int)P[0];
+    zk_madi_s(acc, m[k], (int)P[0]);
     acc >>= 29;   // exact: the low 29 bits are zero
   }
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
 #pragma unroll
     for (int j = k - 8; j < 9; ++j) {
-      acc += (long long)a.l[j] * (long long)(int)b.l[k - j];
-      acc += (long long)m[j] * (long long)(int)P[k - j];
+      if (UNIFORM) zk_madi_s(acc, a.l[j], (int)b.l[k - j]); else zk_madi(acc, a.l[j], (int)b.l[k - j]);
+      zk_madi_s(acc, m[j], (int)P[k - j]);
     }
     r.l[k - 9] = (int)((u32)acc & q29::MASK);
     acc >>= 29;
@@ -152,23 +154,23 @@ ZK_HD LzT lz_mul2(const Lz<L1, H1, V> &a, const Lw &w, const Lz<L2, H2, V2> &b, 
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
     for (int j = 0; j < k; ++j) {
-      acc += (long long)a.l[j] * (long long)(int)w.l[k - j];
-      acc += (long long)b.l[j] * (long long)(int)v.l[k - j];
-      acc += (long long)m[j] * (long long)(int)P[k - j];
+      zk_madi(acc, a.l[j], (int)w.l[k - j]);
+      zk_madi(acc, b.l[j], (int)v.l[k - j]);
+      zk_madi_s(acc, m[j], (int)P[k - j]);
     }
-    acc += (long long)a.l[k] * (long long)(int)w.l[0];
-    acc += (long long)b.l[k] * (long long)(int)v.l[0];
+    zk_madi(acc, a.l[k], (int)w.l[0]);
+    zk_madi(acc, b.l[k], (int)v.l[0]);
     m[k] = (int)(((u32)acc * r29::INV) & q29::MASK);
-    acc += (long long)m[k] * (long long)(int)P[0];
+    zk_madi_s(acc, m[k], (int)P[0]);
     acc >>= 29;
   }
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
 #pragma unroll
     for (int j = k - 8; j < 9; ++j) {
-      acc += (long long)a.l[j] * (long long)(int)w.l[k - j];
-      acc += (long long)b.l[j] * (long long)(int)v.l[k - j];
-      acc += (long long)m[j] * (long long)(int)P[k - j];
+      zk_madi(acc, a.l[j], (int)w.l[k - j]);
+      zk_madi(acc, b.l[j], (int)v.l[k - j]);
+      zk_madi_s(acc, m[j], (int)P[k - j]);
     }
     r.l[k - 9] = (int)((u32)acc & q29::MASK);
     acc >>= 29;
@@ -190,29 +192,29 @@ ZK_HD LzT lz_mul4u(const Lz<0, 1, 1> &a0, const Lw &w0, const Lz<0, 1, 1> &a1, c
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
     for (int j = 0; j < k; ++j) {
-      acc += (u64)(u32)a0.l[j] * (u64)w0.l[k - j];
-      acc += (u64)(u32)a1.l[j] * (u64)w1.l[k - j];
-      acc += (u64)(u32)a2.l[j] * (u64)w2.l[k - j];
-      acc += (u64)(u32)a3.l[j] * (u64)w3.l[k - j];
-      acc += (u64)m[j] * (u64)P[k - j];
+      zk_madu(acc, (u32)a0.l[j], w0.l[k - j]);
+      zk_madu(acc, (u32)a1.l[j], w1.l[k - j]);
+      zk_madu(acc, (u32)a2.l[j], w2.l[k - j]);
+      zk_madu(acc, (u32)a3.l[j], w3.l[k - j]);
+      zk_madu_s(acc, m[j], P[k - j]);
     }
-    acc += (u64)(u32)a0.l[k] * (u64)w0.l[0];
-    acc += (u64)(u32)a1.l[k] * (u64)w1.l[0];
-    acc += (u64)(u32)a2.l[k] * (u64)w2.l[0];
-    acc += (u64)(u32)a3.l[k] * (u64)w3.l[0];
+    zk_madu(acc, (u32)a0.l[k], w0.l[0]);
+    zk_madu(acc, (u32)a1.l[k], w1.l[0]);
+    zk_madu(acc, (u32)a2.l[k], w2.l[0]);
+    zk_madu(acc, (u32)a3.l[k], w3.l[0]);
     m[k] = ((u32)acc * r29::INV) & q29::MASK;
-    acc += (u64)m[k] * (u64)P[0];
+    zk_madu_s(acc, m[k], P[0]);
     acc >>= 29;   // exact: the low 29 bits are zero
   }
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
 #pragma unroll
     for (int j = k - 8; j < 9; ++j) {
-      acc += (u64)(u32)a0.l[j] * (u64)w0.l[k - j];
-      acc += (u64)(u32)a1.l[j] * (u64)w1.l[k - j];
-      acc += (u64)(u32)a2.l[j] * (u64)w2.l[k - j];
-      acc += (u64)(u32)a3.l[j] * (u64)w3.l[k - j];
-      acc += (u64)m[j] * (u64)P[k - j];
+      zk_madu(acc, (u32)a0.l[j], w0.l[k - j]);
+      zk_madu(acc, (u32)a1.l[j], w1.l[k - j]);
+      zk_madu(acc, (u32)a2.l[j], w2.l[k - j]);
+      zk_madu(acc, (u32)a3.l[j], w3.l[k - j]);
+      zk_madu_s(acc, m[j], P[k - j]);
     }
     r.l[k - 9] = (int)((u32)acc & q29::MASK);
     acc >>= 29;

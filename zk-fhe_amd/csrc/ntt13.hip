@@ -93,14 +93,14 @@ template <bool POST>
 __device__ __forceinline__ void pass8_out(const LzT (&x)[8], const Consts &K, const Lw &p, Fr (&y)[8]) {
   ZK_DFT8_CORE(x, K)
   if (POST) {
-    y[0] = lz_store(mulw(y0, p)); ZK_F
-    y[1] = lz_store(mulw(y1, p)); ZK_F
-    y[2] = lz_store(mulw(y2, p)); ZK_F
-    y[3] = lz_store(mulw(y3, p)); ZK_F
-    y[4] = lz_store(mulw(y4, p)); ZK_F
-    y[5] = lz_store(mulw(y5, p)); ZK_F
-    y[6] = lz_store(mulw(y6, p)); ZK_F
-    y[7] = lz_store(mulw(y7, p)); ZK_F
+    y[0] = lz_store(mulw_u(y0, p)); ZK_F
+    y[1] = lz_store(mulw_u(y1, p)); ZK_F
+    y[2] = lz_store(mulw_u(y2, p)); ZK_F
+    y[3] = lz_store(mulw_u(y3, p)); ZK_F
+    y[4] = lz_store(mulw_u(y4, p)); ZK_F
+    y[5] = lz_store(mulw_u(y5, p)); ZK_F
+    y[6] = lz_store(mulw_u(y6, p)); ZK_F
+    y[7] = lz_store(mulw_u(y7, p)); ZK_F
   } else {
     y[0] = lz_store(y0); ZK_F
     y[1] = lz_store(y1); ZK_F

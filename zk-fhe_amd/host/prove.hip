@@ -599,7 +599,9 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     for (const Cell &c : pub) instances.push_back(c.value);
     const size_t n_key = std::min<size_t>(instances.size(), 2 * (size_t)pk->prm.N);
     Transcript::State mid;
-    if (!n_key || !pk->prefix.capacity()) {
+    if (pk->prehash.take(input_json, strlen(input_json), instances.data(), instances.size(), mid)) {
+      tr.restore(mid);   // announced ahead of time (zkfhe_bfv_pk_prehash): `vk digest | public inputs` are absorbed already
+    } else if (!n_key || !pk->prefix.capacity()) {
       tr.common_scalars_async(instances);
     } else if (pk->prefix.lookup(instances.data(), n_key, mid)) {
       tr.restore(mid);
@@ -1455,6 +1457,60 @@ int zkfhe_lookup_permute(zkfhe_ctx *ctx, const zkfhe_fr *cols_dev, size_t n_cols
   ZK_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
   CK(zkw::lookup_permute(ctx, (const Fr *)cols_dev, n, usable_rows, (unsigned)n_cols, (Fr *)a_dev, (Fr *)s_dev, (int *)flag, (unsigned *)((char *)flag + 64)));
   return zkfhe_download(ctx, not_in_table, flag, 4);
+}
+
+// Announce the input of a proof that will be made later with this key: its public inputs (examples/bfv.rs:118-122) are parsed now
+// and `vk digest | public inputs` is absorbed on a helper thread into a transcript state that the zkfhe_bfv_prove of the SAME input
+// picks up (prefix_cache.hpp PreHash; one-shot).  Host only: no context, no GPU work.  started / taken / pending (optional) receive
+// the counters of this key; input_json == NULL only queries them.
+int zkfhe_bfv_pk_prehash(const zkfhe_bfv_pk *pk_c, const char *input_json, uint64_t *started, uint64_t *taken, uint64_t *pending) {
+  if (!pk_c) return ZKFHE_EINVAL;
+  zkfhe_bfv_pk *pk = const_cast<zkfhe_bfv_pk *>(pk_c);
+  int rc = ZKFHE_OK;
+  if (input_json) {
+    const uint32_t kind = pk->cfg.transcript;
+    const U256 digest = pk->vk_digest;
+    const BfvParams prm = pk->prm;
+    PrefixCache *cache = &pk->prefix;
+    // everything on the helper thread: the caller gets its thread back after one copy of the text (2.3 MB of JSON at N = 16384 take 15 ms to parse)
+    const bool ok = pk->prehash.start(input_json, strlen(input_json), [kind, digest, prm, cache](const std::string &text, std::vector<U256> &inst, Transcript::State &out) {
+      struct PublicInputsKnown {};   // thrown by the callback: phase 0 stops as soon as the public inputs are complete
+      try {
+        Context ctx0(CTX_PHASE0, false, false);
+        std::vector<Cell> make_public;
+        BfvState st;
+        const auto on_public = [&](const std::vector<Cell> &pub) {
+          inst.reserve(pub.size());
+          for (const Cell &c : pub) inst.push_back(c.value);
+          throw PublicInputsKnown{};
+        };
+        if (!bfv_phase0_fast(ctx0, text.c_str(), text.size(), prm, make_public, st, on_public))
+          (void)bfv_phase0(ctx0, CircuitInput::parse_json(text.c_str()), prm, make_public, on_public);
+        throw std::runtime_error("phase 0 ended without public inputs");
+      } catch (const PublicInputsKnown &) {
+      }
+      const size_t n_key = std::min<size_t>(inst.size(), 2 * (size_t)prm.N);
+      Transcript tr(kind);
+      tr.common_scalar(digest);
+      Transcript::State mid;
+      size_t from = 0;
+      if (n_key && cache->capacity()) {
+        if (cache->lookup(inst.data(), n_key, mid)) {
+          tr.restore(mid);
+        } else {
+          tr.common_scalars_async(std::vector<U256>(inst.begin(), inst.begin() + (long)n_key));
+          mid = tr.snapshot();
+          cache->insert(inst.data(), n_key, mid);
+        }
+        from = n_key;
+      }
+      tr.common_scalars_async(std::vector<U256>(inst.begin() + (long)from, inst.end()));
+      out = tr.snapshot();
+    });
+    if (!ok) rc = ZKFHE_EINVAL;   // PreHash::MAX_PENDING announced proofs are waiting already
+  }
+  pk->prehash.stats(started, taken, pending);
+  return rc;
 }
 
 // The phase-1 gate stream exactly as the GPU witness generator produces it (gpu_witness.hip.hpp), for a caller-chosen

@@ -312,5 +312,7 @@ struct zkfhe_bfv_pk {
   std::mutex mu;
   // transcript state after `vk digest | pk0 | pk1`, per public key seen (prefix_cache.hpp); shared by the proofs in flight
   PrefixCache prefix;
+  // transcript states of proofs announced ahead of time (zkfhe_bfv_pk_prehash): one-shot, consumed by the proof of the same inputs
+  PreHash prehash;
 };
 
