@@ -138,6 +138,44 @@ __global__ void __launch_bounds__(256) k_perm_std(Args a) {
   a.out[(size_t)blockIdx.y * ne + p] = acc;
 }
 
+// ---- today's arithmetic, ONE load of the advice column per thread: the rotations X w, X w^2, X w^3 of the gate come from the lanes to the
+// right (wave-wide rotate by one lane, v_mov_b32 dpp wave_rol:1), the last three lanes of the wave from three extra values the first three
+// lanes load.  5 load instructions per gate -> 2 (+ one of three active lanes).
+__device__ __forceinline__ Fr rol1(const Fr &v) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)v.l[i], 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+  return r;
+}
+__device__ __forceinline__ Fr pick(bool c, const Fr &a, const Fr &b) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+__global__ void __launch_bounds__(256) k_gate_dpp(Args a) {
+  const size_t n = (size_t)1 << a.log_n, ne = n * a.rows;
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;   // ne is a multiple of 256: every lane is live
+  const size_t row0 = p & ~(n - 1), k2 = p & (n - 1);
+  const unsigned lane = threadIdx.x & 63u;
+  Fr acc = Fr::zero();
+  const int first = blockIdx.y * a.per_group;
+  for (int j = first; j < first + (int)a.per_group; ++j) {
+    const Fr *col = a.adv + (size_t)j * ne + row0;
+    const Fr q = a.fix[(size_t)j * ne + p];
+    const Fr a0 = col[k2];
+    Fr ex = Fr::zero();
+    if (lane < 3) ex = col[(k2 + 64) & (n - 1)];          // lane t < 3: the value 64 rows further (wraps inside the coset row)
+    const Fr A1 = rol1(a0), E1 = rol1(ex);
+    const Fr A2 = rol1(A1), E2 = rol1(E1);
+    const Fr A3 = rol1(A2), E3 = rol1(E2);
+    const Fr r1 = pick(lane >= 63, E1, A1), r2 = pick(lane >= 62, E2, A2), r3 = pick(lane >= 61, E3, A3);
+    if (!q.is_zero()) acc = fp_mul2<FrP>(acc, a.y, q, a0 + r1 * r2 - r3);
+    else acc = acc * a.y;
+  }
+  a.out[(size_t)blockIdx.y * ne + p] = acc;
+}
+
 // ---- nine lazy limbs, data and constants in the 2^261 form ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_gate_lz(Args a) {
   const size_t n = (size_t)1 << a.log_n, ne = n * a.rows;
@@ -251,6 +289,15 @@ int main(int argc, char **argv) {
   const unsigned bx = (unsigned)((ne + 255) / 256);
   a.per_group = 8;
   const float g_std = time_it(k_gate_std, dim3(bx, gate_groups), a, 20), g_lz = time_it(k_gate_lz, dim3(bx, gate_groups), a, 20);
+  const float g_dpp = time_it(k_gate_dpp, dim3(bx, gate_groups), a, 20);
+  {   // the rotated form must give the bytes of the plain one
+    std::vector<uint32_t> h0((size_t)gate_groups * ne * 8), h1(h0.size());
+    k_gate_std<<<dim3(bx, gate_groups), 256>>>(a);
+    CHECK(hipMemcpy(h0.data(), a.out, h0.size() * 4, hipMemcpyDeviceToHost));
+    k_gate_dpp<<<dim3(bx, gate_groups), 256>>>(a);
+    CHECK(hipMemcpy(h1.data(), a.out, h1.size() * 4, hipMemcpyDeviceToHost));
+    printf("gate, one load + lane rotations: %.3f ms (ratio to five loads %.3f), same output: %s\n", g_dpp, g_dpp / g_std, h0 == h1 ? "yes" : "NO");
+  }
   a.per_group = 4;
   const float p_std = time_it(k_perm_std, dim3(bx, perm_groups), a, 20), p_lz = time_it(k_perm_lz, dim3(bx, perm_groups), a, 20);
   const double gates = (double)cols * ne, chunk_terms = (double)chunks * ne;

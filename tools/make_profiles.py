@@ -177,26 +177,41 @@ New in round 3: the fold (`call` - `summing kernel` on the table path) runs 512 
 """ % rd('msm_calls.txt'))
 
 lines = ["# @RT@ -- bench lines (un-profiled, MI355X box, `tools/profile.sh` section (f))", "",
-         "| command | proofs/s | ms per proof | proofs in flight | steady-state pass | host CPU ms / proof | dominant kernel: avg launch ms, int_alu frac |",
-         "|---|---|---|---|---|---|---|"]
+         "`cold` = the same K proofs again with the per-public-key transcript cache off (every proof under a key never seen: BASELINE configs[2]'s 64 keys); `first challenge` = ms from the",
+         "start of a proof to its first Fiat-Shamir challenge, in brackets the part of it the proof waited for the HOST after the phase-0 commitment was back from the GPU (the sequential",
+         "sponge over the 5 N + 1 public inputs); `announced` = every input announced one proof ahead (`zkfhe_bfv_pk_prehash`: that sponge runs on a host thread while the previous proof is on the GPU).", "",
+         "| command | proofs/s | ms per proof | in flight | steady-state pass | cold keys | first challenge ms (host wait) | announced | prefix cache hits / misses | host CPU ms / proof | dominant kernel: avg launch ms, int_alu frac |",
+         "|---|---|---|---|---|---|---|---|---|---|---|"]
 for fn, cmd in (('bench_driver', "`python bench.py --steps 20 --warmup 5` (the driver's command)"), ('bench_default', '`python bench.py --no-cpu-baseline`'),
                 ('bench_blake2b', '`--transcript blake2b`'), ('bench_blake2b_20', '`--transcript blake2b --steps 20 --warmup 5`'),
-                ('bench_single_blake2b', '`--steps 8 --streams 1 --transcript blake2b`'), ('bench_single_poseidon', '`--steps 8 --streams 1`'),
+                ('bench_single_blake2b', '`--steps 8 --streams 1 --transcript blake2b`'), ('bench_single_poseidon', '`--steps 8 --streams 1 --announce off`'),
+                ('bench_single_poseidon_announced', '`--steps 16 --streams 1` (announced)'),
                 ('bench_k16_blake2b', '`--config k16 --steps 4 --streams 1 --transcript blake2b`'),
                 ('bench_k16_2streams', '`--config k16 --steps 8 --warmup 2 --transcript blake2b` (2 in flight)'),
-                ('bench_k16_poseidon', '`--config k16 --steps 4 --streams 1`'), ('bench_k19_blake2b', '`--config k19 --steps 4 --streams 1 --transcript blake2b`'),
-                ('bench_k19_poseidon', '`--config k19 --steps 4 --streams 1`'),
+                ('bench_k16_poseidon', '`--config k16 --steps 6 --streams 1 --announce off` (a lone proof, host-bound)'),
+                ('bench_k16_poseidon_announced', '`--config k16 --steps 9 --streams 1` (announced)'),
+                ('bench_k16_poseidon_s2', '`--config k16 --steps 9 --streams 2` (announced)'), ('bench_k16_poseidon_s3', '`--config k16 --steps 9 --streams 3` (announced)'),
+                ('bench_k16_poseidon_s3_plain', '`--config k16 --steps 9 --streams 3 --announce off`'),
+                ('bench_k19_blake2b', '`--config k19 --steps 4 --streams 1 --transcript blake2b`'),
+                ('bench_k19_poseidon', '`--config k19 --steps 6 --streams 1 --announce off` (a lone proof, host-bound)'),
+                ('bench_k19_poseidon_announced', '`--config k19 --steps 9 --streams 1` (announced)'),
+                ('bench_k19_poseidon_s2', '`--config k19 --steps 9 --streams 2` (announced)'), ('bench_k19_poseidon_s3', '`--config k19 --steps 9 --streams 3` (announced)'),
+                ('bench_k19_poseidon_s3_plain', '`--config k19 --steps 9 --streams 3 --announce off`'),
                 ('bench_driver_shared', "`ZKFHE_HASH_MODE=shared` + the driver's command (eight-lane Poseidon service)"),
                 ('bench_default_shared', '`ZKFHE_HASH_MODE=shared python bench.py --no-cpu-baseline`'),
                 ('bench_driver_nocache', "`ZKFHE_PREFIX_CACHE=0` + the driver's command (no per-public-key transcript cache)")):
     d = jl(fn + '.json')
     if not d:
-        lines.append("| %s | (missing) | | | | | |" % cmd)
+        lines.append("| %s | (missing) | | | | | | | | | |" % cmd)
         continue
     c = d['config']
     r = d['roofline']
-    lines.append("| %s | %.2f | %.2f | %s | %s | %.1f | %s: %.3f, %.2f |" % (
+    lat = c.get('per_proof_latency_ms', {})
+    lines.append("| %s | %.2f | %.2f | %s | %s | %s | %s | %s | %s / %s | %.1f | %s: %.3f, %.2f |" % (
         cmd, d['value'], d['ms_per_step'], c['concurrent_proofs_per_gpu'], ('%.1f' % c['steady_state_proofs_per_s']) if c['steady_state_proofs_per_s'] else '-',
+        ('%.2f' % c['cold_key_proofs_per_s']) if c.get('cold_key_proofs_per_s') else '-',
+        ('%.1f (%.1f)' % (lat['first_challenge'], lat['host_wait_for_first_challenge'])) if 'first_challenge' in lat else '-',
+        'yes' if c.get('inputs_announced_one_proof_ahead') else 'no', c['host'].get('prefix_cache_hits', '-'), c['host'].get('prefix_cache_misses', '-'),
         c['host_cpu_ms_per_proof'], r['kernel'], r['avg_launch_ms'], r['int_alu']['frac']))
 dd = jl('bench_driver.json')
 if dd and dd.get('cpu_baseline'):

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--config", default="k13", choices=["k13", "k16"], help="k16: N = 4096, Q = 2^60 - 93 (auto-configured columns)")
     ap.add_argument("--hash-mode", default="latency", choices=["latency", "shared"], help="shared: the transcripts' long runs through the eight-lane Poseidon service")
     ap.add_argument("--gate", type=int, default=0, help="admission gate of the heavy middle of a proof (zkfhe_prover_gate)")
+    ap.add_argument("--announce", type=int, default=0, help="announce every job's input this many jobs ahead (zkfhe_bfv_pk_prehash; 0 = off, at most 16 - streams): the "
+                                                            "helper threads, the one-shot states and the per-key prefix cache under concurrency")
     args = ap.parse_args()
     import zk_fhe_amd as zk
     zk.host_hash_mode(args.hash_mode)
@@ -56,6 +58,11 @@ def main():
     def one(c, j):
         # every third job repeats an earlier (input, seed) pair: the bytes must repeat too
         key = (j % len(ins), j if j % 3 else j // 3 % 50)
+        if args.announce:
+            try:
+                pk.prehash(ins[(j + args.announce) % len(ins)])
+            except zk.ZkfheError:
+                pass   # sixteen announcements pending: this job's successor hashes for itself
         proof, inst, _ = pk.prove(ins[key[0]], b"soak-%d" % key[1], ctx=c)
         ok, why = zk.bfv_verify(vk, inst, proof)
         with lock:
@@ -71,7 +78,7 @@ def main():
     dt = time.time() - t0
     print(json.dumps({"proofs": done[0], "failed": len(bad), "first_failures": bad[:5], "seconds": round(dt, 1),
                       "distinct_pairs": len(first), "streams": args.streams, "transcript": args.transcript,
-                      "hash_mode": zk.host_hash_mode(), "gate": args.gate, "table_bits": srs.table_bits()[0]}))
+                      "hash_mode": zk.host_hash_mode(), "gate": args.gate, "announce": args.announce, "prehash": pk.prehash(), "table_bits": srs.table_bits()[0]}))
     return 1 if bad else 0
 
 
