@@ -226,10 +226,10 @@ W('_microbench.md', "# @RT@ -- micro-benchmarks (`python tools/microbench.py`, M
 # ---- wave occupancy --------------------------------------------------------------------------------------------------------
 W('_wave_occupancy.md', """# @RT@ -- GPU occupancy over the driver's wave of 20 concurrent proofs (2 ms bins)
 
-`rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-seconds 0` (`tools/profile.sh`), `tools/busy_bins.py <db> 260 2`:
+`rocprofv3 --kernel-trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-seconds 0` (`tools/profile.sh`), `tools/busy_bins.py <db> 400 2`:
 per bin the fraction of time with at least one kernel running, the average number of kernels in flight and the kernel with the largest
-share.  The last ~60 ms of the trace are the two profiled proofs that follow the timed region (one in flight); the wave is the ~100 ms
-block before them: a head of 14-18 ms in which the proofs' early work (phase-0 commitment, gadgets, early phase-1 commitment) shares the
+share.  The trace ends with what follows the timed region -- the cold-key pass (the same 20 proofs with the per-key transcript cache off:
+a second wave of ~100 ms) and the two profiled proofs (one in flight, ~60 ms); the timed wave is the ~100 ms block before those: a head of 14-18 ms in which the proofs' early work (phase-0 commitment, gadgets, early phase-1 commitment) shares the
 chip while every proof hashes its 5 121 public inputs, 50-75 ms with 12-16 kernels in flight -- the proofs move through their rounds
 together, so this block is one phase after the other (the 2^13 tiles of all twenty proofs alone fill ~35 ms of it) -- and 14-25 ms in
 which the kernels in flight fall from ten to one: the proofs' serial ends (evaluations, 758 Poseidon permutations on the host, two
