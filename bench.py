@@ -65,7 +65,10 @@ def _measure_traffic(transcript, timeout_s=300):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         return None   # this process is being profiled itself: no nested profiler
     got = {}
-    env = dict(os.environ, TMPDIR="/tmp")
+    # the children are plain one-GPU runs: nothing of this process's rendezvous (a forced one-rank process group holds its port) goes along
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR",
+                                                             "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID", "ZKFHE_BENCH_FORCE_DIST")}
+    env["TMPDIR"] = "/tmp"
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="zkfhe_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",

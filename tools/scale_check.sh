@@ -26,7 +26,7 @@ run() {  # ranks mode hash_mode tag extra bench arguments...
   # the PLAIN form: `python bench.py --gpus N` starts its own N ranks under torch.distributed.run (one per GPU, RCCL) and refuses to
   # print a line whose n_gpus is not N; at N = 1 the process group is forced as well, so that the 1-GPU row of the table has paid
   # for the same collectives as the others
-  ZKFHE_BENCH_FORCE_DIST=1 ZKFHE_HASH_MODE=$hm python bench.py --gpus "$n" --no-cpu-baseline --mode "$mode" "$@" > "$log.json" 2> "$log.err"
+  ZKFHE_BENCH_FORCE_DIST=1 ZKFHE_HASH_MODE=$hm python bench.py --gpus "$n" --no-cpu-baseline --no-traffic-pass --mode "$mode" "$@" > "$log.json" 2> "$log.err"
   python - "$log.json" "$n" "$mode" "$hm" >> "$OUT/scale.jsonl" <<'PY'
 import json, sys
 path, n, mode, hm = sys.argv[1:5]

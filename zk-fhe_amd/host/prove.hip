@@ -516,14 +516,20 @@ struct GateHold {
 // ZKFHE_TRACE=1: host-side phase times of one proof on stderr
 struct Trace {
   bool on;
-  double t0, last;
+  double t0, last, cpu_last;
   unsigned long tid;   // proofs in flight on other threads: their lines interleave
-  Trace() : on(getenv("ZKFHE_TRACE") != nullptr), t0(now_ms()), last(t0), tid((unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) % 10000) {}
+  static double thread_cpu_ms() {   // CPU time of the calling thread: what of a phase was work on this core and what was waiting
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  }
+  Trace() : on(getenv("ZKFHE_TRACE") != nullptr), t0(now_ms()), last(t0), cpu_last(on ? thread_cpu_ms() : 0), tid((unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()) % 10000) {}
   void mark(const char *what) {
     if (!on) return;
-    const double t = now_ms();
-    fprintf(stderr, "[zkfhe trace %04lu] %8.3f ms (+%7.3f) %s\n", tid, t - t0, t - last, what);
+    const double t = now_ms(), c = thread_cpu_ms();
+    fprintf(stderr, "[zkfhe trace %04lu] %8.3f ms (+%7.3f, cpu %6.3f) %s\n", tid, t - t0, t - last, c - cpu_last, what);
     last = t;
+    cpu_last = c;
   }
 };
 

@@ -2,6 +2,7 @@
 // workspace, small host helpers.  Not part of the public ABI.
 #pragma once
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstring>
 #include <map>
