@@ -134,7 +134,7 @@ def main():
                     help="announce every proof's input one proof ahead (zkfhe_bfv_pk_prehash: the sponge over its 5 N + 1 public inputs runs on a host thread "
                          "while the previous proof is on the GPU) -- auto: with the Poseidon transcript and at most 8 proofs in flight; never on the driver's wave of 20")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-traffic-pass", action="store_true", help="do not measure roofline.traffic with two child rocprofv3 --pmc passes (N = 1, k13 only; ~1.5 min): "
+    ap.add_argument("--no-traffic-pass", action="store_true", help="do not measure roofline.traffic with two child rocprofv3 --pmc passes (N = 1, k13 only; ~20 s): "
                                                                    "take it from the committed pass under profiles/")
     ap.add_argument("--stagger-ms", type=float, default=None, help="start offset between the concurrent proofs of the timed wave")
     ap.add_argument("--transcript", choices=["poseidon", "blake2b"], default="poseidon",
