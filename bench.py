@@ -345,7 +345,10 @@ def main():
             c.sync()
         cold = jobs * args.steps / batch.max_over_ranks(time.perf_counter() - tc, device=dev)
         si += args.steps
-        pk.prefix_cache(8)
+        try:
+            pk.prefix_cache(max(0, min(64, int(os.environ.get("ZKFHE_PREFIX_CACHE", "8")))))   # back to what the run had (library default: 8)
+        except ValueError:
+            pk.prefix_cache(8)
 
     # dominant kernel timed live with HIP events on the library's stream, in a separate untimed pass: k_msm_table (the sum of
     # table points of a commitment batch) when the SRS holds a digit-multiple table wide enough for such calls, else the
