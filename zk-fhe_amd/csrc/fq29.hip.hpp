@@ -22,24 +22,20 @@ struct F29 {
   u32 l[9];
 };
 
-// acc += a * b, the multiply-add of every nine-limb product.  Plain C by default.  -DZK_MAD_TIED (round-6 experiment, measured and
-// NOT adopted: profiles/r6_probes.md section 2) makes it one inline v_mad_u64_u32 / v_mad_i64_i32 on the RUNNING accumulator: in C,
-// LLVM's reassociation adds the previous column's carry last, so every column of a product starts in a register pair of its own and a
-// v_lshl_add_u64 joins it to the carry -- 17 of a product's ~240 instructions, up to eleven accumulator pairs in flight.  Tied to one
-// pair the joins go (k_msm_table's addition loop: 277 -> 39, k_ntt13: 246 -> 218 VGPRs), but gfx950 wants a wait state between two
-// DEPENDENT 64-bit multiply-adds and the compiler pays it with an s_nop after nearly every one: k_msm_table 2.5 % faster, k_ntt13 3 %
-// and k_msm_accumulate 1-3 % slower, a lone k = 13 proof 4 % slower.  The *_s forms take a wave-uniform constant (a limb of p) in an SGPR.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(ZK_MAD_TIED)
-__device__ __forceinline__ void zk_madu(u64 &acc, u32 a, u32 b) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
-__device__ __forceinline__ void zk_madu_s(u64 &acc, u32 a, u32 s) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(s) : "vcc"); }
-__device__ __forceinline__ void zk_madi(long long &acc, int a, int b) { asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
-__device__ __forceinline__ void zk_madi_s(long long &acc, int a, int s) { asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(s) : "vcc"); }
-#else
+// acc += a * b, the multiply-add of the nine-limb products' C bodies (the host pass, the native CPU checks, and -DZK_MAD_C).
+// ON THE DEVICE the products are generated inline assembly since round 6 (f29_tied.inc, lz29_tied.inc; tools/gen_tied_products.py): one
+// asm statement per COLUMN on the running accumulator.  Left to the compiler, `acc += (u64)a * b` after `acc >>= 29` is reassociated so
+// that the previous column's carry is added last: every column starts in a register pair of its own and a v_lshl_add_u64 joins it to the
+// carry -- 17 of a product's ~240 instructions, up to eleven accumulator pairs in flight.  Tied to one pair the joins go (k_msm_table's
+// addition loop: 277 -> 39; k_ntt13: 246 -> 220 VGPRs).  One statement per multiply-add was tried first and lost: the compiler cannot see
+// into an asm statement and puts a wait state before every VALU read of a register one defines (~150 s_nop per product); inside ONE
+// statement it inserts nothing, and the step m_k = (low word * inv) mod 2^29 between two statements costs one wait state per column.
+// Measured (profiles/r6_probes.md section 2): k_msm_table -6 %, k_msm_accumulate -3..4 %, k_ntt13 unchanged, the driver's wave +4.5 %,
+// 96 steps +4 %, one proof alone -2 % (faster), bit-exact.  -DZK_MAD_C (ZKFHE_EXTRA_FLAGS) restores the compiler's form.
 ZK_HD void zk_madu(u64 &acc, u32 a, u32 b) { acc += (u64)a * b; }
 ZK_HD void zk_madu_s(u64 &acc, u32 a, u32 s) { acc += (u64)a * s; }
 ZK_HD void zk_madi(long long &acc, int a, int b) { acc += (long long)a * (long long)b; }
 ZK_HD void zk_madi_s(long long &acc, int a, int s) { acc += (long long)a * (long long)s; }
-#endif
 
 namespace q29 {
 constexpr u32 MASK = (1u << 29) - 1;

@@ -102,6 +102,9 @@ ZK_HD LzW lz_weak(const Lz<LO, HI, V> &a) {
   return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MAD_C)
+#include "lz29_tied.inc"
+#endif
 // Montgomery product a * w / 2^261 mod r for |a w| < 2^261 r: value in (-r, 2 r).  Column k: nine |a_j| w_(k-j) < 2^30 2^29,
 // nine m_j r_(k-j) < 2^58 and the carry: magnitude below 9 2^59 + 9 2^58 + 2^35 < 2^63.
 // UNIFORM: the constant is the same for every lane of the wave (a butterfly constant, n^-1 -- loaded through a uniform address): its
@@ -110,6 +113,10 @@ template <bool UNIFORM = false, int LO, int HI, int V>
 ZK_HD LzT lz_mul(const Lz<LO, HI, V> &a, const Lw &b) {
   static_assert(LO <= 2 && HI <= 2, "product: limbs below 2^30 in magnitude");
   static_assert(V <= 160, "product: |a w| < 2^261 r");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MAD_C)
+  if (UNIFORM) return lz_mul_tied_s(a, b);
+  return lz_mul_tied_v(a, b);
+#endif
   constexpr u32 P[9] = ZK_R29_P;
   int m[9];
   LzT r;
@@ -146,6 +153,9 @@ template <int L1, int H1, int V, int L2, int H2, int V2>
 ZK_HD LzT lz_mul2(const Lz<L1, H1, V> &a, const Lw &w, const Lz<L2, H2, V2> &b, const Lw &v) {
   static_assert(L1 <= 1 && H1 <= 1 && L2 <= 1 && H2 <= 1, "two-product form: limbs below 2^29 in magnitude");
   static_assert(V + V2 <= 160, "two-product form: |a w + b v| < 2^261 r");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_MAD_C)
+  return lz_mul2_tied(a, w, b, v);
+#endif
   constexpr u32 P[9] = ZK_R29_P;
   int m[9];
   LzT r;
