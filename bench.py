@@ -278,6 +278,10 @@ def main():
         c.sync()
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("ZKFHE_TRACE"):   # the library's per-proof trace lines carry the same clock (steady_clock = CLOCK_MONOTONIC, ms)
+        t1m = time.monotonic() * 1e3
+        thr = [l.split()[1] for l in open("/sys/fs/cgroup/cpu.stat") if l.startswith(("nr_throttled", "throttled_usec"))] if os.path.exists("/sys/fs/cgroup/cpu.stat") else []
+        sys.stderr.write("[bench trace] timed region @%.3f .. @%.3f (%.3f ms), cgroup nr_throttled / throttled_usec so far: %s\n" % (t1m - dt * 1e3, t1m, dt * 1e3, " / ".join(thr)))
     host_cpu_ms = (time.process_time() - cpu0) * 1e3 / max(1, args.steps)   # all threads of this rank
     # the per-public-key transcript cache over the timed region (host/prefix_cache.hpp: the sponge state behind vk digest | pk0 | pk1,
     # nothing beyond the public key): the bench cycles four inputs = four public keys, all remembered after the warm-up

@@ -527,7 +527,7 @@ struct Trace {
   void mark(const char *what) {
     if (!on) return;
     const double t = now_ms(), c = thread_cpu_ms();
-    fprintf(stderr, "[zkfhe trace %04lu] %8.3f ms (+%7.3f, cpu %6.3f) %s\n", tid, t - t0, t - last, c - cpu_last, what);
+    fprintf(stderr, "[zkfhe trace %04lu] %8.3f ms (+%7.3f, cpu %6.3f) %s @%.3f\n", tid, t - t0, t - last, c - cpu_last, what, t);
     last = t;
     cpu_last = c;
   }
