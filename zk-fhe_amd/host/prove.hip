@@ -639,10 +639,18 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     inst_staged = staged;
   }
   auto blind_and_upload = [&](unsigned c_lo, unsigned c_hi) -> int {
-    // the table is pinned and column-contiguous: one DMA for the whole phase; the blinding rows u .. n-1 are drawn on the device
-    ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c_lo * n, as.t.advice[c_lo], (size_t)(c_hi - c_lo) * n * 32, hipMemcpyHostToDevice, ctx->stream));
-    CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
-                        (size_t)(c_hi - c_lo) * n));
+    // the table is pinned and column-contiguous; the blinding rows u .. n-1 are drawn on the device.  The conversion kernel reads the
+    // pinned table itself (hipHostMalloc memory is mapped into the device's address space): no copy command on the stream -- with twenty
+    // proofs starting together the runtime's copy path cost each of them 2-5 ms of CPU before their first kernel (ZKFHE_UPLOAD=copy: one
+    // DMA for the whole phase, then the conversion in place)
+    static const bool upload_by_copy = getenv("ZKFHE_UPLOAD") && !strcmp(getenv("ZKFHE_UPLOAD"), "copy");
+    if (upload_by_copy) {
+      ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c_lo * n, as.t.advice[c_lo], (size_t)(c_hi - c_lo) * n * 32, hipMemcpyHostToDevice, ctx->stream));
+      CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
+                          (size_t)(c_hi - c_lo) * n));
+    } else {
+      CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)as.t.advice[c_lo], (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (size_t)(c_hi - c_lo) * n));
+    }
     return rng_fill(ctx->stream, ctr_adv + (uint64_t)c_lo * nbl_all, nbl_all, ws->adv_l.fr() + (size_t)c_lo * n + u, nbl_all, n, c_hi - c_lo);
   };
   std::vector<AffinePoint> adv_commit(cfg.n_advice()), pts;
