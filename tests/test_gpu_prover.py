@@ -244,9 +244,16 @@ def test_device_and_host_witness_generators_agree(ctx):
             plain, inst_e, _ = pk.prove(text, b"w-%d" % i)
             os.environ.pop("ZKFHE_EARLY_P1", None)
             assert inst_e == inst_d and first_diff(plain, dev) is None
+            # The phase-0 / RLC columns reach the device through a kernel that reads the pinned witness table (round 6);
+            # ZKFHE_UPLOAD=copy keeps the copy command + in-place conversion it replaced
+            os.environ["ZKFHE_UPLOAD"] = "copy"
+            copied, inst_c, _ = pk.prove(text, b"w-%d" % i)
+            os.environ.pop("ZKFHE_UPLOAD", None)
+            assert inst_c == inst_d and first_diff(copied, dev) is None
     finally:
         os.environ.pop("ZKFHE_WITNESS", None)
         os.environ.pop("ZKFHE_EARLY_P1", None)
+        os.environ.pop("ZKFHE_UPLOAD", None)
     pk.destroy()
     srs.destroy()
 

@@ -643,7 +643,8 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     // pinned table itself (hipHostMalloc memory is mapped into the device's address space): no copy command on the stream -- with twenty
     // proofs starting together the runtime's copy path cost each of them 2-5 ms of CPU before their first kernel (ZKFHE_UPLOAD=copy: one
     // DMA for the whole phase, then the conversion in place)
-    static const bool upload_by_copy = getenv("ZKFHE_UPLOAD") && !strcmp(getenv("ZKFHE_UPLOAD"), "copy");
+    const char *upload_env = getenv("ZKFHE_UPLOAD");   // read per proof, like ZKFHE_WITNESS / ZKFHE_EARLY_P1 (the tests switch it)
+    const bool upload_by_copy = upload_env && !strcmp(upload_env, "copy");
     if (upload_by_copy) {
       ZK_HIP(ctx, hipMemcpyAsync(ws->adv_l.fr() + (size_t)c_lo * n, as.t.advice[c_lo], (size_t)(c_hi - c_lo) * n * 32, hipMemcpyHostToDevice, ctx->stream));
       CK(zkfhe_fr_to_mont(ctx, (const zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n), (zkfhe_fr *)(ws->adv_l.fr() + (size_t)c_lo * n),
