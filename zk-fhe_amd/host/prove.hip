@@ -1254,6 +1254,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
     // canonical values straight into pinned memory (the conversion kernel stores them there): no copy command
     CK(zkfhe_fr_from_mont(ctx, (const zkfhe_fr *)od.p, (zkfhe_fr *)ws->out_ev(), jobs.size() * 4));
     ZK_HIP(ctx, zk_wait(ctx));
+    trace.mark("evaluations (GPU)");
     const U256 *ev = ws->out_ev();
     for (size_t i = 0; i < items.size(); ++i)
       for (int r = 0; r < items[i].n_rot; ++r) items[i].ev[r] = ev[i * 4 + r];
@@ -1271,6 +1272,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   }
   // ------------------------------------------------------------ SHPLONK (halo2 ProverSHPLONK; Lagrange form, commitments are basis independent)
   const Fr yq = mont(tr.squeeze());
+  trace.mark("transcript: evaluations");
   std::vector<int> all_rots;
   const std::vector<OpenSet> sets = intermediate_sets(layout, open_queries(cfg, layout), all_rots);
   const size_t ns = sets.size();
@@ -1383,6 +1385,7 @@ int prove_impl(zkfhe_ctx *ctx, const zkfhe_srs *srs, zkfhe_bfv_pk *pk, const cha
   CK(commit_cols_out(ctx, srs, srs->g_lagrange, hq, 1, ws, hq_commit));
   tr.write_point(hq_commit[0]);
   const Fr uu = mont(tr.squeeze());
+  trace.mark("shplonk h (GPU)");
   {
     Fr ztu = Fr::one();
     for (int r : all_rots) ztu = ztu * (uu - pts_rot[r]);
